@@ -1,0 +1,117 @@
+/* lctvqa.h -- C ABI of the MI355X (gfx950) kernels behind the VQA train-step hot path.
+ *
+ * Library: lct_vqa_amd/_C/liblctvqa_hip.so (built by `python -m lct_vqa_amd.build`).
+ *
+ * The reference (aahamed/LCT-VQA) is pure Python/PyTorch: it has no FFI of its own.  The
+ * boundary a maintainer binds is therefore the set of tensor ops that torch.nn dispatches for
+ * the path named in BASELINE.json; every entry point below names the reference line whose
+ * ATen/cuDNN/cuBLAS dispatch it replaces.  Conventions:
+ *   - all pointers are DEVICE pointers (hipMalloc'ed / torch CUDA tensors' data_ptr()),
+ *     fp32 unless stated; `long` is 64-bit (torch.int64 index tensors);
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); calls are asynchronous;
+ *   - return 0 on success, <0 for invalid arguments (LCT_E*), >0 = hipError_t; the message
+ *     is available from lctvqa_last_error() (thread local);
+ *   - no call allocates, frees or synchronises: workspaces are caller-owned (graph-capturable).
+ * See INTEGRATION.md for the ctypes binding used by lct_vqa_amd and for the binding a
+ * maintainer of the reference would add.
+ */
+#ifndef LCTVQA_H
+#define LCTVQA_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCTVQA_OK 0
+#define LCTVQA_EINVAL (-1)
+#define LCTVQA_EUNSUPPORTED (-2)
+#define LCTVQA_EWORKSPACE (-3)
+
+int lctvqa_version(void);
+const char* lctvqa_last_error(void);
+int lctvqa_device_count(void);
+
+/* ---- VGG19 trunk: torchvision vgg19.features/avgpool as called at basic_vqa/models.py:36,
+ *      models_lct.py:61-63, darts_vqa/vqa_model.py:28-32.  Activations are NHWC. ---------- */
+
+/* elements of the packed weight buffer for a Cout x Cin x 3 x 3 filter bank */
+long lctvqa_conv3x3_packed_elems(int Cout, int Cin);
+/* 1 if the MFMA kernel tiles this shape, 0 if the direct fallback kernel is used */
+int lctvqa_conv3x3_uses_mfma(int B, int H, int W, int Cin, int Cout, int pool);
+/* OIHW parameter -> [Cout/32][(Cin/16)*9][4][32][4] step tiles (run every forward: parameters
+ * are read by pointer each call, see architect_lct.py:142-155,194-207) */
+int lctvqa_conv3x3_pack_weights(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream);
+/* nn.Conv2d(Cin,Cout,3,padding=1) + ReLU (+ MaxPool2d(2,2) when pool) on NHWC activations.
+ * y: [B,H,W,Cout] or [B,H/2,W/2,Cout].  pool_tmp ([B,H,W,Cout]) is only used by the fallback. */
+int lctvqa_conv3x3_nhwc(const float* x, const float* w_oihw, const float* w_packed, const float* bias, float* y,
+                        float* pool_tmp, int B, int H, int W, int Cin, int Cout, int relu, int pool, void* stream);
+/* first layer: NCHW image [B,3,H,W] (the layout the reference's loaders produce,
+ * data_loader_v2.py:82-86) -> NHWC [B,H,W,Cout], conv3x3 + bias + ReLU */
+int lctvqa_conv3x3_first_nchw(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc, int B,
+                              int H, int W, int Cout, int relu, void* stream);
+int lctvqa_maxpool2x2_nhwc(const float* x, float* y, int B, int H, int W, int C, void* stream);
+/* AdaptiveAvgPool2d((7,7)) + torch.flatten(x,1) in NCHW feature order: NHWC -> [B, C*49] */
+int lctvqa_adaptive_avgpool7_flatten(const float* x_nhwc, float* y, int B, int H, int W, int C, void* stream);
+
+/* ---- GEMM: every nn.Linear on the path (models.py:29,37,53,66,80,81; models_lct.py:87-88)
+ *      and both of its backward products, via operand strides.
+ *      C[m][n] = mask*mask_scale*act(sum_k A[m*a_ms+k*a_ks]*B[n*b_ns+k*b_ks] + bias[n] + addend[m][n])
+ *      act: 0 none, 1 relu, 2 tanh.  bias/addend/mask may be NULL. ------------------------ */
+long lctvqa_gemm_workspace_bytes(int M, int N, int K);
+int lctvqa_gemm_f32(const float* A, long a_ms, long a_ks, const float* B, long b_ns, long b_ks, float* C, long ldc,
+                    int M, int N, int K, const float* bias, const float* addend, long ld_add, int act,
+                    const uint8_t* mask, long ld_mask, float mask_scale, float* workspace, long workspace_bytes,
+                    void* stream);
+/* out[n] = sum_m X[m][n]  (bias gradients) */
+int lctvqa_colsum_f32(const float* X, long ld, int M, int N, float* out, void* stream);
+
+/* ---- question encoder: nn.Embedding + tanh + nn.LSTM (models.py:58-61, models_lct.py:101-108) */
+/* idx [B][T] int64 -> out [T][B][E] = (tanh) emb[idx]  (transpose(0,1) fused) */
+int lctvqa_embed_gather(const long* idx, const float* emb, float* out, int B, int T, int E, int V, int apply_tanh, void* stream);
+/* demb[idx[b,t]] += dy[t,b,:] * (apply_tanh ? 1-y^2 : 1)   (dense grad; demb pre-zeroed) */
+int lctvqa_embed_scatter_add(const long* idx, const float* dy, const float* y, float* demb, int B, int T, int E, int V,
+                             int apply_tanh, void* stream);
+/* one LSTM time step, gate order i,f,g,o.  pre-activations = xp + hp, each [B][4H] */
+int lctvqa_lstm_cell_fwd(const float* xp, const float* hp, const float* c_prev, float* gates, float* c_out, float* h_out,
+                         int B, int H, void* stream);
+int lctvqa_lstm_cell_bwd(const float* dh_rec, const float* dh_ext, const float* dc_next, const float* gates,
+                         const float* c_prev, const float* c_cur, float* dgates, float* dc_prev, int B, int H, void* stream);
+/* tanh(cat(h,c)) of models.py:62-65 (num_layers = 1) and its backward */
+int lctvqa_cat_tanh_fwd(const float* h, const float* c, float* out, int B, int H, void* stream);
+int lctvqa_cat_tanh_bwd(const float* dy, const float* y, float* dh, float* dc, int B, int H, void* stream);
+int lctvqa_tanh_fwd(const float* x, float* y, long n, void* stream);
+/* backward of the GEMM epilogue: dx = dy * mask*scale * act'(.) with y = the epilogue's output */
+int lctvqa_act_bwd(const float* dy, const float* y, const uint8_t* mask, float scale, float* dx, long n, int act, void* stream);
+
+/* ---- fusion head: mul -> tanh -> dropout (models.py:96-98) and image-feature L2 norm (models.py:39-40) */
+int lctvqa_mul_tanh_drop_fwd(const float* a, const float* b, const uint8_t* mask, float scale, float* t, float* z, long n, void* stream);
+int lctvqa_mul_tanh_drop_bwd(const float* dz, const float* a, const float* b, const float* t, const uint8_t* mask, float scale,
+                             float* da, float* db, long n, void* stream);
+int lctvqa_l2norm_rows_fwd(const float* x, float* y, float* inv_norm, int M, int N, void* stream);
+int lctvqa_scale_rows(const float* x, const float* s, float* y, int M, int N, void* stream);
+
+/* ---- losses: nn.CrossEntropyLoss (kind 0) and softXEnt (kind 1), models.py:7-10,89,115-125.
+ *      loss_out[0] = loss_scale * sum_rows;  dlogits (optional) = gscale * d(row loss)/d logits */
+int lctvqa_xent(const float* logits, long ld, const long* labels, const float* target, long ldt, float* row_loss,
+                float* loss_out, float loss_scale, float* dlogits, long ldd, float gscale, int M, int N, int kind, void* stream);
+/* F.softmax(x * inv_temp, dim=1)  (experiment.py:245, architect_lct.py:55) */
+int lctvqa_softmax_rows(const float* x, float* y, int M, int N, float inv_temp, void* stream);
+/* torch.argmax(x, 1) (first maximal index) -> int64  (models_lct.py:161, experiment.py:218) */
+int lctvqa_argmax_rows(const float* x, long ld, int M, int N, long* out, void* stream);
+/* nn.Dropout keep mask from a counter-based generator: mask[i] = U(seed, offset+i) >= p */
+int lctvqa_dropout_mask(uint8_t* mask, long n, unsigned long long seed, unsigned long long offset, float p, void* stream);
+
+/* ---- optimiser on a flat parameter arena: clip_grad_norm_(5) + Adam (experiment.py:226-227,
+ *      model_factory.py:20-21) and the architects' vector ops (architect_lct.py:112-116) ---- */
+int lctvqa_grad_norm(const float* g, long n, float* scratch /* >=1024 floats */, float* total_norm_out, void* stream);
+int lctvqa_adam_step(float* p, const float* g, float* m, float* v, long n, const float* total_norm /* or NULL */,
+                     float max_norm, float lr, float b1, float b2, float eps, int step, float weight_decay, void* stream);
+int lctvqa_axpy(float a, const float* x, float* y, long n, void* stream);
+int lctvqa_scale(float a, float* y, long n, void* stream);
+/* y = x * a[0], scalar read from device memory (grad_output of a scalar loss; no host sync) */
+int lctvqa_scale_by_device_scalar(const float* a, const float* x, float* y, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCTVQA_H */

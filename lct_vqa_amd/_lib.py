@@ -1,0 +1,96 @@
+"""ctypes binding of include/lctvqa.h (single source of truth: the header is parsed for the
+argument types).  The product path has NO fallback: if the HIP library is missing or a call
+fails, this raises."""
+import ctypes
+import os
+import re
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), 'include', 'lctvqa.h')
+LIB_PATH = os.path.join(HERE, '_C', 'liblctvqa_hip.so')
+
+_CT = {
+    'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float,
+    'unsigned long long': ctypes.c_ulonglong,
+}
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes])} for every function declared in the header."""
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
+    src = re.sub(r'//[^\n]*', ' ', src)
+    out = {}
+    for m in re.finditer(r'\b(int|long|const char\s*\*)\s+(lctvqa_\w+)\s*\(([^)]*)\)\s*;', src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        restype = ctypes.c_char_p if 'char' in ret else _CT[ret]
+        argtypes = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                if '*' in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    ty = ' '.join(a.split()[:-1])
+                    argtypes.append(_CT[ty])
+        out[name] = (restype, argtypes)
+    return out
+
+
+class _Lib:
+    def __init__(self):
+        self._dll = None
+        self._sigs = parse_header()
+
+    def load(self):
+        if self._dll is not None:
+            return self._dll
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f'{LIB_PATH} not found: build it with `python -m lct_vqa_amd.build` '
+                '(hipcc --offload-arch=gfx950).  lct_vqa_amd has no CPU/eager fallback.')
+        dll = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in self._sigs.items():
+            fn = getattr(dll, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        self._dll = dll
+        return dll
+
+    def last_error(self):
+        return self.load().lctvqa_last_error().decode()
+
+    def raw(self, name):
+        return getattr(self.load(), 'lctvqa_' + name)
+
+    def query(self, name, *args):
+        """Call a value-returning entry point (no error convention, no stream)."""
+        return self.raw(name)(*args)
+
+    def __call__(self, name, *args):
+        """Call lctvqa_<name>; tensors are passed as device pointers; the current torch stream is
+        appended when the C signature ends in `void* stream` and it was not given."""
+        fn = self.raw(name)
+        conv = []
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                conv.append(ctypes.c_void_p(a.data_ptr()))
+            elif a is None:
+                conv.append(None)
+            else:
+                conv.append(a)
+        if len(conv) == len(fn.argtypes) - 1:
+            conv.append(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = fn(*conv)
+        if fn.restype is ctypes.c_int and rc != 0:
+            raise RuntimeError(f'lctvqa_{name} failed (rc={rc}): {self.last_error()}')
+        return rc
+
+
+lib = _Lib()

@@ -1,0 +1,107 @@
+"""W model (plain VQA model): same classes, constructor signatures, attribute names and
+state_dict keys as reference basic_vqa/models.py:7-125; forward/backward run in the HIP library."""
+import torch
+import torch.nn as nn
+
+from .. import ops, vgg
+from . import config as _config
+
+
+def softXEnt(pred, target):
+    """Soft cross entropy loss (reference models.py:7-10)."""
+    return ops.soft_xent(pred, target)
+
+
+class ImgEncoder(nn.Module):
+    """Frozen VGG19 (minus last fc) -> fc -> / detached L2 norm (reference models.py:12-42)."""
+
+    def __init__(self, embed_size):
+        super(ImgEncoder, self).__init__()
+        model = vgg.vgg19(pretrained=True)
+        in_features = model.classifier[-1].in_features
+        model.classifier = nn.Sequential(*list(model.classifier.children())[:-1])
+        self.model = model
+        self.fc = nn.Linear(in_features, embed_size)
+
+    def forward(self, image):
+        with torch.no_grad():
+            img_feature = self.model(image)
+        img_feature = ops.linear(img_feature, self.fc.weight, self.fc.bias)
+        return ops.L2NormFn.apply(img_feature)
+
+
+def _single_layer(lstm):
+    if lstm.num_layers != 1:
+        raise NotImplementedError('lct_vqa_amd: the HIP LSTM path implements num_layers == 1 '
+                                  '(the reference default, config.py:22)')
+    return lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0
+
+
+class QstEncoder(nn.Module):
+    """Embedding -> tanh -> LSTM -> cat(h,c) -> tanh -> fc (reference models.py:45-68)."""
+
+    def __init__(self, qst_vocab_size, word_embed_size, embed_size, num_layers, hidden_size):
+        super(QstEncoder, self).__init__()
+        self.word2vec = nn.Embedding(qst_vocab_size, word_embed_size)
+        self.tanh = nn.Tanh()
+        self.lstm = nn.LSTM(word_embed_size, hidden_size, num_layers)
+        self.fc = nn.Linear(2 * num_layers * hidden_size, embed_size)
+
+    def forward(self, question):
+        qst_vec = ops.embed(question, self.word2vec.weight, True)        # [T,B,We], tanh fused
+        _, hidden, cell = ops.lstm(qst_vec, *_single_layer(self.lstm))
+        qst_feature = ops.CatTanhFn.apply(hidden, cell)
+        return ops.linear(qst_feature, self.fc.weight, self.fc.bias)
+
+
+class VqaModel(nn.Module):
+
+    def __init__(self, embed_size, qst_vocab_size, ans_vocab_size, word_embed_size, num_layers, hidden_size):
+        super(VqaModel, self).__init__()
+        self.img_encoder = ImgEncoder(embed_size)
+        self.qst_encoder = QstEncoder(qst_vocab_size, word_embed_size, embed_size, num_layers, hidden_size)
+        self.tanh = nn.Tanh()
+        self.dropout = nn.Dropout(0.5)
+        self.fc1 = nn.Linear(embed_size, ans_vocab_size)
+        self.fc2 = nn.Linear(ans_vocab_size, ans_vocab_size)
+        self.embed_size = embed_size
+        self.qst_vocab_size = qst_vocab_size
+        self.ans_vocab_size = ans_vocab_size
+        self.word_embed_size = word_embed_size
+        self.num_layers = num_layers
+        self.hidden_size = hidden_size
+        self.criterion = nn.CrossEntropyLoss()
+
+    def _head(self, img_feature, qst_feature):
+        """mul -> tanh -> dropout -> fc1 -> tanh -> dropout -> fc2 (reference models.py:96-102)."""
+        p = self.dropout.p
+        train = self.training and p > 0
+        dev = img_feature.device
+        scale = 1.0 / (1.0 - p) if train else 1.0
+        m1 = ops.dropout_mask(tuple(img_feature.shape), dev, p) if train else None
+        z = ops.MulTanhDropFn.apply(img_feature, qst_feature, m1, scale)
+        m2 = ops.dropout_mask((z.shape[0], self.fc1.out_features), dev, p) if train else None
+        z = ops.linear(z, self.fc1.weight, self.fc1.bias, ops.ACT_TANH, m2, scale)
+        return ops.linear(z, self.fc2.weight, self.fc2.bias)
+
+    def forward(self, img, qst):
+        img_feature = self.img_encoder(img)
+        qst_feature = self.qst_encoder(qst)
+        return self._head(img_feature, qst_feature)
+
+    def new(self):
+        new_model = VqaModel(self.embed_size, self.qst_vocab_size, self.ans_vocab_size,
+                             self.word_embed_size, self.num_layers, self.hidden_size)
+        new_model.to(_config.active().DEVICE)
+        return new_model
+
+    def _loss(self, images, questions, labels):
+        ans_out = self(images, questions)
+        return ops.cross_entropy(ans_out, labels)
+
+    def _soft_loss(self, images, questions, labels, pseudo_qst, pseudo_labels):
+        ans_out_1 = self(images, questions)
+        loss_1 = ops.cross_entropy(ans_out_1, labels)
+        ans_out_2 = self(images, pseudo_qst)
+        loss_2 = softXEnt(ans_out_2, pseudo_labels)
+        return loss_1 + _config.active().W_LAMBDA * loss_2

@@ -1,0 +1,44 @@
+// Shared helpers for the gfx950 (MI355X / CDNA4) kernels of the VQA hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LCT_OK 0
+#define LCT_EINVAL (-1)
+#define LCT_EUNSUPPORTED (-2)
+#define LCT_EWORKSPACE (-3)
+
+void lct_set_error(const char* fmt, ...);
+int lct_check_launch(const char* what);
+
+#define LCT_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      lct_set_error(__VA_ARGS__);         \
+      return LCT_EINVAL;                  \
+    }                                     \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// async global -> LDS copy, 16 B per lane.  LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

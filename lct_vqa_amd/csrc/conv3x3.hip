@@ -1,0 +1,495 @@
+// 3x3 / stride 1 / pad 1 convolution for the VGG19 trunk on gfx950, fp32 in / fp32 accumulate.
+//
+// Replaces the cuDNN/ATen dispatch behind torchvision vgg19.features as called at
+// reference basic_vqa/models.py:36 and basic_vqa/models_lct.py:61-63.
+//
+// Design (MI355X-first, not a GEMM library call, no im2col buffer):
+//  * activations are NHWC fp32 in HBM ("stacked rows": R = n*H + y, pixel = R*W + x);
+//  * implicit GEMM  M = pixels, N = Cout, K = 9*Cin on v_mfma_f32_32x32x2_f32
+//    (exact fp32 FMA chains, 64 FLOP/clk/SIMD -> 157.3 TFLOP/s chip peak);
+//  * a workgroup (4 waves) owns a TH x TW patch of output pixels and BN = 32*WN output
+//    channels.  For every 16-channel chunk of Cin the input HALO patch
+//    ((TH+2+gaps) x (TW+2) pixels x 16 ch, zero padding materialised at staging time)
+//    is brought HBM->LDS once with global_load_lds (no VGPR round trip) and reused by all
+//    9 filter taps; each (chunk, tap) step streams one pre-packed 2 KB x WN weight tile;
+//  * image boundaries inside a patch of stacked rows are handled by giving every image
+//    one shared all-zero LDS row after its last row ("expanded" row coordinate
+//    E = n*(H+1)+y), so the inner loop has no masks and no per-tap address math beyond
+//    one add + a 2-bit XOR swizzle;
+//  * LDS tiles are PLANAR per 16-B channel chunk: halo [4 chunks][pixel][4 ch], weights
+//    [4 chunks][32 cout][4 ch].  A lane's ds_read_b128 address is then
+//    (per-lane base) + (compile-time immediate for tap / k-group / buffer): consecutive
+//    lanes read consecutive 16-B slots (bank-conflict free) and the inner loop carries no
+//    address arithmetic at all.  The four waves of a workgroup each gather one chunk plane
+//    of the same 64 pixels, so the 64-B pixel segments are fetched from L2 once;
+//  * double-buffered halo + weight tiles, one barrier per (chunk, tap) step (64 MFMAs
+//    = 4096 cycles per wave), two workgroups per CU so one computes while the other waits;
+//  * n-tile = blockIdx % NT, so (blocks are dealt round-robin over the 8 XCDs) every XCD
+//    streams the weights of a single n-tile and keeps them in its private 4 MiB L2.
+//  * epilogue fuses bias + ReLU (+ 2x2 max-pool when requested) and writes NHWC.
+#include "common.h"
+
+__device__ __attribute__((aligned(64))) float g_zero_page[64];
+
+// ----------------------------------------------------------------------------------------
+// weight packing:  OIHW [Cout][Cin][3][3]  ->  [Cout/32][S = (Cin/16)*9][4 chunks][32 cout][4 ch]
+// Runs every call (parameters are read by pointer each time: the architects of the
+// reference overwrite parameters in place between forwards, architect_lct.py:142-155,194-207).
+// ----------------------------------------------------------------------------------------
+__global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin) {
+  const long total = (long)Cout * Cin * 9;
+  const int S = (Cin / 16) * 9;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    int e = o & 3;
+    int j = (o >> 2) & 31;
+    int c = (o >> 7) & 3;
+    long rest = o >> 9;
+    int s = rest % S;
+    int nt = rest / S;
+    int chunk = s / 9, tap = s % 9;
+    int co = nt * 32 + j;
+    int ci = chunk * 16 + c * 4 + e;
+    wp[o] = w[((long)co * Cin + ci) * 9 + tap];
+  }
+}
+
+// Pixel mapping inside a 32-row MFMA sub-tile.  A sub-tile covers SH x SW pixels (SH*SW = 32).
+// Row rr = 8a + 4hh + b of the MFMA C/D layout (reg = 4a + b, hh = lane>>5) is mapped so that the
+// four pixels of every 2x2 pooling window live in ONE lane (dx = b&1, dy = a&1): the fused
+// max-pool is then four in-register fmaxf, no LDS, no cross-lane traffic.
+template <int SH, int SW, int TW>
+__device__ __forceinline__ void subtile_pixel(int msub, int rr, int& ty, int& tx) {
+  static_assert(SH * SW == 32 && SH % 2 == 0 && SW % 2 == 0, "sub-tile shape");
+  const int a = rr >> 3, hh = (rr >> 2) & 1, b = rr & 3;
+  const int u = (a >> 1) * 4 + hh * 2 + (b >> 1);        // pooled cell 0..7
+  const int cx = u % (SW / 2), cy = u / (SW / 2);
+  const int sx = 2 * cx + (b & 1), sy = 2 * cy + (a & 1);
+  constexpr int SPR = TW / SW;                            // sub-tiles per patch row
+  ty = (msub / SPR) * SH + sy;
+  tx = (msub % SPR) * SW + sx;
+}
+
+template <int TH, int TW, int SH, int SW, int WM, int WN, int MT, bool POOL>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ y, int Btot, int H, int W, int Cin, int Cout, int relu, int G) {
+  static_assert(TH * TW == WM * MT * 32, "tile mismatch");
+  static_assert(TW % SW == 0 && TH % SH == 0, "sub-tile must tile the patch");
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int TWP = TW + 2;
+  constexpr int HRMAX = TH + 4;                       // TH + 2 halo + up to 2 gap rows
+  constexpr int PMAX = HRMAX * TWP;                   // halo pixels
+  constexpr int AROUNDS = (PMAX + 63) / 64;           // each wave gathers one chunk plane of 64 pixels per round
+  constexpr int PPAD = AROUNDS * 64;                  // pixels per plane (padded)
+  constexpr int PLANE = PPAD * 4;                     // floats per chunk plane
+  constexpr int ASZ = 4 * PLANE;                      // floats per halo buffer
+  constexpr int WSZ = WN * 512;                       // floats per weight step tile
+  constexpr int WCHUNKS = WN * 128;                   // 16-B chunks per weight step tile
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* abuf = smem;                // [2][ASZ]
+  float* wbuf = smem + 2 * ASZ;      // [2][WSZ]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int j = lane & 31, h = lane >> 5;
+
+  const int NT = Cout / (32 * WN);
+  const int n_tile = blockIdx.x % NT;
+  const int m_tile = blockIdx.x / NT;
+  const int CT = W / TW;
+  const int ct = m_tile % CT, rt = m_tile / CT;
+  const int R0 = rt * TH, x0 = ct * TW;
+  const int Rtot = Btot * H;
+  const int n0img = R0 / H, y0 = R0 % H;
+  const int NCH = Cin / 16;
+  const int S = NCH * 9;
+  const int PLIVE = (TH + 2 + G) * TWP;               // live halo pixels
+
+  // ---- per-lane source offsets of the halo staging (same for every channel chunk) ----
+  // round r: this lane gathers 16 B (channel chunk = wave id) of halo pixel p = r*64 + lane
+  int aoff[AROUNDS];
+#pragma unroll
+  for (int r = 0; r < AROUNDS; r++) {
+    int p = r * 64 + lane;
+    int hr = p / TWP, hx = p % TWP;
+    int xx = x0 - 1 + hx;
+    int yv = y0 - 1 + hr;
+    int n = n0img;
+    while (yv > H) { yv -= (H + 1); n++; }
+    bool ok = (p < PLIVE) && (yv >= 0) && (yv < H) && (n < Btot) && (xx >= 0) && (xx < W);
+    aoff[r] = ok ? (((n * H + yv) * W + xx) * Cin + wave * 4) : -1;
+  }
+  // ---- per-lane LDS pixel index (tap (0,0)) of each M-subtile row this lane feeds ----
+  int base[MT];
+#pragma unroll
+  for (int m = 0; m < MT; m++) {
+    int ty, tx;
+    subtile_pixel<SH, SW, TW>(wm * MT + m, j, ty, tx);
+    int yy = y0 + ty;
+    int g = (yy >= H) + (yy >= 2 * H);
+    base[m] = ((ty + g) * TWP + tx) * 4 + h * PLANE;     // float offset inside a halo buffer
+  }
+  const int bbase = wn * 512 + h * 128 + j * 4;           // float offset inside a weight step tile
+  const float* wsrc = wp + (long)(n_tile * WN) * S * 512;   // [WN pieces][S][512] -> piece stride S*512
+
+  auto stage_a = [&](int chunk, float* dst) {
+#pragma unroll
+    for (int r = 0; r < AROUNDS; r++) {
+      if (r * 64 < PLIVE) {
+        const float* src = (aoff[r] >= 0) ? (x + (long)aoff[r] + chunk * 16) : g_zero_page;
+        glds16(src, dst + wave * PLANE + r * 256);
+      }
+    }
+  };
+  auto stage_w = [&](int s, float* dst) {
+#pragma unroll
+    for (int r = 0; r < (WCHUNKS + 255) / 256; r++) {
+      int q = r * 256 + tid;
+      if (WCHUNKS >= 256 || tid < WCHUNKS) {
+        int piece = q >> 7, within = q & 127;
+        glds16(wsrc + ((long)piece * S + s) * 512 + within * 4, dst + (r * 256 + wave * 64) * 4);
+      }
+    }
+  };
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+
+  stage_a(0, abuf);
+  stage_w(0, wbuf);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int s = 0;
+  for (int chunk = 0; chunk < NCH; chunk++) {
+    const float* ab = abuf + (chunk & 1) * ASZ;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++, s++) {
+      if (s + 1 < S) stage_w(s + 1, wbuf + ((s + 1) & 1) * WSZ);
+      if (tap == 0 && chunk + 1 < NCH) stage_a(chunk + 1, abuf + ((chunk + 1) & 1) * ASZ);
+      const float* wb = wbuf + (s & 1) * WSZ + bbase;
+      const int tapoff = ((tap / 3) * TWP + (tap % 3)) * 4;
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++) {
+        const f32x4 bf = *(const f32x4*)(wb + kk * 256);
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+          const f32x4 af = *(const f32x4*)(ab + base[m] + tapoff + kk * 2 * PLANE);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], acc[m], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: bias + ReLU (+ in-register 2x2 max pool), NHWC store ----
+  const int co = (n_tile * WN + wn) * 32 + j;
+  const float bv = bias ? bias[co] : 0.f;
+  if (!POOL) {
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+        int ty, tx;
+        subtile_pixel<SH, SW, TW>(wm * MT + m, rr, ty, tx);
+        const int R = R0 + ty;
+        if (R < Rtot) {
+          float v = acc[m][r] + bv;
+          if (relu) v = fmaxf(v, 0.f);
+          y[((long)R * W + x0 + tx) * Cout + co] = v;
+        }
+      }
+    }
+  } else {
+    const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+#pragma unroll
+      for (int ap = 0; ap < 2; ap++) {
+#pragma unroll
+        for (int bp = 0; bp < 2; bp++) {
+          const int r00 = 8 * ap + 2 * bp;            // reg of (dy=0,dx=0): a = 2ap, b = 2bp
+          float v = fmaxf(fmaxf(acc[m][r00], acc[m][r00 + 1]), fmaxf(acc[m][r00 + 4], acc[m][r00 + 5])) + bv;
+          if (relu) v = fmaxf(v, 0.f);
+          const int rr = (2 * bp) + 8 * (2 * ap) + 4 * h;   // row of the window's (0,0) pixel
+          int ty, tx;
+          subtile_pixel<SH, SW, TW>(wm * MT + m, rr, ty, tx);
+          const int R = R0 + ty;
+          if (R < Rtot) {
+            const int n = R / H, yy = R % H;
+            const long opix = ((long)n * Ho + (yy >> 1)) * Wo + ((x0 + tx) >> 1);
+            y[opix * Cout + co] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// naive fallback for shapes the MFMA kernel does not tile (tiny test images, Cin % 16 != 0)
+__global__ void conv3x3_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                      const float* __restrict__ bias, float* __restrict__ y, int B, int H,
+                                      int W, int Cin, int Cout, int relu) {
+  long total = (long)B * H * W * Cout;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    int co = o % Cout;
+    long pix = o / Cout;
+    int xx = pix % W;
+    int yy = (pix / W) % H;
+    int n = pix / ((long)W * H);
+    float a = bias ? bias[co] : 0.f;
+    for (int ky = 0; ky < 3; ky++) {
+      int iy = yy + ky - 1;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; kx++) {
+        int ix = xx + kx - 1;
+        if (ix < 0 || ix >= W) continue;
+        const float* xp = x + (((long)n * H + iy) * W + ix) * Cin;
+        const float* wq = w + (long)co * Cin * 9 + ky * 3 + kx;
+        for (int ci = 0; ci < Cin; ci++) a = fmaf(xp[ci], wq[(long)ci * 9], a);
+      }
+    }
+    if (relu) a = fmaxf(a, 0.f);
+    y[o] = a;
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// first layer (Cin = 3, K = 27): bandwidth-bound, VALU.  NCHW image in -> NHWC out.
+// lane = output channel (Cout = 64 = one wave), a wave walks a strip of pixels of one row;
+// the 3 x 3 x (W+2) input rows of the strip are staged zero-padded in LDS and read as
+// wave-uniform broadcasts.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ y, int B, int H, int W,
+                                                            int Cout, int relu) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [3 ch][3 rows][W+2]
+  const int WP = W + 2;
+  const int R = blockIdx.x;             // stacked row n*H + y
+  const int n = R / H, yy = R % H;
+  for (int i = threadIdx.x; i < 9 * WP; i += blockDim.x) {
+    int c = i / (3 * WP), r = (i / WP) % 3, xx = i % WP - 1;
+    int iy = yy + r - 1;
+    float v = 0.f;
+    if (iy >= 0 && iy < H && xx >= 0 && xx < W) v = x[(((long)n * 3 + c) * H + iy) * W + xx];
+    smem[i] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int cg = 0; cg < Cout; cg += 64) {
+    const int co = cg + lane;
+    float wr[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) wr[k] = (co < Cout) ? w[co * 27 + k] : 0.f;   // [co][ci][ky][kx]
+    const float bv = (bias && co < Cout) ? bias[co] : 0.f;
+    for (int xx = wave; xx < W; xx += nw) {
+      float a = bv;
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int k = 0; k < 3; k++) a = fmaf(smem[(c * 3 + r) * WP + xx + k], wr[c * 9 + r * 3 + k], a);
+      if (relu) a = fmaxf(a, 0.f);
+      if (co < Cout) y[((long)R * W + xx) * Cout + co] = a;
+    }
+  }
+}
+
+__global__ void maxpool2x2_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W,
+                                       int C) {
+  const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+  long total = (long)B * Ho * Wo * C4;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    int c4 = o % C4;
+    long pix = o / C4;
+    int ox = pix % Wo;
+    int oy = (pix / Wo) % Ho;
+    int n = pix / ((long)Wo * Ho);
+    const f32x4* p = (const f32x4*)(x + (((long)n * H + 2 * oy) * W + 2 * ox) * C) + c4;
+    f32x4 a = p[0], b = p[C4], c = p[(long)W * C4], d = p[(long)W * C4 + C4];
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = fmaxf(fmaxf(a[k], b[k]), fmaxf(c[k], d[k]));
+    ((f32x4*)y)[o] = r;
+  }
+}
+
+// AdaptiveAvgPool2d((7,7)) + flatten in NCHW order (torchvision vgg19.avgpool + torch.flatten):
+// NHWC [B,H,W,C] -> [B, C*49] with feature index c*49 + oy*7 + ox.  Identity pooling at H=W=7.
+__global__ void adaptive_avgpool7_flatten_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H,
+                                                 int W, int C) {
+  long total = (long)B * C * 49;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    // iterate with c fastest for coalesced NHWC reads; scatter the (small) output
+    int c = o % C;
+    int cell = (o / C) % 49;
+    int n = o / ((long)C * 49);
+    int oy = cell / 7, ox = cell % 7;
+    int ys = (oy * H) / 7, ye = ((oy + 1) * H + 6) / 7;
+    int xs = (ox * W) / 7, xe = ((ox + 1) * W + 6) / 7;
+    float a = 0.f;
+    for (int iy = ys; iy < ye; iy++)
+      for (int ix = xs; ix < xe; ix++) a += x[(((long)n * H + iy) * W + ix) * C + c];
+    y[((long)n * C + c) * 49 + cell] = a / (float)((ye - ys) * (xe - xs));
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------
+static int max_boundaries(int H, int TH, long Rtot) {
+  // largest number of image boundaries strictly inside a tile of TH stacked rows starting at k*TH
+  int best = 0;
+  long lim = Rtot < (long)H * TH * 2 ? Rtot : (long)H * TH * 2;   // pattern repeats with lcm(H,TH) <= H*TH
+  for (long R0 = 0; R0 < lim; R0 += TH) {
+    int g = (int)((R0 + TH - 1) / H - R0 / H);
+    if (g > best) best = g;
+  }
+  return best;
+}
+
+template <int TH, int TW, int SH, int SW, int WM, int WN, int MT>
+static int launch_conv(const float* x, const float* wp, const float* bias, float* y, int B, int H, int W, int Cin,
+                       int Cout, int relu, int pool, int G, hipStream_t st) {
+  constexpr int TWP = TW + 2;
+  constexpr int AROUNDS = ((TH + 4) * TWP + 63) / 64;
+  constexpr int ASZ = AROUNDS * 64 * 16;
+  constexpr int WSZ = WN * 512;
+  size_t lds = (size_t)(2 * ASZ + 2 * WSZ) * sizeof(float);
+  long Rtot = (long)B * H;
+  int mtiles = cdiv(Rtot, TH) * (W / TW);
+  int ntiles = Cout / (32 * WN);
+  dim3 grid(mtiles * ntiles);
+  if (pool) {
+    auto k = conv3x3_mfma_kernel<TH, TW, SH, SW, WM, WN, MT, true>;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, wp, bias, y, B, H, W, Cin, Cout, relu, G);
+  } else {
+    auto k = conv3x3_mfma_kernel<TH, TW, SH, SW, WM, WN, MT, false>;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, wp, bias, y, B, H, W, Cin, Cout, relu, G);
+  }
+  return lct_check_launch("conv3x3_mfma");
+}
+
+extern "C" {
+
+long lctvqa_conv3x3_packed_elems(int Cout, int Cin) { return (long)Cout * Cin * 9; }
+
+// returns 1 when the MFMA kernel tiles this shape, 0 when the direct fallback is used
+int lctvqa_conv3x3_uses_mfma(int B, int H, int W, int Cin, int Cout, int pool) {
+  if (Cin % 16 || Cout % 64) return 0;
+  if (pool && ((H & 1) || (W & 1))) return 0;
+  long Rtot = (long)B * H;
+  int TH, TW;
+  if (W % 32 == 0) { TH = 8; TW = 32; }
+  else if (W % 28 == 0) { TH = 8; TW = 28; }
+  else if (W % 16 == 0) { TH = 16; TW = 16; }
+  else if (W % 14 == 0) { TH = 16; TW = 14; }
+  else if (W % 8 == 0) { TH = 32; TW = 8; }
+  else return 0;
+  if ((TH * TW) % 64 && Cout % 128) return 0;    // 224-pixel tiles only exist in the WN=4 layout
+  if (max_boundaries(H, TH, Rtot) > 2) return 0;
+  return 1;
+}
+
+int lctvqa_conv3x3_pack_weights(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream) {
+  LCT_REQUIRE(Cin % 16 == 0 && Cout % 32 == 0, "conv3x3_pack_weights: need Cin%%16==0, Cout%%32==0 (got %d,%d)", Cin, Cout);
+  long total = (long)Cout * Cin * 9;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(conv3x3_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, w_packed, Cout, Cin);
+  return lct_check_launch("conv3x3_pack");
+}
+
+// x NHWC [B,H,W,Cin] -> y NHWC [B,H,W,Cout] (or [B,H/2,W/2,Cout] when pool).  w_oihw is the
+// PyTorch parameter, w_packed the output of lctvqa_conv3x3_pack_weights (may be NULL when
+// the shape falls back to the direct kernel).
+int lctvqa_conv3x3_nhwc(const float* x, const float* w_oihw, const float* w_packed, const float* bias, float* y,
+                        float* pool_tmp, int B, int H, int W, int Cin, int Cout, int relu, int pool, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  LCT_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_nhwc: bad shape");
+  LCT_REQUIRE(!pool || (!(H & 1) && !(W & 1)), "conv3x3_nhwc: pooling needs even H,W");
+  if (!lctvqa_conv3x3_uses_mfma(B, H, W, Cin, Cout, pool)) {
+    float* dst = pool ? pool_tmp : y;
+    LCT_REQUIRE(dst != nullptr, "conv3x3_nhwc: pool_tmp required for the fallback path with pooling");
+    long total = (long)B * H * W * Cout;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(conv3x3_direct_kernel, dim3(blocks), dim3(256), 0, st, x, w_oihw, bias, dst, B, H, W, Cin, Cout, relu);
+    int rc = lct_check_launch("conv3x3_direct");
+    if (rc) return rc;
+    if (pool) {
+      long t2 = (long)B * (H / 2) * (W / 2) * (Cout / 4);
+      int b2 = (int)((t2 + 255) / 256);
+      if (b2 > 8192) b2 = 8192;
+      if (b2 < 1) b2 = 1;
+      hipLaunchKernelGGL(maxpool2x2_nhwc_kernel, dim3(b2), dim3(256), 0, st, dst, y, B, H, W, Cout);
+      return lct_check_launch("maxpool2x2");
+    }
+    return LCT_OK;
+  }
+  LCT_REQUIRE(w_packed != nullptr, "conv3x3_nhwc: packed weights required");
+  long Rtot = (long)B * H;
+  const bool n4 = (Cout % 128 == 0);
+#define LAUNCH(TH, TW, SH, SW)                                                                                          \
+  do {                                                                                                          \
+    int G = max_boundaries(H, TH, Rtot);                                                                        \
+    constexpr int BMs = (TH * TW) / 32;                                                                         \
+    if (n4) return launch_conv<TH, TW, SH, SW, 1, 4, BMs>(x, w_packed, bias, y, B, H, W, Cin, Cout, relu, pool, G, st); \
+    if constexpr (BMs % 2 == 0)                                                                                 \
+      return launch_conv<TH, TW, SH, SW, 2, 2, BMs / 2>(x, w_packed, bias, y, B, H, W, Cin, Cout, relu, pool, G, st);   \
+  } while (0)
+  if (W % 32 == 0) LAUNCH(8, 32, 2, 16);
+  else if (W % 28 == 0) LAUNCH(8, 28, 8, 4);
+  else if (W % 16 == 0) LAUNCH(16, 16, 2, 16);
+  else if (W % 14 == 0) LAUNCH(16, 14, 16, 2);
+  else if (W % 8 == 0) LAUNCH(32, 8, 4, 8);
+#undef LAUNCH
+  lct_set_error("conv3x3_nhwc: no tiling for H=%d W=%d Cin=%d Cout=%d", H, W, Cin, Cout);
+  return LCT_EUNSUPPORTED;
+}
+
+int lctvqa_conv3x3_first_nchw(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc, int B,
+                              int H, int W, int Cout, int relu, void* stream) {
+  LCT_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_first: bad shape");
+  size_t lds = (size_t)9 * (W + 2) * sizeof(float);
+  LCT_REQUIRE(lds <= 64 * 1024, "conv3x3_first: W too large");
+  hipLaunchKernelGGL(conv3x3_first_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, x_nchw, w_oihw, bias,
+                     y_nhwc, B, H, W, Cout, relu);
+  return lct_check_launch("conv3x3_first");
+}
+
+int lctvqa_maxpool2x2_nhwc(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+  LCT_REQUIRE(C % 4 == 0 && !(H & 1) && !(W & 1), "maxpool2x2: need C%%4==0 and even H,W");
+  long t = (long)B * (H / 2) * (W / 2) * (C / 4);
+  int b = (int)((t + 255) / 256);
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  hipLaunchKernelGGL(maxpool2x2_nhwc_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C);
+  return lct_check_launch("maxpool2x2");
+}
+
+int lctvqa_adaptive_avgpool7_flatten(const float* x_nhwc, float* y, int B, int H, int W, int C, void* stream) {
+  long t = (long)B * C * 49;
+  int b = (int)((t + 255) / 256);
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(adaptive_avgpool7_flatten_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, x_nhwc, y, B, H, W, C);
+  return lct_check_launch("adaptive_avgpool7_flatten");
+}
+
+}  // extern "C"

@@ -1,0 +1,478 @@
+// HBM-bound pointwise / gather / reduction kernels of the VQA head and the question encoder.
+// All of them are memory-bound: one pass, 16-B accesses where rows allow it, no reshaping into GEMMs.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// word2vec gather (+tanh) with the (B,T)->(T,B) transpose fused:  reference basic_vqa/models.py:58-60,
+// models_lct.py:101-104 (tanh) and models_lct.py:153-154 (no tanh for generated tokens).
+// idx [B][T] int64 -> out [T][B][E]
+// ------------------------------------------------------------------------------------------
+__global__ void embed_gather_kernel(const long* __restrict__ idx, const float* __restrict__ emb, float* __restrict__ out,
+                                    int B, int T, int E, int V, int apply_tanh) {
+  const int row = blockIdx.x;            // t*B + b
+  const int t = row / B, b = row % B;
+  long id = idx[(long)b * T + t];
+  if (id < 0 || id >= V) id = 0;         // host validates; stay in bounds regardless
+  const float* src = emb + id * E;
+  float* dst = out + (long)row * E;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float v = src[e];
+    dst[e] = apply_tanh ? tanhf(v) : v;
+  }
+}
+
+// backward: demb[idx[b,t]] += dy[t,b,:] * (1 - y^2)   (dense grad, nn.Embedding(sparse=False))
+__global__ void embed_scatter_kernel(const long* __restrict__ idx, const float* __restrict__ dy,
+                                     const float* __restrict__ y, float* __restrict__ demb, int B, int T, int E, int V,
+                                     int apply_tanh) {
+  const int row = blockIdx.x;
+  const int t = row / B, b = row % B;
+  long id = idx[(long)b * T + t];
+  if (id < 0 || id >= V) return;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float g = dy[(long)row * E + e];
+    if (apply_tanh) {
+      float v = y[(long)row * E + e];
+      g *= (1.f - v * v);
+    }
+    atomicAdd(demb + id * E + e, g);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LSTM cell pointwise (gate order i,f,g,o = nn.LSTM; reference basic_vqa/models.py:52,61).
+// pre = xp[b][4H] + hp[b][4H]  (xp already holds b_ih + b_hh)
+// ------------------------------------------------------------------------------------------
+__global__ void lstm_cell_fwd_kernel(const float* __restrict__ xp, const float* __restrict__ hp,
+                                     const float* __restrict__ c_prev, float* __restrict__ gates,
+                                     float* __restrict__ c_out, float* __restrict__ h_out, int B, int H) {
+  long total = (long)B * H;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    int u = o % H;
+    long b = o / H;
+    long g0 = b * 4 * H + u;
+    float i = sigmoidf_(xp[g0] + hp[g0]);
+    float f = sigmoidf_(xp[g0 + H] + hp[g0 + H]);
+    float g = tanhf(xp[g0 + 2 * H] + hp[g0 + 2 * H]);
+    float oo = sigmoidf_(xp[g0 + 3 * H] + hp[g0 + 3 * H]);
+    float c = f * c_prev[o] + i * g;
+    gates[g0] = i; gates[g0 + H] = f; gates[g0 + 2 * H] = g; gates[g0 + 3 * H] = oo;
+    c_out[o] = c;
+    h_out[o] = oo * tanhf(c);
+  }
+}
+
+// dh = dh_rec (from t+1 through W_hh, may be null) + dh_ext (from heads at this t, may be null)
+// dc = dc_next (may be null)
+__global__ void lstm_cell_bwd_kernel(const float* __restrict__ dh_rec, const float* __restrict__ dh_ext,
+                                     const float* __restrict__ dc_next, const float* __restrict__ gates,
+                                     const float* __restrict__ c_prev, const float* __restrict__ c_cur,
+                                     float* __restrict__ dgates, float* __restrict__ dc_prev, int B, int H) {
+  long total = (long)B * H;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    int u = o % H;
+    long b = o / H;
+    long g0 = b * 4 * H + u;
+    float i = gates[g0], f = gates[g0 + H], g = gates[g0 + 2 * H], oo = gates[g0 + 3 * H];
+    float dh = (dh_rec ? dh_rec[o] : 0.f) + (dh_ext ? dh_ext[o] : 0.f);
+    float tc = tanhf(c_cur[o]);
+    float dc = (dc_next ? dc_next[o] : 0.f) + dh * oo * (1.f - tc * tc);
+    dgates[g0] = dc * g * i * (1.f - i);
+    dgates[g0 + H] = dc * c_prev[o] * f * (1.f - f);
+    dgates[g0 + 2 * H] = dc * i * (1.f - g * g);
+    dgates[g0 + 3 * H] = dh * tc * oo * (1.f - oo);
+    dc_prev[o] = dc * f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic small pointwise ops
+// ------------------------------------------------------------------------------------------
+// out[b][0:H] = tanh(h[b]), out[b][H:2H] = tanh(c[b])   (models.py:62-65 with num_layers = 1)
+__global__ void cat_tanh_kernel(const float* __restrict__ h, const float* __restrict__ c, float* __restrict__ out, int B, int H) {
+  long total = (long)B * 2 * H;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    int k = o % (2 * H);
+    long b = o / (2 * H);
+    out[o] = tanhf(k < H ? h[b * H + k] : c[b * H + k - H]);
+  }
+}
+// dh[b] = dy[b][0:H]*(1-y^2), dc[b] = dy[b][H:2H]*(1-y^2)
+__global__ void cat_tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dh,
+                                    float* __restrict__ dc, int B, int H) {
+  long total = (long)B * 2 * H;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    int k = o % (2 * H);
+    long b = o / (2 * H);
+    float g = dy[o] * (1.f - y[o] * y[o]);
+    if (k < H) dh[b * H + k] = g; else dc[b * H + k - H] = g;
+  }
+}
+// y = tanh(x)
+__global__ void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) y[o] = tanhf(x[o]);
+}
+// dx = dy * (1 - y^2) * (mask ? mask*scale : 1)     [act = 2]
+// dx = dy * (y > 0)   * (mask ? mask*scale : 1)     [act = 1]
+// dx = dy             * (mask ? mask*scale : 1)     [act = 0]
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const uint8_t* __restrict__ mask,
+                               float scale, float* __restrict__ dx, long n, int act) {
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
+    float g = dy[o];
+    float v = y[o];
+    if (mask) {
+      if (mask[o]) { g *= scale; v = v / scale; } else { g = 0.f; v = 0.f; }   // y holds the post-mask value
+    }
+    if (act == 2) g *= (1.f - v * v);
+    else if (act == 1) g = (v > 0.f) ? g : 0.f;
+    dx[o] = g;
+  }
+}
+
+// z = mask*scale*tanh(a*b)   (reference basic_vqa/models.py:96-98); t = tanh(a*b) kept for backward
+__global__ void mul_tanh_drop_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                         const uint8_t* __restrict__ mask, float scale, float* __restrict__ t,
+                                         float* __restrict__ z, long n) {
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
+    float v = tanhf(a[o] * b[o]);
+    t[o] = v;
+    z[o] = mask ? (mask[o] ? v * scale : 0.f) : v;
+  }
+}
+__global__ void mul_tanh_drop_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ a,
+                                         const float* __restrict__ b, const float* __restrict__ t,
+                                         const uint8_t* __restrict__ mask, float scale, float* __restrict__ da,
+                                         float* __restrict__ db, long n) {
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
+    float g = dz[o];
+    if (mask) g = mask[o] ? g * scale : 0.f;
+    g *= (1.f - t[o] * t[o]);
+    if (da) da[o] = g * b[o];
+    if (db) db[o] = g * a[o];
+  }
+}
+
+// row-wise L2 normalisation with DETACHED norm (reference basic_vqa/models.py:39-40): y = x/||x||, inv = 1/||x||
+__global__ void l2norm_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv, int N) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  float s = 0.f;
+  for (int e = threadIdx.x; e < N; e += blockDim.x) { float v = x[row * N + e]; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  s = red[0] + red[1] + red[2] + red[3];
+  const float r = 1.f / sqrtf(s);
+  if (threadIdx.x == 0) inv[row] = r;
+  for (int e = threadIdx.x; e < N; e += blockDim.x) y[row * N + e] = x[row * N + e] * r;
+}
+__global__ void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y, int N, long n) {
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) y[o] = x[o] * s[o / N];
+}
+
+// ------------------------------------------------------------------------------------------
+// losses:  CrossEntropyLoss (mean) and softXEnt (reference basic_vqa/models.py:7-10,89,115).
+// One workgroup per row; writes per-row loss and (optionally) d logits scaled by gscale.
+// kind 0: hard labels (labels int64 [M]); kind 1: soft targets (target f32 [M][N]).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ labels,
+                                                       const float* __restrict__ target, long ldt, float* __restrict__ row_loss,
+                                                       float* __restrict__ dlogits, long ldd, float gscale, int N, int kind) {
+  __shared__ float red[4];
+  __shared__ float red2[4];
+  const long row = blockIdx.x;
+  const float* x = logits + row * ld;
+  float mx = -INFINITY;
+  for (int e = threadIdx.x; e < N; e += blockDim.x) mx = fmaxf(mx, x[e]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f, st = 0.f, stx = 0.f;
+  for (int e = threadIdx.x; e < N; e += blockDim.x) {
+    float v = x[e];
+    se += expf(v - mx);
+    if (kind == 1) { float t = target[row * ldt + e]; st += t; stx += t * v; }
+  }
+  se = wave_sum(se); st = wave_sum(st); stx = wave_sum(stx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = se;
+  __syncthreads();
+  se = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  if (kind == 1) {
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = st; red2[threadIdx.x >> 6] = stx; }
+    __syncthreads();
+    st = red[0] + red[1] + red[2] + red[3];
+    stx = red2[0] + red2[1] + red2[2] + red2[3];
+  }
+  const float lse = mx + logf(se);
+  long lab = 0;
+  if (kind == 0) { lab = labels[row]; if (lab < 0 || lab >= N) lab = 0; }
+  if (threadIdx.x == 0) row_loss[row] = (kind == 0) ? (lse - x[lab]) : (st * lse - stx);
+  if (dlogits) {
+    for (int e = threadIdx.x; e < N; e += blockDim.x) {
+      float p = expf(x[e] - lse);
+      float g = (kind == 0) ? (p - (e == lab ? 1.f : 0.f)) : (p * st - target[row * ldt + e]);
+      dlogits[row * ldd + e] = g * gscale;
+    }
+  }
+}
+
+// deterministic sum of n floats scaled (single workgroup): out[0] = scale * sum(x)
+__global__ __launch_bounds__(1024) void sum_scale_kernel(const float* __restrict__ x, long n, float scale, float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long o = threadIdx.x; o < n; o += blockDim.x) s += x[o];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += red[i];
+    out[0] = t * scale;
+  }
+}
+
+// row softmax with temperature (pseudo-label softmax: experiment.py:245, architect_lct.py:55)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int N, float inv_temp) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  float mx = -INFINITY;
+  for (int e = threadIdx.x; e < N; e += blockDim.x) mx = fmaxf(mx, x[row * N + e] * inv_temp);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int e = threadIdx.x; e < N; e += blockDim.x) se += expf(x[row * N + e] * inv_temp - mx);
+  se = wave_sum(se);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = se;
+  __syncthreads();
+  se = red[0] + red[1] + red[2] + red[3];
+  const float r = 1.f / se;
+  for (int e = threadIdx.x; e < N; e += blockDim.x) y[row * N + e] = expf(x[row * N + e] * inv_temp - mx) * r;
+}
+
+// row argmax (first maximal index, like torch.argmax) -> int64
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, long ld, int N, long* __restrict__ out) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const long row = blockIdx.x;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int e = threadIdx.x; e < N; e += blockDim.x) {
+    float v = x[row * ld + e];
+    if (v > best || (v == best && e < idx)) { best = v; idx = e; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++)
+      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    out[row] = idx;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// dropout keep-mask from a counter-based generator (seed, offset): mask[i] = U(i) >= p.
+// (PyTorch's CPU Bernoulli stream cannot be reproduced on the GPU; parity tests inject masks.)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (uint32_t)((z ^ (z >> 31)) >> 32);
+}
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ mask, long n, uint64_t seed, uint64_t offset, float p) {
+  const uint32_t thr = (uint32_t)(p * 4294967296.0);
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x)
+    mask[o] = mix32(seed * 0xD1342543DE82EF95ull + offset + (uint64_t)o) >= thr ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// optimiser: global grad-norm clip (clip_grad_norm_(5), experiment.py:226,256) + Adam
+// (model_factory.py:20-21,41-42) over ONE flat parameter arena: 16 B/param read + 12 B/param write.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) { float v = g[o]; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// norm_out[0] = sqrt(sum(part[0:np]) + extra_sq)
+__global__ void norm_finish_kernel(const float* __restrict__ part, int np, float* __restrict__ norm_out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < np; i += blockDim.x) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) norm_out[0] = sqrtf(red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, long n, const float* __restrict__ total_norm, float max_norm,
+                                 float lr, float b1, float b2, float eps, float bc1, float bc2, float wd) {
+  float coef = 1.f;
+  if (total_norm) {
+    coef = max_norm / (total_norm[0] + 1e-6f);
+    coef = coef < 1.f ? coef : 1.f;
+  }
+  const float step = lr / bc1, rs2 = 1.f / sqrtf(bc2);
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
+    float gg = g[o] * coef;
+    float pp = p[o];
+    if (wd != 0.f) gg += wd * pp;
+    float mm = b1 * m[o] + (1.f - b1) * gg;
+    float vv = b2 * v[o] + (1.f - b2) * gg * gg;
+    m[o] = mm; v[o] = vv;
+    p[o] = pp - step * mm / (sqrtf(vv) * rs2 + eps);
+  }
+}
+// y = a*x + y  (architect vector ops on the flat arena: architect_lct.py:112-116,194-207)
+__global__ void axpy_kernel(float a, const float* __restrict__ x, float* __restrict__ y, long n) {
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) y[o] = fmaf(a, x[o], y[o]);
+}
+__global__ void scale_kernel(float a, float* __restrict__ y, long n) {
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) y[o] *= a;
+}
+
+static inline int ew_blocks(long n, int per = 256) {
+  long b = (n + per - 1) / per;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" {
+
+int lctvqa_embed_gather(const long* idx, const float* emb, float* out, int B, int T, int E, int V, int apply_tanh, void* stream) {
+  LCT_REQUIRE(B > 0 && T > 0 && E > 0 && V > 0, "embed_gather: bad shape");
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(B * T), dim3(128), 0, (hipStream_t)stream, idx, emb, out, B, T, E, V, apply_tanh);
+  return lct_check_launch("embed_gather");
+}
+int lctvqa_embed_scatter_add(const long* idx, const float* dy, const float* y, float* demb, int B, int T, int E, int V,
+                             int apply_tanh, void* stream) {
+  LCT_REQUIRE(B > 0 && T > 0 && E > 0 && V > 0, "embed_scatter_add: bad shape");
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(B * T), dim3(128), 0, (hipStream_t)stream, idx, dy, y, demb, B, T, E, V, apply_tanh);
+  return lct_check_launch("embed_scatter_add");
+}
+int lctvqa_lstm_cell_fwd(const float* xp, const float* hp, const float* c_prev, float* gates, float* c_out, float* h_out,
+                         int B, int H, void* stream) {
+  LCT_REQUIRE(B > 0 && H > 0, "lstm_cell_fwd: bad shape");
+  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ew_blocks((long)B * H)), dim3(256), 0, (hipStream_t)stream, xp, hp, c_prev, gates, c_out, h_out, B, H);
+  return lct_check_launch("lstm_cell_fwd");
+}
+int lctvqa_lstm_cell_bwd(const float* dh_rec, const float* dh_ext, const float* dc_next, const float* gates,
+                         const float* c_prev, const float* c_cur, float* dgates, float* dc_prev, int B, int H, void* stream) {
+  LCT_REQUIRE(B > 0 && H > 0, "lstm_cell_bwd: bad shape");
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ew_blocks((long)B * H)), dim3(256), 0, (hipStream_t)stream, dh_rec, dh_ext, dc_next, gates, c_prev, c_cur, dgates, dc_prev, B, H);
+  return lct_check_launch("lstm_cell_bwd");
+}
+int lctvqa_cat_tanh_fwd(const float* h, const float* c, float* out, int B, int H, void* stream) {
+  hipLaunchKernelGGL(cat_tanh_kernel, dim3(ew_blocks((long)B * 2 * H)), dim3(256), 0, (hipStream_t)stream, h, c, out, B, H);
+  return lct_check_launch("cat_tanh_fwd");
+}
+int lctvqa_cat_tanh_bwd(const float* dy, const float* y, float* dh, float* dc, int B, int H, void* stream) {
+  hipLaunchKernelGGL(cat_tanh_bwd_kernel, dim3(ew_blocks((long)B * 2 * H)), dim3(256), 0, (hipStream_t)stream, dy, y, dh, dc, B, H);
+  return lct_check_launch("cat_tanh_bwd");
+}
+int lctvqa_tanh_fwd(const float* x, float* y, long n, void* stream) {
+  hipLaunchKernelGGL(tanh_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  return lct_check_launch("tanh_fwd");
+}
+int lctvqa_act_bwd(const float* dy, const float* y, const uint8_t* mask, float scale, float* dx, long n, int act, void* stream) {
+  LCT_REQUIRE(act >= 0 && act <= 2, "act_bwd: bad act");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, mask, scale, dx, n, act);
+  return lct_check_launch("act_bwd");
+}
+int lctvqa_mul_tanh_drop_fwd(const float* a, const float* b, const uint8_t* mask, float scale, float* t, float* z, long n, void* stream) {
+  hipLaunchKernelGGL(mul_tanh_drop_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, mask, scale, t, z, n);
+  return lct_check_launch("mul_tanh_drop_fwd");
+}
+int lctvqa_mul_tanh_drop_bwd(const float* dz, const float* a, const float* b, const float* t, const uint8_t* mask, float scale,
+                             float* da, float* db, long n, void* stream) {
+  hipLaunchKernelGGL(mul_tanh_drop_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dz, a, b, t, mask, scale, da, db, n);
+  return lct_check_launch("mul_tanh_drop_bwd");
+}
+int lctvqa_l2norm_rows_fwd(const float* x, float* y, float* inv_norm, int M, int N, void* stream) {
+  LCT_REQUIRE(M > 0 && N > 0, "l2norm_rows: bad shape");
+  hipLaunchKernelGGL(l2norm_rows_fwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, y, inv_norm, N);
+  return lct_check_launch("l2norm_rows_fwd");
+}
+int lctvqa_scale_rows(const float* x, const float* s, float* y, int M, int N, void* stream) {
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(ew_blocks((long)M * N)), dim3(256), 0, (hipStream_t)stream, x, s, y, N, (long)M * N);
+  return lct_check_launch("scale_rows");
+}
+// loss_out[0] = loss_scale * sum_rows(row loss);  dlogits = gscale * d(row loss)/d(logits) (may be null)
+int lctvqa_xent(const float* logits, long ld, const long* labels, const float* target, long ldt, float* row_loss,
+                float* loss_out, float loss_scale, float* dlogits, long ldd, float gscale, int M, int N, int kind, void* stream) {
+  LCT_REQUIRE(M > 0 && N > 0 && (kind == 0 || kind == 1), "xent: bad args");
+  LCT_REQUIRE(kind == 0 ? labels != nullptr : target != nullptr, "xent: missing labels/target");
+  hipLaunchKernelGGL(xent_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, target, ldt, row_loss, dlogits, ldd, gscale, N, kind);
+  int rc = lct_check_launch("xent_rows");
+  if (rc) return rc;
+  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_loss, (long)M, loss_scale, loss_out);
+  return lct_check_launch("xent_sum");
+}
+int lctvqa_softmax_rows(const float* x, float* y, int M, int N, float inv_temp, void* stream) {
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, y, N, inv_temp);
+  return lct_check_launch("softmax_rows");
+}
+int lctvqa_argmax_rows(const float* x, long ld, int M, int N, long* out, void* stream) {
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ld, N, out);
+  return lct_check_launch("argmax_rows");
+}
+int lctvqa_dropout_mask(uint8_t* mask, long n, unsigned long long seed, unsigned long long offset, float p, void* stream) {
+  LCT_REQUIRE(p >= 0.f && p < 1.f, "dropout_mask: bad p");
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, mask, n, (uint64_t)seed, (uint64_t)offset, p);
+  return lct_check_launch("dropout_mask");
+}
+// total_norm_out[0] = ||g||_2 over the flat arena;  scratch: >= 1024 floats
+int lctvqa_grad_norm(const float* g, long n, float* scratch, float* total_norm_out, void* stream) {
+  int nb = ew_blocks(n, 1024);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, n, scratch);
+  int rc = lct_check_launch("sumsq_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, nb, total_norm_out);
+  return lct_check_launch("norm_finish");
+}
+// Adam step over a flat arena; total_norm (device scalar, may be null) enables the fused global-norm clip
+int lctvqa_adam_step(float* p, const float* g, float* m, float* v, long n, const float* total_norm, float max_norm,
+                     float lr, float b1, float b2, float eps, int step, float weight_decay, void* stream) {
+  LCT_REQUIRE(step >= 1, "adam_step: step counts from 1");
+  float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+  hipLaunchKernelGGL(adam_clip_kernel, dim3(ew_blocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, total_norm, max_norm, lr, b1, b2, eps, bc1, bc2, weight_decay);
+  return lct_check_launch("adam_step");
+}
+int lctvqa_axpy(float a, const float* x, float* y, long n, void* stream) {
+  hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, a, x, y, n);
+  return lct_check_launch("axpy");
+}
+int lctvqa_scale(float a, float* y, long n, void* stream) {
+  hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, a, y, n);
+  return lct_check_launch("scale");
+}
+
+}  // extern "C"
+
+// y *= a[0] with the scalar read from device memory (autograd grad_output of a scalar loss)
+__global__ void scale_dev_kernel(const float* __restrict__ a, const float* __restrict__ x, float* __restrict__ y, long n) {
+  const float s = a[0];
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) y[o] = x[o] * s;
+}
+extern "C" int lctvqa_scale_by_device_scalar(const float* a, const float* x, float* y, long n, void* stream) {
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_blocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, a, x, y, n);
+  return lct_check_launch("scale_by_device_scalar");
+}

@@ -1,0 +1,443 @@
+"""Host-side op layer: thin torch.autograd.Function wrappers over the C ABI (include/lctvqa.h).
+
+PyTorch is plumbing here (device memory, streams, autograd graph bookkeeping); every FLOP of
+the hot path runs in the HIP library.  There is NO eager/CPU fallback: tensors must live on a
+ROCm device and the library must be built, otherwise these functions raise.
+"""
+import contextlib
+import threading
+
+import torch
+
+from ._lib import lib
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+
+
+# ----------------------------------------------------------------------------- helpers
+def _chk(t, name='tensor'):
+    if not t.is_cuda:
+        raise RuntimeError(f'lct_vqa_amd: {name} must be on a ROCm device (no CPU fallback)')
+    if t.dtype != torch.float32:
+        raise RuntimeError(f'lct_vqa_amd: {name} must be float32, got {t.dtype}')
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty(max(nbytes // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def gemm(A, a_ms, a_ks, B, b_ns, b_ks, M, N, K, bias=None, addend=None, act=ACT_NONE,
+         mask=None, mask_scale=1.0, out=None):
+    """C[M,N] = epi(A (M x K, strides a_ms/a_ks) . B^T (N x K, strides b_ns/b_ks))."""
+    dev = A.device
+    C = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
+    need = lib.query('gemm_workspace_bytes', M, N, K)
+    ws = _workspace(need, dev) if need else None
+    lib('gemm_f32', A, a_ms, a_ks, B, b_ns, b_ks, C, C.stride(0), M, N, K, bias, addend,
+        addend.stride(0) if addend is not None else 0, act, mask,
+        mask.stride(0) if mask is not None else 0, float(mask_scale), ws, need)
+    return C
+
+
+def linear_fwd(x, W, b=None, act=ACT_NONE, mask=None, mask_scale=1.0, addend=None, out=None):
+    M, K = x.shape
+    N = W.shape[0]
+    return gemm(x, x.stride(0), 1, W, W.stride(0), 1, M, N, K, b, addend, act, mask, mask_scale, out)
+
+
+def linear_bwd_input(dY, W):
+    """dX[M,K] = dY[M,N] . W[N,K]"""
+    M, N = dY.shape
+    K = W.shape[1]
+    return gemm(dY, dY.stride(0), 1, W, 1, W.stride(0), M, K, N)
+
+
+def linear_bwd_weight(dY, X):
+    """dW[N,K] = dY[M,N]^T . X[M,K]"""
+    M, N = dY.shape
+    K = X.shape[1]
+    return gemm(dY, 1, dY.stride(0), X, 1, X.stride(0), N, K, M)
+
+
+def colsum(X):
+    M, N = X.shape
+    out = torch.empty(N, dtype=torch.float32, device=X.device)
+    lib('colsum_f32', X, X.stride(0), M, N, out)
+    return out
+
+
+# ----------------------------------------------------------------------------- dropout masks
+class _MaskState(threading.local):
+    def __init__(self):
+        self.injected = None
+        self.seed = None
+        self.offset = 0
+
+
+_mask_state = _MaskState()
+
+
+@contextlib.contextmanager
+def inject_masks(masks):
+    """Parity tests: use these keep-masks (uint8/bool/float 0-1 tensors, in call order) instead of
+    the device generator, exactly like the oracle's ``masks`` argument."""
+    prev = _mask_state.injected
+    _mask_state.injected = list(masks)
+    try:
+        yield
+    finally:
+        _mask_state.injected = prev
+
+
+def manual_seed(seed):
+    _mask_state.seed = int(seed)
+    _mask_state.offset = 0
+
+
+def dropout_mask(shape, device, p=0.5):
+    """uint8 keep-mask for nn.Dropout(p) in train mode."""
+    if _mask_state.injected is not None:
+        m = _mask_state.injected.pop(0)
+        assert tuple(m.shape) == tuple(shape), (tuple(m.shape), tuple(shape))
+        return m.to(device=device, dtype=torch.uint8).contiguous()
+    if _mask_state.seed is None:
+        _mask_state.seed = torch.initial_seed() & 0xFFFFFFFFFFFF
+    n = 1
+    for s in shape:
+        n *= s
+    m = torch.empty(shape, dtype=torch.uint8, device=device)
+    lib('dropout_mask', m, n, _mask_state.seed, _mask_state.offset, float(p))
+    _mask_state.offset += n
+    return m
+
+
+# ----------------------------------------------------------------------------- autograd Functions
+class LinearFn(torch.autograd.Function):
+    """nn.Linear (+ fused act + dropout mask) -- reference basic_vqa/models.py:37,66,99-102."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, mask, mask_scale):
+        shp = x.shape
+        x2 = _chk(x, 'x').reshape(-1, shp[-1])
+        W = _chk(W, 'weight')
+        y = linear_fwd(x2, W, b, act, mask, mask_scale)
+        ctx.act, ctx.mask_scale, ctx.shp = act, mask_scale, shp
+        ctx.save_for_backward(x2, W, y if (act or mask is not None) else None, mask)
+        ctx.has_b = b is not None
+        return y.reshape(*shp[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, y, mask = ctx.saved_tensors
+        dy = _chk(dy, 'grad').reshape(-1, W.shape[0])
+        if ctx.act or mask is not None:
+            dpre = torch.empty_like(dy)
+            lib('act_bwd', dy, y, mask, float(ctx.mask_scale), dpre, dy.numel(), ctx.act)
+        else:
+            dpre = dy
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_bwd_input(dpre, W).reshape(ctx.shp)
+        if ctx.needs_input_grad[1]:
+            dW = linear_bwd_weight(dpre, x2)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = colsum(dpre)
+        return dx, dW, db, None, None, None
+
+
+def linear(x, W, b=None, act=ACT_NONE, mask=None, mask_scale=1.0):
+    return LinearFn.apply(x, W, b, act, mask, mask_scale)
+
+
+class EmbedFn(torch.autograd.Function):
+    """nn.Embedding -> (tanh) -> transpose(0,1): reference basic_vqa/models.py:58-60."""
+
+    @staticmethod
+    def forward(ctx, idx, weight, apply_tanh):
+        weight = _chk(weight, 'embedding')
+        if idx.dtype != torch.int64 or not idx.is_cuda:
+            raise RuntimeError('lct_vqa_amd: question indices must be int64 on the device')
+        idx = idx.contiguous()
+        B, T = idx.shape
+        V, E = weight.shape
+        out = torch.empty((T, B, E), dtype=torch.float32, device=weight.device)
+        lib('embed_gather', idx, weight, out, B, T, E, V, int(apply_tanh))
+        ctx.save_for_backward(idx, out)
+        ctx.apply_tanh, ctx.V = int(apply_tanh), V
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, out = ctx.saved_tensors
+        B, T = idx.shape
+        E = out.shape[2]
+        dy = _chk(dy, 'grad')
+        demb = torch.zeros((ctx.V, E), dtype=torch.float32, device=dy.device)
+        lib('embed_scatter_add', idx, dy, out, demb, B, T, E, ctx.V, ctx.apply_tanh)
+        return None, demb, None
+
+
+def embed(idx, weight, apply_tanh=True):
+    return EmbedFn.apply(idx, weight, apply_tanh)
+
+
+class LSTMFn(torch.autograd.Function):
+    """Single-layer nn.LSTM over a [T,B,I] sequence (reference basic_vqa/models.py:61,
+    models_lct.py:107-108).  Returns (out [T,B,H], h_T [B,H], c_T [B,H])."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h0, c0):
+        ctx.set_materialize_grads(False)
+        x = _chk(x, 'x')
+        T, B, I = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        w_ih, w_hh = _chk(w_ih), _chk(w_hh)
+        xp = linear_fwd(x.reshape(T * B, I), w_ih, b_ih).reshape(T, B, 4 * H)
+        gates = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
+        h_all = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
+        c_all = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
+        if h0 is None:
+            h_all[0].zero_()
+            c_all[0].zero_()
+        else:
+            h_all[0].copy_(h0.reshape(B, H))
+            c_all[0].copy_(c0.reshape(B, H))
+        hp = torch.empty((B, 4 * H), dtype=torch.float32, device=dev)
+        for t in range(T):
+            linear_fwd(h_all[t], w_hh, b_hh, out=hp)
+            lib('lstm_cell_fwd', xp[t], hp, c_all[t], gates[t], c_all[t + 1], h_all[t + 1], B, H)
+        ctx.save_for_backward(x, w_ih, w_hh, gates, h_all, c_all)
+        ctx.has_init = h0 is not None
+        return h_all[1:], h_all[T].clone(), c_all[T].clone()
+
+    @staticmethod
+    def backward(ctx, dout, dhT, dcT):
+        x, w_ih, w_hh, gates, h_all, c_all = ctx.saved_tensors
+        T, B, I = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        dout = _chk(dout) if dout is not None else None
+        dh_rec = _chk(dhT) if dhT is not None else None
+        dc = _chk(dcT) if dcT is not None else None
+        dgates = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
+        for t in range(T - 1, -1, -1):
+            dc_prev = torch.empty((B, H), dtype=torch.float32, device=dev)
+            lib('lstm_cell_bwd', dh_rec, dout[t] if dout is not None else None, dc, gates[t],
+                c_all[t], c_all[t + 1], dgates[t], dc_prev, B, H)
+            dc = dc_prev
+            if t > 0 or ctx.has_init:
+                dh_rec = linear_bwd_input(dgates[t], w_hh)
+        dg2 = dgates.reshape(T * B, 4 * H)
+        ni = ctx.needs_input_grad
+        dx = linear_bwd_input(dg2, w_ih).reshape(T, B, I) if ni[0] else None
+        dw_ih = linear_bwd_weight(dg2, x.reshape(T * B, I)) if ni[1] else None
+        dw_hh = linear_bwd_weight(dg2, h_all[:T].reshape(T * B, H)) if ni[2] else None
+        db = colsum(dg2) if (ni[3] or ni[4]) else None
+        dh0 = dh_rec if (ctx.has_init and ni[5]) else None
+        dc0 = dc if (ctx.has_init and ni[6]) else None
+        return dx, dw_ih, dw_hh, db, (db.clone() if db is not None else None), dh0, dc0
+
+
+def lstm(x, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None):
+    return LSTMFn.apply(x, w_ih, w_hh, b_ih, b_hh, h0, c0)
+
+
+class CatTanhFn(torch.autograd.Function):
+    """tanh(reshape(transpose(cat(h,c,2)))) for num_layers = 1 (models.py:62-65)."""
+
+    @staticmethod
+    def forward(ctx, h, c):
+        h, c = _chk(h), _chk(c)
+        B, H = h.shape
+        out = torch.empty((B, 2 * H), dtype=torch.float32, device=h.device)
+        lib('cat_tanh_fwd', h, c, out, B, H)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (out,) = ctx.saved_tensors
+        B, H2 = out.shape
+        dy = _chk(dy)
+        dh = torch.empty((B, H2 // 2), dtype=torch.float32, device=dy.device)
+        dc = torch.empty_like(dh)
+        lib('cat_tanh_bwd', dy, out, dh, dc, B, H2 // 2)
+        return dh, dc
+
+
+class TanhFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x)
+        y = torch.empty_like(x)
+        lib('tanh_fwd', x, y, x.numel())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _chk(dy)
+        dx = torch.empty_like(dy)
+        lib('act_bwd', dy, y, None, 1.0, dx, dy.numel(), ACT_TANH)
+        return dx
+
+
+class L2NormFn(torch.autograd.Function):
+    """x / ||x||_2.detach()  (reference basic_vqa/models.py:39-40): backward = dy / ||x||."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x)
+        M, N = x.shape
+        y = torch.empty_like(x)
+        inv = torch.empty(M, dtype=torch.float32, device=x.device)
+        lib('l2norm_rows_fwd', x, y, inv, M, N)
+        ctx.save_for_backward(inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (inv,) = ctx.saved_tensors
+        dy = _chk(dy)
+        dx = torch.empty_like(dy)
+        lib('scale_rows', dy, inv, dx, dy.shape[0], dy.shape[1])
+        return dx
+
+
+class MulTanhDropFn(torch.autograd.Function):
+    """dropout(tanh(a*b)) (reference basic_vqa/models.py:96-98)."""
+
+    @staticmethod
+    def forward(ctx, a, b, mask, scale):
+        a, b = _chk(a), _chk(b)
+        t = torch.empty_like(a)
+        z = torch.empty_like(a)
+        lib('mul_tanh_drop_fwd', a, b, mask, float(scale), t, z, a.numel())
+        ctx.save_for_backward(a, b, t, mask)
+        ctx.scale = scale
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        a, b, t, mask = ctx.saved_tensors
+        dz = _chk(dz)
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        lib('mul_tanh_drop_bwd', dz, a, b, t, mask, float(ctx.scale), da, db, a.numel())
+        return da, db, None, None
+
+
+class XentFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss() (kind 0, int64 labels) / softXEnt (kind 1, soft targets):
+    reference basic_vqa/models.py:7-10,89.  Both are sum_rows / M."""
+
+    @staticmethod
+    def forward(ctx, logits, target, kind):
+        shp = logits.shape
+        lg = _chk(logits).reshape(-1, shp[-1])
+        M, N = lg.shape
+        dev = lg.device
+        row = torch.empty(M, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dl = torch.empty_like(lg)
+        if kind == 0:
+            labels = target.reshape(-1).contiguous()
+            if labels.dtype != torch.int64:
+                raise RuntimeError('labels must be int64')
+            lib('xent', lg, lg.stride(0), labels, None, 0, row, loss, 1.0 / M, dl, dl.stride(0), 1.0 / M, M, N, 0)
+        else:
+            tg = _chk(target).reshape(-1, N)
+            lib('xent', lg, lg.stride(0), None, tg, tg.stride(0), row, loss, 1.0 / M, dl, dl.stride(0), 1.0 / M, M, N, 1)
+        ctx.save_for_backward(dl)
+        ctx.shp = shp
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        g = _chk(g.reshape(1))
+        out = torch.empty_like(dl)
+        lib('scale_by_device_scalar', g, dl, out, dl.numel())
+        return out.reshape(ctx.shp), None, None
+
+
+def cross_entropy(logits, labels):
+    return XentFn.apply(logits, labels, 0)
+
+
+def soft_xent(pred, target):
+    return XentFn.apply(pred, target.detach(), 1)
+
+
+def softmax_rows(x, inv_temp=1.0):
+    """F.softmax(x * inv_temp, dim=1) -- forward only (pseudo labels: experiment.py:245)."""
+    x = _chk(x.detach())
+    y = torch.empty_like(x)
+    lib('softmax_rows', x, y, x.shape[0], x.shape[1], float(inv_temp))
+    return y
+
+
+def argmax_rows(x):
+    x = _chk(x.detach())
+    out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
+    lib('argmax_rows', x, x.stride(0), x.shape[0], x.shape[1], out)
+    return out
+
+
+# ----------------------------------------------------------------------------- VGG19 trunk (forward)
+def vgg_trunk_forward(image, convs, fcs, train):
+    """torchvision vgg19 (reference basic_vqa/models.py:23-28,36), forward only.
+    image: NCHW fp32 [B,3,H,W].  convs: list of (weight OIHW, bias) in layer order with the
+    string 'M' marking MaxPool2d(2,2).  fcs: list of (weight, bias, act, drop_p) for the classifier.
+    Returns [B, fcs[-1] out features]."""
+    image = _chk(image, 'image')
+    B, C, H, W = image.shape
+    if C != 3:
+        raise RuntimeError('VGG19 expects 3 input channels')
+    dev = image.device
+    w0, b0 = convs[0]
+    cur = torch.empty((B, H, W, w0.shape[0]), dtype=torch.float32, device=dev)
+    lib('conv3x3_first_nchw', image, _chk(w0), b0, cur, B, H, W, w0.shape[0], 1)
+    i = 1
+    while i < len(convs):
+        item = convs[i]
+        if isinstance(item, str):                       # a pool that could not be fused
+            out = torch.empty((B, H // 2, W // 2, cur.shape[3]), dtype=torch.float32, device=dev)
+            lib('maxpool2x2_nhwc', cur, out, B, H, W, cur.shape[3])
+            cur, H, W = out, H // 2, W // 2
+            i += 1
+            continue
+        w, b = item
+        w = _chk(w)
+        Cout, Cin = w.shape[0], w.shape[1]
+        pool = 1 if (i + 1 < len(convs) and isinstance(convs[i + 1], str) and H % 2 == 0 and W % 2 == 0) else 0
+        mfma = lib.query('conv3x3_uses_mfma', B, H, W, Cin, Cout, pool)
+        wp = tmp = None
+        if mfma:
+            wp = torch.empty(Cout * Cin * 9, dtype=torch.float32, device=dev)
+            lib('conv3x3_pack_weights', w, wp, Cout, Cin)
+        elif pool:
+            tmp = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
+        Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
+        lib('conv3x3_nhwc', cur, w, wp, b, out, tmp, B, H, W, Cin, Cout, 1, pool)
+        cur, H, W = out, Ho, Wo
+        i += 2 if pool else 1
+    Cl = cur.shape[3]
+    x = torch.empty((B, Cl * 49), dtype=torch.float32, device=dev)
+    lib('adaptive_avgpool7_flatten', cur, x, B, H, W, Cl)
+    for (w, b, act, drop_p) in fcs:
+        m = dropout_mask((B, w.shape[0]), dev, drop_p) if (train and drop_p > 0) else None
+        x = linear_fwd(x, _chk(w), b, act, m, 1.0 / (1.0 - drop_p) if m is not None else 1.0)
+    return x

@@ -1,0 +1,99 @@
+"""Adam (+ fused global-norm clip) on the HIP library.
+
+``FusedAdam`` is call-compatible with ``torch.optim.Adam`` as the reference uses it
+(basic_vqa/model_factory.py:20-21,41-42: ``optim.Adam(model.parameters(), lr=...)``; StepLR reads
+``param_groups[i]['lr']``).  With ``flatten=True`` the trainable parameters, their gradients and the
+Adam moments live in ONE contiguous fp32 arena each (parameters/gradients become views), so that
+  * ``step(max_grad_norm=5)`` = one grad-norm reduction + one fused clip+Adam kernel
+    (16 B/param read, 12 B/param written: HBM-bound),
+  * the data-parallel all-reduce works on the flat gradient buffer directly (parallel.py),
+  * the architects' ``_concat``/axpy vector ops (architect_lct.py:112-116,194-207) are zero-copy.
+"""
+import torch
+
+from ._lib import lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, flatten=False):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.flat = None
+        if flatten:
+            self._flatten()
+
+    # ------------------------------------------------------------------ flat arena
+    def _flatten(self):
+        if len(self.param_groups) != 1:
+            raise ValueError('flatten=True supports a single param group')
+        ps = [p for p in self.param_groups[0]['params'] if p.requires_grad]
+        if not ps:
+            raise ValueError('no trainable parameters')
+        dev = ps[0].device
+        if dev.type != 'cuda':
+            raise RuntimeError('FusedAdam(flatten=True): parameters must already be on the ROCm device')
+        n = sum(p.numel() for p in ps)
+        fp = torch.empty(n, dtype=torch.float32, device=dev)
+        fg = torch.zeros(n, dtype=torch.float32, device=dev)
+        o = 0
+        for p in ps:
+            k = p.numel()
+            fp[o:o + k].copy_(p.data.reshape(-1))
+            p.data = fp[o:o + k].view_as(p.data)
+            p.grad = fg[o:o + k].view_as(p.data)
+            o += k
+        self.flat = dict(params=ps, p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), step=0,
+                         scratch=torch.empty(1024, dtype=torch.float32, device=dev),
+                         norm=torch.zeros(1, dtype=torch.float32, device=dev))
+
+    @property
+    def flat_grad(self):
+        return self.flat['g'] if self.flat else None
+
+    @property
+    def flat_param(self):
+        return self.flat['p'] if self.flat else None
+
+    def zero_grad(self, set_to_none=False):
+        if self.flat is not None:
+            self.flat['g'].zero_()
+            return
+        super().zero_grad(set_to_none=set_to_none)
+
+    def grad_norm(self):
+        """Device scalar ||g||_2 over the arena (clip_grad_norm_'s total_norm)."""
+        f = self.flat
+        lib('grad_norm', f['g'], f['g'].numel(), f['scratch'], f['norm'])
+        return f['norm']
+
+    # ------------------------------------------------------------------ step
+    @torch.no_grad()
+    def step(self, closure=None, max_grad_norm=None):
+        loss = closure() if closure is not None else None
+        if self.flat is not None:
+            f, g = self.flat, self.param_groups[0]
+            f['step'] += 1
+            norm = self.grad_norm() if max_grad_norm is not None else None
+            lib('adam_step', f['p'], f['g'], f['m'], f['v'], f['p'].numel(), norm,
+                float(max_grad_norm or 0.0), float(g['lr']), float(g['betas'][0]), float(g['betas'][1]),
+                float(g['eps']), f['step'], float(g['weight_decay']))
+            return loss
+        if max_grad_norm is not None:
+            raise ValueError('fused clipping needs flatten=True (use nn.utils.clip_grad_norm_ otherwise)')
+        for g in self.param_groups:
+            for p in g['params']:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st['step'] = 0
+                    st['exp_avg'] = torch.zeros_like(p)
+                    st['exp_avg_sq'] = torch.zeros_like(p)
+                st['step'] += 1
+                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if not p.is_contiguous():
+                    raise RuntimeError('FusedAdam: non-contiguous parameter')
+                lib('adam_step', p, grad, st['exp_avg'], st['exp_avg_sq'], p.numel(), None, 0.0,
+                    float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
+                    int(st['step']), float(g['weight_decay']))
+        return loss

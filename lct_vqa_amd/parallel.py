@@ -1,0 +1,103 @@
+"""Data-parallel train step: one process per GPU, torch.distributed (backend 'nccl' == RCCL on
+ROCm, xGMI point-to-point links), gradients all-reduced as a few large flat buckets that are
+launched as soon as backward has produced them.
+
+The reference has no distributed code at all; the collective sits where
+``loss.backward()`` returns in basic_vqa/experiment.py:225 / :255, before ``clip_grad_norm_`` and
+``optimizer.step()``.  Samples are independent in every layer of the VGG/LSTM/fusion models, so
+DP-N on batch B/N each equals the single-process batch-B step up to summation order.
+
+Works on any flat fp32 gradient buffer (CPU tensors + gloo in the unit tests, HBM + RCCL on MI355X).
+Bucket size: xGMI is 7 point-to-point links x ~153 GB/s per GPU, so a ring step is per-link bound
+and wants few, large messages: default 32 MiB buckets (the W model's 84 MB of gradients = 3 buckets).
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatGradReducer:
+    def __init__(self, params, flat_grad, process_group=None, bucket_bytes=32 << 20, scale_fn=None):
+        """params: the parameters whose .grad are consecutive views into flat_grad (arena order)."""
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.flat = flat_grad
+        self.scale_fn = scale_fn
+        self.buckets = []          # [start, end, n_params_pending, n_params]
+        self.param_bucket = {}
+        per = max(1, bucket_bytes // 4)
+        o, start, cnt, ids = 0, 0, 0, []
+        for p in params:
+            k = p.numel()
+            ids.append(p)
+            cnt += 1
+            o += k
+            if o - start >= per:
+                self._close(start, o, ids)
+                start, cnt, ids = o, 0, []
+        if ids:
+            self._close(start, o, ids)
+        assert o == flat_grad.numel()
+        self.handles = []
+        self._hooks = []
+        if self.world > 1:
+            for p in params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self.reset()
+
+    def _close(self, start, end, ids):
+        b = len(self.buckets)
+        self.buckets.append([start, end, len(ids), len(ids)])
+        for p in ids:
+            self.param_bucket[p] = b
+
+    def reset(self):
+        for b in self.buckets:
+            b[2] = b[3]
+        self.handles = []
+
+    def _on_grad(self, p):
+        b = self.buckets[self.param_bucket[p]]
+        b[2] -= 1
+        if b[2] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        h = dist.all_reduce(self.flat[b[0]:b[1]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.handles.append(h)
+
+    def finish(self):
+        """Wait for every bucket (launching the ones whose hooks did not all fire, e.g. unused
+        parameters), then average."""
+        if self.world > 1:
+            for b in self.buckets:
+                if b[2] != 0:
+                    self._launch(b)
+            for h in self.handles:
+                h.wait()
+            if self.scale_fn is not None:
+                self.scale_fn(1.0 / self.world, self.flat)
+            else:
+                self.flat.mul_(1.0 / self.world)
+        self.reset()
+
+
+def hip_scale(a, flat):
+    from ._lib import lib
+    lib('scale', float(a), flat, flat.numel())
+
+
+def init_distributed():
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract) and bind this process
+    to its GPU.  Returns (rank, world, local_rank)."""
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local

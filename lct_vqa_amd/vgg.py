@@ -1,0 +1,78 @@
+"""VGG19 (configuration E) module shell with torchvision's attribute names / state_dict keys
+(``features.{0,2,5,...}``, ``classifier.{0,3,6}``) whose forward runs the HIP trunk.
+
+Stands where the reference calls ``torchvision.models.vgg19`` (basic_vqa/models.py:23,
+models_lct.py:46, darts_vqa/vqa_model.py:19).  ``pretrained=True`` would download ImageNet
+weights; offline it is a seeded random init (torchvision's own ``_initialize_weights`` scheme).
+Like the reference, callers may truncate ``classifier`` with
+``nn.Sequential(*list(model.classifier.children())[:-1])`` -- forward interprets whatever
+Linear/ReLU/Dropout sequence is present.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+CFG_E = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M',
+         512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
+
+
+class VGG(nn.Module):
+    def __init__(self, num_classes=1000):
+        super().__init__()
+        layers, cin = [], 3
+        for v in CFG_E:
+            if v == 'M':
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        self.features = nn.Sequential(*layers)
+        self.avgpool = nn.AdaptiveAvgPool2d((7, 7))
+        self.classifier = nn.Sequential(
+            nn.Linear(512 * 7 * 7, 4096), nn.ReLU(True), nn.Dropout(),
+            nn.Linear(4096, 4096), nn.ReLU(True), nn.Dropout(),
+            nn.Linear(4096, num_classes))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.constant_(m.bias, 0)
+
+    def _plan(self):
+        convs = []
+        for m in self.features:
+            if isinstance(m, nn.Conv2d):
+                convs.append((m.weight, m.bias))
+            elif isinstance(m, nn.MaxPool2d):
+                convs.append('M')
+        fcs, mods, i = [], list(self.classifier), 0
+        while i < len(mods):
+            lin = mods[i]
+            if not isinstance(lin, nn.Linear):
+                raise RuntimeError(f'unexpected classifier module {type(lin).__name__}')
+            act, p = ops.ACT_NONE, 0.0
+            i += 1
+            if i < len(mods) and isinstance(mods[i], nn.ReLU):
+                act = ops.ACT_RELU
+                i += 1
+            if i < len(mods) and isinstance(mods[i], nn.Dropout):
+                p = mods[i].p
+                i += 1
+            fcs.append((lin.weight, lin.bias, act, p))
+        return convs, fcs
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                'lct_vqa_amd: backward through the VGG19 trunk (ImgEncoderFixed with pretrained=False, '
+                'reference models_lct.py:62-63) is not built yet; freeze it or call under no_grad')
+        convs, fcs = self._plan()
+        with torch.no_grad():
+            return ops.vgg_trunk_forward(x, convs, fcs, self.training)
+
+
+def vgg19(pretrained=False, **kw):
+    return VGG(**kw)

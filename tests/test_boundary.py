@@ -1,0 +1,67 @@
+"""CPU: the plugin surface mirrors the reference (names, signatures, state_dict keys, defaults)."""
+import inspect
+import types
+
+import pytest
+import torch
+
+from _util import load
+
+
+class _DS:
+    qst_vocab = types.SimpleNamespace(vocab_size=50)
+    ans_vocab = types.SimpleNamespace(vocab_size=40)
+
+
+def test_factory_surface():
+    from lct_vqa_amd.basic_vqa import model_factory as mf, architect_factory as af, config
+    for fn, args in [('get_ef_model', ['dataset']), ('get_ef_optimizer', ['model']), ('get_ef_scheduler', ['optimizer']),
+                     ('get_w_model', ['dataset']), ('get_w_optimizer', ['model']), ('get_w_scheduler', ['optimizer'])]:
+        assert list(inspect.signature(getattr(mf, fn)).parameters) == args
+    assert list(inspect.signature(af.get_architect).parameters) == ['ef_model', 'w_model', 'ef_optimizer', 'w_optimizer']
+    old = config.ARCH_TYPE
+    try:
+        config.ARCH_TYPE = 'fixed'
+        w = mf.get_w_model(_DS)
+        ef = mf.get_ef_model(_DS)
+        assert w.fc2.weight.shape == (40, 40) and ef.qst_encoder.fc2.weight.shape == (50, 512)
+        opt = mf.get_w_optimizer(w)
+        sch = mf.get_w_scheduler(opt)
+        assert opt.param_groups[0]['lr'] == config.LEARNING_RATE and sch.step_size == config.STEP_SIZE
+        assert af.get_architect(ef, w, opt, opt) is None
+        config.ARCH_TYPE = 'bogus'
+        with pytest.raises(AssertionError):
+            af.get_architect(ef, w, opt, opt)
+    finally:
+        config.ARCH_TYPE = old
+
+
+def test_state_dict_keys_match_reference():
+    from lct_vqa_amd.basic_vqa import models, models_lct, config
+    fx = load('w_small.pt')
+    torch.manual_seed(fx['seed'])
+    w = models.VqaModel(**fx['dims'])
+    ref_keys = set(fx['state']) | set(fx['vgg_checksums'])
+    assert set(w.state_dict()) == ref_keys and len(ref_keys) == 49
+    # same seed + same construction order => identical initial parameters as the reference modules
+    for k, v in fx['state'].items():
+        assert torch.equal(w.state_dict()[k], v), k
+    fe = load('ef_small_frozen.pt')
+    old = config.ARCH_TYPE
+    try:
+        config.ARCH_TYPE = 'fixed'
+        torch.manual_seed(fe['seed'])
+        ef = models_lct.VqaModel(pretrained=True, **fe['dims'])
+    finally:
+        config.ARCH_TYPE = old
+    assert set(ef.state_dict()) == set(fe['state']) | set(fe['vgg_checksums']) and len(ef.state_dict()) == 51
+    for k, v in fe['state'].items():
+        assert torch.equal(ef.state_dict()[k], v), k
+    assert ef.qst_encoder.max_length == 30 and ef.qst_encoder.deterministic and ef.qst_encoder.temperature == 0.1
+
+
+def test_config_defaults_and_active():
+    from lct_vqa_amd.basic_vqa import config
+    assert (config.IMG_EMBED_SIZE, config.WORD_EMBED_SIZE, config.LSTM_HIDDEN_SIZE, config.GRAD_CLIP) == (512, 300, 512, 5)
+    assert config.SEED == 10 and config.W_LAMBDA == 1.0 and config.TEMPERATURE == 0.1
+    assert config.active() is config
