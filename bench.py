@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Headline benchmark: image-question pairs/s of one train step of the W model
+(basic_vqa VGG19+LSTM, fp32, 224x224 images, 14-token questions, 3129 answers, QV=17858)
+= BASELINE.json configs[1], on N MI355X GPUs of one node (one process per GPU, RCCL all-reduce).
+
+A step = forward (frozen VGG19 trunk under no_grad, dropout live) + CE loss + backward through the
+trainable head + all-reduce (N>1) + global-norm clip(5) + Adam, on synthetic inputs already
+resident in HBM.  Contract: W untimed warm-up steps, then exactly K timed steps bracketed by
+barrier + synchronize; MAX over ranks; rank 0 prints ONE JSON line.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 256]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+DIMS = dict(embed_size=512, qst_vocab_size=17858, ans_vocab_size=3129, word_embed_size=300, num_layers=1, hidden_size=512)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (weak scaling)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=6)
+    ap.add_argument('--layer-report', default='', help='write the per-conv-layer timing table to this file')
+    return ap.parse_args()
+
+
+def cpu_baseline(steps):
+    """The oracle's W train step (fwd + CE + bwd + clip + Adam), B=4 at full resolution, timed on the
+    host cores of this box.  Reported baseline only (kind 'port': the reference's Python cannot travel)."""
+    from oracle import vqa_oracle as O
+    from lct_vqa_amd.basic_vqa import models
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    torch.manual_seed(10)
+    m = models.VqaModel(**DIMS)
+    P = {k: v.detach() for k, v in m.state_dict().items()}
+    del m
+    B = 4
+    img = torch.randn(B, 3, 224, 224)
+    qst = torch.randint(DIMS['qst_vocab_size'], (B, 14)); qst[:, 0] = 2
+    lab = torch.randint(DIMS['ans_vocab_size'], (B,))
+    state, times = {}, []
+    for it in range(steps + 1):
+        masks = O.draw_masks(O.w_mask_shapes(B, DIMS['ans_vocab_size'], DIMS['embed_size']))
+        t0 = time.perf_counter()
+        _, _, P, _ = O.w_train_step(img, qst, lab, P, state, masks)
+        times.append(time.perf_counter() - t0)
+    times = sorted(times[1:])
+    med = times[len(times) // 2]
+    return {'value': B / med, 'unit': 'pairs/s', 'cores': ncores, 'kind': 'port',
+            'sample': f'oracle W train step, B={B}, 224x224, T=14, A=3129, QV=17858, fp32, median of {steps} steps after 1 warm-up '
+                      f'({med * 1e3:.0f} ms/step, torch {torch.__version__} CPU, {ncores} threads)'}
+
+
+def main():
+    args = parse()
+    from lct_vqa_amd import ops, parallel
+    from lct_vqa_amd._lib import lib
+    from lct_vqa_amd.basic_vqa import models, config
+    from lct_vqa_amd.optim import FusedAdam
+    lib.load()                                      # fail loudly if the HIP library is missing
+    rank, world, local = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    dev = torch.device('cuda', local)
+    config.DEVICE = dev
+    config.ARCH_TYPE = 'fixed'
+
+    torch.manual_seed(10)                           # config.SEED: identical replicas on every rank
+    model = models.VqaModel(**DIMS).to(dev).train()
+    opt = FusedAdam(list(model.parameters()), lr=config.LEARNING_RATE, flatten=True)
+    trainable = opt.flat['params']
+    reducer = parallel.FlatGradReducer(trainable, opt.flat_grad, scale_fn=parallel.hip_scale) if world > 1 else None
+
+    B = args.batch
+    g = torch.Generator().manual_seed(10 + rank)    # rank r uses seed 10+r for data
+    img = torch.randn(B, 3, 224, 224, generator=g).to(dev)
+    qst = torch.randint(DIMS['qst_vocab_size'], (B, 14), generator=g); qst[:, 0] = 2
+    qst = qst.to(dev)
+    lab = torch.randint(DIMS['ans_vocab_size'], (B,), generator=g).to(dev)
+    ops.manual_seed(10 + rank)
+
+    def step():
+        opt.zero_grad()
+        logits = model(img, qst)
+        loss = ops.cross_entropy(logits, lab)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step(max_grad_norm=config.GRAD_CLIP)
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ops.conv_timer_start()                          # HIP events around every conv3x3 MFMA launch (same stream)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    conv = ops.conv_timer_stop()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    ms = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    # ---- roofline of the dominant kernel (conv3x3_mfma_kernel, every instantiation) ----
+    tot_flops = sum(r['flops'] for r in conv)
+    tot_ms = sum(r['ms'] for r in conv)
+    nlaunch = max(1, len(conv))
+    achieved = tot_flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    roofline = {'bound': 'mfma', 'kernel': 'conv3x3_mfma_kernel (15 VGG19 layers/step)', 'achieved': round(achieved, 2),
+                'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                'traffic': None, 'launches': nlaunch, 'avg_launch_ms': round(tot_ms / nlaunch, 4),
+                'flops_per_launch': tot_flops / nlaunch, 'conv_ms_per_step': round(tot_ms / args.steps, 3)}
+    if args.layer_report:
+        per = {}
+        for r in conv:
+            k = r['name']
+            a = per.setdefault(k, {'ms': 0.0, 'flops': 0.0, 'n': 0})
+            a['ms'] += r['ms']; a['flops'] += r['flops']; a['n'] += 1
+        with open(args.layer_report, 'w') as f:
+            for k, a in per.items():
+                f.write(f"{k}: {a['ms'] / a['n']:.3f} ms/launch, {a['flops'] / a['ms'] / 1e9:.1f} TFLOP/s ({a['n']} launches)\n")
+    out = {
+        'metric': 'image-question pairs/sec (train step) at 224x224, seq=14, 3129-way', 'value': round(value, 2),
+        'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'basic_vqa VGG19+LSTM fp32 W-model train step (frozen VGG19 trunk, fwd+CE+bwd+clip+Adam), '
+                               'batch %d per GPU, 224x224x3 images, 14-token questions, 3129 answers, QV=17858' % B,
+                   'global_batch': world * B, 'seq_len': 14, 'parallelism': f'dp{world}'},
+        'loss': round(float(loss.item()), 5),
+        'model_flops_per_step': 39.48e9 * B, 'model_tflops': round(39.48e9 * B / (ms * 1e-3) / 1e12, 2),
+        'roofline': roofline,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out['cpu_baseline'] = cpu_baseline(args.cpu_steps)
+    else:
+        out['cpu_baseline'] = None
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -395,6 +395,25 @@ def argmax_rows(x):
     return out
 
 
+# ----------------------------------------------------------------------------- per-launch timing (bench.py roofline)
+_conv_timer = None
+
+
+def conv_timer_start():
+    """Record a pair of events (on the launch stream) around every conv3x3 MFMA launch until
+    conv_timer_stop(); used by bench.py to price the dominant kernel against the MFMA roofline."""
+    global _conv_timer
+    _conv_timer = []
+
+
+def conv_timer_stop():
+    """-> list of dicts {name, ms, flops} (synchronises)."""
+    global _conv_timer
+    rec, _conv_timer = _conv_timer or [], None
+    torch.cuda.synchronize()
+    return [dict(name=n, ms=a.elapsed_time(b), flops=f) for (n, a, b, f) in rec]
+
+
 # ----------------------------------------------------------------------------- VGG19 trunk (forward)
 def vgg_trunk_forward(image, convs, fcs, train):
     """torchvision vgg19 (reference basic_vqa/models.py:23-28,36), forward only.
@@ -431,7 +450,15 @@ def vgg_trunk_forward(image, convs, fcs, train):
             tmp = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
-        lib('conv3x3_nhwc', cur, w, wp, b, out, tmp, B, H, W, Cin, Cout, 1, pool)
+        if _conv_timer is not None and mfma:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            lib('conv3x3_nhwc', cur, w, wp, b, out, tmp, B, H, W, Cin, Cout, 1, pool)
+            e1.record()
+            _conv_timer.append((f'conv{H}x{W}_{Cin}->{Cout}{"+pool" if pool else ""}', e0, e1,
+                                2.0 * B * H * W * Cout * Cin * 9))
+        else:
+            lib('conv3x3_nhwc', cur, w, wp, b, out, tmp, B, H, W, Cin, Cout, 1, pool)
         cur, H, W = out, Ho, Wo
         i += 2 if pool else 1
     Cl = cur.shape[3]

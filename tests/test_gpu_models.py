@@ -1,0 +1,114 @@
+"""GPU parity of the whole models through the plugin surface against the golden vectors that the
+REFERENCE's own modules produced (tests/golden), and against the oracle on fresh seeded inputs."""
+import pytest
+import torch
+
+from _util import load, full_params, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def pkg(hip_lib):
+    from lct_vqa_amd import ops
+    from lct_vqa_amd.basic_vqa import models, models_lct, config
+    config.DEVICE = torch.device(DEV)
+    return ops, models, models_lct, config
+
+
+def _build(cls, fx, **kw):
+    m = cls(**fx['dims'], **kw)
+    m.load_state_dict(full_params(fx))
+    return m.to(DEV)
+
+
+def test_w_small_against_reference_goldens(pkg):
+    ops, models, _, _ = pkg
+    fx = load('w_small.pt')
+    m = _build(models.VqaModel, fx)
+    img, qst, lab = fx['image'].to(DEV), fx['question'].to(DEV), fx['label'].to(DEV)
+    m.eval()
+    with torch.no_grad():
+        ev = m(img, qst)
+    assert rel_err(ev, fx['eval_logits']) < 1e-3
+    assert torch.equal(ev.argmax(1).cpu(), fx['eval_logits'].argmax(1))
+    m.train()
+    with ops.inject_masks(fx['train_masks']):
+        tr = m(img, qst)
+        loss = ops.cross_entropy(tr, lab)
+    assert rel_err(tr, fx['train_logits']) < 1e-3 and rel_err(loss, fx['train_loss']) < 1e-4
+    grads = torch.autograd.grad(loss, list(m.parameters()), allow_unused=True)
+    assert sum(g is None for g in grads) == fx['num_none_grads'] == 36
+    for (k, _), g in zip(m.named_parameters(), grads):
+        if g is not None:
+            assert rel_err(g, fx['grads'][k]) < 1e-3, k
+    m.eval()
+    with torch.no_grad():
+        sl = m._soft_loss(img, qst, lab, fx['pseudo_qst'].to(DEV), fx['pseudo_label'].to(DEV))
+    assert rel_err(sl, fx['soft_loss']) < 1e-4
+
+
+def test_ef_small_against_reference_goldens(pkg):
+    ops, _, models_lct, config = pkg
+    fx = load('ef_small_frozen.pt')
+    config.ARCH_TYPE = 'fixed'
+    m = _build(models_lct.VqaModel, fx, pretrained=True).eval()
+    img, qst, lab = fx['image'].to(DEV), fx['question'].to(DEV), fx['label'].to(DEV)
+    with torch.no_grad():
+        ans, qo = m(img, qst)
+        gq, ga = m.generate(img)
+    assert rel_err(ans, fx['eval_ans']) < 1e-3 and rel_err(qo, fx['eval_qst_out']) < 1e-3
+    assert torch.equal(gq.cpu(), fx['gen_qst'])          # greedy token ids: bit-exact
+    assert rel_err(ga, fx['gen_ans']) < 1e-3
+    loss = m._loss(img, qst, lab)
+    assert rel_err(loss, fx['loss']) < 1e-4
+    grads = torch.autograd.grad(loss, list(m.parameters()), allow_unused=True)
+    assert sum(g is None for g in grads) == 36
+    for (k, _), g in zip(m.named_parameters(), grads):
+        if g is not None:
+            assert rel_err(g, fx['grads'][k]) < 1e-3, k
+    # gradient through generated answers reaches everything except the token head (architect_lct.py:77: 2 Nones
+    # among trainable tensors + the 36 frozen ones)
+    wq, wa = m.generate(img)
+    g2 = torch.autograd.grad(ops.soft_xent(wa, torch.softmax(fx['gen_ans'].to(DEV), 1)), list(m.parameters()), allow_unused=True)
+    none_names = [k for (k, _), g in zip(m.named_parameters(), g2) if g is None and '.model.' not in k]
+    assert none_names == [] or set(none_names) <= {'qst_encoder.fc2.weight', 'qst_encoder.fc2.bias'}
+
+
+def test_w_full_b4_logits_argmax(pkg):
+    """BASELINE config 1 shapes on the GPU: B=4, 224x224, T=14, A=3129, QV=17858, vs the reference's logits."""
+    ops, models, _, _ = pkg
+    fx = load('w_full_b4.pt')
+    torch.manual_seed(fx['seed'])
+    m = models.VqaModel(**fx['dims']).to(DEV).eval()
+    torch.manual_seed(fx['data_seed'])
+    img = torch.randn(fx['B'], 3, 224, 224).to(DEV)
+    with torch.no_grad():
+        lg = m(img, fx['question'].to(DEV))
+    assert rel_err(lg, fx['eval_logits']) < 1e-3
+    assert torch.equal(lg.argmax(1).cpu(), fx['argmax'])
+
+
+def test_train_step_matches_oracle(pkg):
+    """One full W train step (fwd, CE, bwd, clip 5, Adam) vs the oracle's, injected masks."""
+    ops, models, _, _ = pkg
+    from oracle import vqa_oracle as O
+    from lct_vqa_amd.optim import FusedAdam
+    fx = load('w_small.pt')
+    m = _build(models.VqaModel, fx).train()
+    P = full_params(fx)
+    img, qst, lab = fx['image'], fx['question'], fx['label']
+    opt = FusedAdam([p for p in m.parameters()], lr=1e-3, flatten=True)
+    state = {}
+    for it in range(2):
+        masks = [mk.float() for mk in fx['train_masks']]
+        loss_o, _, P, _ = O.w_train_step(img, qst, lab, P, state, masks)
+        opt.zero_grad()
+        with ops.inject_masks(fx['train_masks']):
+            loss = ops.cross_entropy(m(img.to(DEV), qst.to(DEV)), lab.to(DEV))
+        loss.backward()
+        opt.step(max_grad_norm=5)
+        assert rel_err(loss, loss_o) < 1e-4
+    for k, v in m.state_dict().items():
+        assert rel_err(v, P[k]) < 1e-3, k

@@ -1,0 +1,225 @@
+"""GPU parity tests of the individual C-ABI entry points against the CPU oracle / plain torch fp32
+on the same seeded inputs.  Tolerances: fp32 kernels, different summation order -> 1e-4 relative
+(north_star: 1e-3 relative on logits); integer outputs bit-exact."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def ops(hip_lib):
+    from lct_vqa_amd import ops as _ops
+    return _ops
+
+
+def _conv_case(ops, hip_lib, B, H, W, Cin, Cout, pool, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = torch.relu(F.conv2d(x, w, b, padding=1))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd, bd = w.to(DEV), b.to(DEV)
+    mfma = hip_lib.query('conv3x3_uses_mfma', B, H, W, Cin, Cout, pool)
+    wp = tmp = None
+    if mfma:
+        wp = torch.empty(Cout * Cin * 9, device=DEV)
+        hip_lib('conv3x3_pack_weights', wd, wp, Cout, Cin)
+    elif pool:
+        tmp = torch.empty(B, H, W, Cout, device=DEV)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.full((B, Ho, Wo, Cout), float('nan'), device=DEV)
+    hip_lib('conv3x3_nhwc', xd, wd, wp, bd, y, tmp, B, H, W, Cin, Cout, 1, pool)
+    torch.cuda.synchronize()
+    got = y.permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got).all()
+    return rel_err(got, ref), mfma
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,pool', [
+    (2, 32, 32, 64, 64, 0), (2, 32, 32, 64, 64, 1),      # TW=32 tile, 2x2 wave layout (conv1_2)
+    (3, 16, 16, 64, 128, 0), (3, 16, 16, 128, 128, 1),   # TW=16 tile (conv2_x), ragged stacked rows
+    (2, 56, 56, 128, 256, 0), (1, 56, 56, 256, 256, 1),  # TW=8 tile (conv3_x): patch spans images
+    (3, 28, 28, 256, 512, 0), (2, 28, 28, 512, 512, 1),  # TW=28 tile (conv4_x), 7 sub-tiles
+    (5, 14, 14, 512, 512, 0), (3, 14, 14, 512, 512, 1),  # TW=14 tile (conv5_x): 2 image gaps per patch
+    (1, 64, 32, 16, 64, 0),                              # single channel chunk, non-square
+    (2, 4, 4, 32, 64, 1), (1, 6, 10, 8, 24, 0),          # direct fallback (tiny map / odd channels)
+])
+def test_conv3x3(ops, hip_lib, B, H, W, Cin, Cout, pool):
+    err, mfma = _conv_case(ops, hip_lib, B, H, W, Cin, Cout, pool)
+    assert err < 2e-5, (err, mfma)
+
+
+def test_conv3x3_vgg_shapes_use_mfma(hip_lib):
+    for (H, Cin, Cout, pool) in [(224, 64, 64, 1), (112, 64, 128, 0), (56, 128, 256, 0), (28, 256, 512, 0), (14, 512, 512, 1)]:
+        assert hip_lib.query('conv3x3_uses_mfma', 4, H, H, Cin, Cout, pool) == 1
+
+
+def test_conv3x3_full_res_layer(ops, hip_lib):
+    """conv1_2 at the real 224x224 resolution (B=1) incl. fused pool."""
+    err, mfma = _conv_case(ops, hip_lib, 1, 224, 224, 64, 64, 1)
+    assert mfma == 1 and err < 2e-5
+
+
+def test_conv_first_and_pool_and_avgpool(hip_lib):
+    g = torch.Generator().manual_seed(1)
+    for (B, H, W) in [(2, 32, 32), (1, 224, 224), (3, 10, 6)]:
+        x = torch.randn(B, 3, H, W, generator=g)
+        w = torch.randn(64, 3, 3, 3, generator=g) * 0.2
+        b = torch.randn(64, generator=g) * 0.1
+        ref = torch.relu(F.conv2d(x, w, b, padding=1))
+        y = torch.empty(B, H, W, 64, device=DEV)
+        hip_lib('conv3x3_first_nchw', x.to(DEV), w.to(DEV), b.to(DEV), y, B, H, W, 64, 1)
+        assert rel_err(y.permute(0, 3, 1, 2).cpu(), ref) < 1e-5
+        yp = torch.empty(B, H // 2, W // 2, 64, device=DEV)
+        hip_lib('maxpool2x2_nhwc', y, yp, B, H, W, 64)
+        assert torch.equal(yp.permute(0, 3, 1, 2).cpu(), F.max_pool2d(y.permute(0, 3, 1, 2).cpu(), 2, 2))
+    for (H, W) in [(7, 7), (2, 2), (1, 1), (14, 14), (3, 5)]:
+        x = torch.randn(2, 16, H, W, generator=g)
+        ref = F.adaptive_avg_pool2d(x, (7, 7)).flatten(1)
+        y = torch.empty(2, 16 * 49, device=DEV)
+        hip_lib('adaptive_avgpool7_flatten', x.permute(0, 2, 3, 1).contiguous().to(DEV), y, 2, H, W, 16)
+        assert rel_err(y.cpu(), ref) < 1e-6
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 512, 4096), (4, 3129, 3129), (37, 45, 19), (256, 4096, 25088), (3584, 2048, 300), (128, 128, 16)])
+def test_gemm_linear_fwd_bwd(ops, M, N, K):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    xd, Wd, bd, dyd = x.to(DEV), W.to(DEV), b.to(DEV), dy.to(DEV)
+    assert rel_err(ops.linear_fwd(xd, Wd, bd), x @ W.t() + b) < 2e-5
+    assert rel_err(ops.linear_bwd_input(dyd, Wd), dy @ W) < 2e-5
+    assert rel_err(ops.linear_bwd_weight(dyd, xd), dy.t() @ x) < 2e-5
+    assert rel_err(ops.colsum(dyd), dy.sum(0)) < 2e-5
+
+
+def test_gemm_epilogue_and_autograd(ops):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(33, 70, generator=g)
+    W = torch.randn(50, 70, generator=g) * 0.2
+    b = torch.randn(50, generator=g)
+    mask = (torch.rand(33, 50, generator=g) > 0.5)
+    for act, f in [(ops.ACT_TANH, torch.tanh), (ops.ACT_RELU, torch.relu), (ops.ACT_NONE, lambda t: t)]:
+        xr, Wr, br = x.clone().requires_grad_(), W.clone().requires_grad_(), b.clone().requires_grad_()
+        ref = f(xr @ Wr.t() + br) * mask * 2.0
+        ref.square().sum().backward()
+        xd, Wd, bd = (t.detach().to(DEV).requires_grad_() for t in (x, W, b))
+        y = ops.linear(xd, Wd, bd, act, mask.to(DEV, torch.uint8), 2.0)
+        assert rel_err(y, ref) < 2e-5
+        y.square().sum().backward()       # torch glue for the toy loss; grads flow through LinearFn.backward
+        for a, r in [(xd, xr), (Wd, Wr), (bd, br)]:
+            assert rel_err(a.grad, r.grad) < 5e-5
+
+
+def test_lstm_embed_fwd_bwd(ops):
+    from oracle import vqa_oracle as O
+    torch.manual_seed(4)
+    B, T, We, H, V = 5, 7, 12, 16, 30
+    lstm = torch.nn.LSTM(We, H, 1)
+    emb = torch.nn.Embedding(V, We)
+    idx = torch.randint(V, (B, T))
+    h0 = torch.randn(B, H) * 0.3
+    for use_init in (False, True):
+        # torch reference (nn.LSTM itself)
+        v = torch.tanh(emb(idx)).transpose(0, 1)
+        init = (h0.view(1, B, H), h0.view(1, B, H)) if use_init else None
+        out, (h, c) = lstm(v, init)
+        loss = (out * 0.3).sum() + (h * 0.7).sum() + (c * c).sum()
+        params = [emb.weight] + list(lstm.parameters())
+        ref = torch.autograd.grad(loss, params)
+        # HIP
+        pd = [p.detach().to(DEV).requires_grad_() for p in params]
+        h0d = h0.to(DEV).requires_grad_() if use_init else None
+        vd = ops.embed(idx.to(DEV), pd[0], True)
+        od, hd, cd = ops.lstm(vd, pd[1], pd[2], pd[3], pd[4], h0d, h0d)
+        assert rel_err(od, out) < 2e-5 and rel_err(hd, h[0]) < 2e-5 and rel_err(cd, c[0]) < 2e-5
+        lossd = (od * 0.3).sum() + (hd * 0.7).sum() + (cd * cd).sum()
+        got = torch.autograd.grad(lossd, pd)
+        for a, r in zip(got, ref):
+            assert rel_err(a, r) < 1e-4
+
+
+def test_head_ops_and_losses(ops):
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(6, 32, generator=g), torch.randn(6, 32, generator=g)
+    mask = torch.rand(6, 32, generator=g) > 0.5
+    ar, br = a.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = torch.tanh(ar * br) * mask * 2.0
+    ref.sum().backward()
+    ad, bd = a.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    z = ops.MulTanhDropFn.apply(ad, bd, mask.to(DEV, torch.uint8), 2.0)
+    z.sum().backward()
+    assert rel_err(z, ref) < 1e-6 and rel_err(ad.grad, ar.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
+    # L2 norm with detached norm
+    xr = a.clone().requires_grad_()
+    yr = xr / xr.norm(p=2, dim=1, keepdim=True).detach()
+    (yr * b).sum().backward()
+    xd = a.to(DEV).requires_grad_()
+    yd = ops.L2NormFn.apply(xd)
+    (yd * b.to(DEV)).sum().backward()
+    assert rel_err(yd, yr) < 1e-6 and rel_err(xd.grad, xr.grad) < 1e-6
+    # losses
+    lg = torch.randn(9, 3129, generator=g)
+    lab = torch.randint(3129, (9,), generator=g)
+    tgt = torch.softmax(torch.randn(9, 3129, generator=g) / 0.1, 1)
+    for kind in (0, 1):
+        lr = lg.clone().requires_grad_()
+        ref = F.cross_entropy(lr, lab) if kind == 0 else -(tgt * F.log_softmax(lr, 1)).sum() / 9
+        (ref * 1.7).backward()
+        ld = lg.to(DEV).requires_grad_()
+        got = ops.cross_entropy(ld, lab.to(DEV)) if kind == 0 else ops.soft_xent(ld, tgt.to(DEV))
+        (got * 1.7).backward()
+        assert rel_err(got, ref) < 1e-6 and rel_err(ld.grad, lr.grad) < 1e-5
+    assert torch.equal(ops.argmax_rows(lg.to(DEV)).cpu(), lg.argmax(1))
+    assert rel_err(ops.softmax_rows(lg.to(DEV), 10.0), torch.softmax(lg * 10.0, 1)) < 1e-5
+
+
+def test_fused_clip_adam_matches_torch(ops):
+    from lct_vqa_amd.optim import FusedAdam
+    torch.manual_seed(6)
+    shapes = [(300, 17), (64,), (129, 33)]
+    ps = [torch.randn(s) for s in shapes]
+    ref_p = [p.clone().requires_grad_() for p in ps]
+    dev_p = [torch.nn.Parameter(p.clone().to(DEV)) for p in ps]
+    ref_opt = torch.optim.Adam(ref_p, lr=1e-3)
+    for flatten in (True, False):
+        opt = FusedAdam(dev_p, lr=1e-3, flatten=flatten)
+        for it in range(3):
+            gs = [torch.randn(s) * (10.0 if it == 0 else 0.1) for s in shapes]
+            for p, g in zip(ref_p, gs):
+                p.grad = g.clone()
+            torch.nn.utils.clip_grad_norm_(ref_p, 5)
+            ref_opt.step()
+            opt.zero_grad()
+            for p, g in zip(dev_p, gs):
+                if flatten:
+                    p.grad.copy_(g)
+                else:
+                    p.grad = g.to(DEV)
+            if flatten:
+                opt.step(max_grad_norm=5)
+            else:
+                torch.nn.utils.clip_grad_norm_(dev_p, 5)
+                opt.step()
+            for a, r in zip(dev_p, ref_p):
+                assert rel_err(a, r) < 1e-5
+        # second pass continues from the same parameters with a fresh torch optimizer
+        ref_opt = torch.optim.Adam(ref_p, lr=1e-3)
+
+
+def test_dropout_mask_statistics(ops):
+    ops.manual_seed(123)
+    m = ops.dropout_mask((1000, 1000), torch.device(DEV), 0.5)
+    assert abs(m.float().mean().item() - 0.5) < 5e-3
+    ops.manual_seed(123)
+    assert torch.equal(m, ops.dropout_mask((1000, 1000), torch.device(DEV), 0.5))
