@@ -39,12 +39,34 @@ def parse():
     return ap.parse_args()
 
 
+def host_threads():
+    """CPU threads this process may really use: min(affinity, cgroup quota), so that a box whose cgroup grants
+    16 of 256 hardware threads is not oversubscribed 16x."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    env = os.environ.get('LCTVQA_CPU_THREADS')
+    if env:
+        n = int(env)
+    return min(n, 64) if n > 64 else n
+
+
 def cpu_baseline(steps):
     """The oracle's W train step (fwd + CE + bwd + clip + Adam), B=4 at full resolution, timed on the
     host cores of this box.  Reported baseline only (kind 'port': the reference's Python cannot travel)."""
     from oracle import vqa_oracle as O
     from lct_vqa_amd.basic_vqa import models
-    ncores = os.cpu_count() or 1
+    ncores = host_threads()
     torch.set_num_threads(ncores)
     torch.manual_seed(10)
     m = models.VqaModel(**DIMS)
@@ -83,7 +105,7 @@ def main():
 
     torch.manual_seed(10)                           # config.SEED: identical replicas on every rank
     model = models.VqaModel(**DIMS).to(dev).train()
-    opt = FusedAdam(list(model.parameters()), lr=config.LEARNING_RATE, flatten=True)
+    opt = FusedAdam(model.trainable_parameters(), lr=config.LEARNING_RATE, flatten=True)
     trainable = opt.flat['params']
     reducer = parallel.FlatGradReducer(trainable, opt.flat_grad, scale_fn=parallel.hip_scale) if world > 1 else None
 

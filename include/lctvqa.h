@@ -62,8 +62,9 @@ int lctvqa_gemm_f32(const float* A, long a_ms, long a_ks, const float* B, long b
                     int M, int N, int K, const float* bias, const float* addend, long ld_add, int act,
                     const uint8_t* mask, long ld_mask, float mask_scale, float* workspace, long workspace_bytes,
                     void* stream);
-/* out[n] = sum_m X[m][n]  (bias gradients) */
-int lctvqa_colsum_f32(const float* X, long ld, int M, int N, float* out, void* stream);
+/* out[n] = sum_m X[m][n]  (bias gradients); scratch: lctvqa_colsum_scratch_elems(M,N) floats */
+long lctvqa_colsum_scratch_elems(int M, int N);
+int lctvqa_colsum_f32(const float* X, long ld, int M, int N, float* out, float* scratch, void* stream);
 
 /* ---- question encoder: nn.Embedding + tanh + nn.LSTM (models.py:58-61, models_lct.py:101-108) */
 /* idx [B][T] int64 -> out [T][B][E] = (tanh) emb[idx]  (transpose(0,1) fused) */

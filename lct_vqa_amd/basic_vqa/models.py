@@ -89,6 +89,12 @@ class VqaModel(nn.Module):
         qst_feature = self.qst_encoder(qst)
         return self._head(img_feature, qst_feature)
 
+    def trainable_parameters(self):
+        """Parameters that can receive a gradient: everything outside the VGG19 trunk, which runs under
+        no_grad (models.py:35-36).  torch.optim.Adam skips grad-None parameters; a flat arena
+        (optim.FusedAdam(flatten=True)) and the DP all-reduce should only hold these."""
+        return [p for n, p in self.named_parameters() if not n.startswith('img_encoder.model.')]
+
     def new(self):
         new_model = VqaModel(self.embed_size, self.qst_vocab_size, self.ans_vocab_size,
                              self.word_embed_size, self.num_layers, self.hidden_size)

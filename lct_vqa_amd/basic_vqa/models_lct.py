@@ -142,6 +142,11 @@ class VqaModel(nn.Module):
         qst_feature, _ = self.qst_encoder(qst, img_feature)
         return qst, self._head(img_feature, qst_feature)
 
+    def trainable_parameters(self):
+        """See models.VqaModel.trainable_parameters: the trunk is frozen only when pretrained."""
+        frozen = isinstance(self.img_encoder, ImgEncoderFixed) and self.img_encoder.pretrained
+        return [p for n, p in self.named_parameters() if not (frozen and n.startswith('img_encoder.model.'))]
+
     def genotype(self):
         return self.img_encoder.darts.genotype()
 

@@ -22,8 +22,10 @@
 //    lanes read consecutive 16-B slots (bank-conflict free) and the inner loop carries no
 //    address arithmetic at all.  The four waves of a workgroup each gather one chunk plane
 //    of the same 64 pixels, so the 64-B pixel segments are fetched from L2 once;
-//  * double-buffered halo + weight tiles, one barrier per (chunk, tap) step (64 MFMAs
-//    = 4096 cycles per wave), two workgroups per CU so one computes while the other waits;
+//  * every wave streams its OWN 2 KB weight piece per (chunk, tap) step into a private
+//    double buffer and waits only on its own vmcnt -> no workgroup barrier per step; the
+//    one barrier per 16-channel chunk (9 steps, ~500+ MFMAs per wave) guards the shared,
+//    double-buffered halo tile.  Two workgroups per CU cover each other's waits;
 //  * n-tile = blockIdx % NT, so (blocks are dealt round-robin over the 8 XCDs) every XCD
 //    streams the weights of a single n-tile and keeps them in its private 4 MiB L2.
 //  * epilogue fuses bias + ReLU (+ 2x2 max-pool when requested) and writes NHWC.
@@ -69,30 +71,32 @@ __device__ __forceinline__ void subtile_pixel(int msub, int rr, int& ty, int& tx
   tx = (msub % SPR) * SW + sx;
 }
 
-template <int TH, int TW, int SH, int SW, int WM, int WN, int MT, bool POOL>
+template <int TH, int TW, int RS, int SH, int SW, int WM, int WN, int MT, bool POOL>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ y, int Btot, int H, int W, int Cin, int Cout, int relu, int G) {
   static_assert(TH * TW == WM * MT * 32, "tile mismatch");
   static_assert(TW % SW == 0 && TH % SH == 0, "sub-tile must tile the patch");
   static_assert(WM * WN == 4, "4 waves");
-  constexpr int TWP = TW + 2;
+  static_assert(RS >= TW + 2, "LDS row stride must cover the halo row");
+  constexpr int TWP = RS;                             // LDS row stride in pixels (>= TW+2; padded to dodge bank conflicts)
   constexpr int HRMAX = TH + 4;                       // TH + 2 halo + up to 2 gap rows
   constexpr int PMAX = HRMAX * TWP;                   // halo pixels
   constexpr int AROUNDS = (PMAX + 63) / 64;           // each wave gathers one chunk plane of 64 pixels per round
-  constexpr int PPAD = AROUNDS * 64;                  // pixels per plane (padded)
-  constexpr int PLANE = PPAD * 4;                     // floats per chunk plane
+  constexpr int PLANE = PMAX * 4;                     // floats per chunk plane (last round is lane-masked)
   constexpr int ASZ = 4 * PLANE;                      // floats per halo buffer
-  constexpr int WSZ = WN * 512;                       // floats per weight step tile
-  constexpr int WCHUNKS = WN * 128;                   // 16-B chunks per weight step tile
+#ifndef CONV_WBUFS
+#define CONV_WBUFS 3
+#endif
+  constexpr int WBUFS = CONV_WBUFS;                   // private weight ring: 3 = prefetch distance 2 steps, 2 = distance 1
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* abuf = smem;                // [2][ASZ]
-  float* wbuf = smem + 2 * ASZ;      // [2][WSZ]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* wbuf = smem + 2 * ASZ + wave * (WBUFS * 512);   // this wave's private [3][512] weight ring
   const int wm = wave / WN, wn = wave % WN;
   const int j = lane & 31, h = lane >> 5;
 
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     int yv = y0 - 1 + hr;
     int n = n0img;
     while (yv > H) { yv -= (H + 1); n++; }
-    bool ok = (p < PLIVE) && (yv >= 0) && (yv < H) && (n < Btot) && (xx >= 0) && (xx < W);
+    bool ok = (p < PLIVE) && (hx < TW + 2) && (yv >= 0) && (yv < H) && (n < Btot) && (xx >= 0) && (xx < W);
     aoff[r] = ok ? (((n * H + yv) * W + xx) * Cin + wave * 4) : -1;
   }
   // ---- per-lane LDS pixel index (tap (0,0)) of each M-subtile row this lane feeds ----
@@ -132,27 +136,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     int g = (yy >= H) + (yy >= 2 * H);
     base[m] = ((ty + g) * TWP + tx) * 4 + h * PLANE;     // float offset inside a halo buffer
   }
-  const int bbase = wn * 512 + h * 128 + j * 4;           // float offset inside a weight step tile
-  const float* wsrc = wp + (long)(n_tile * WN) * S * 512;   // [WN pieces][S][512] -> piece stride S*512
+  const int bbase = h * 128 + j * 4;                      // float offset inside this wave's weight piece
+  const float* wsrc = wp + (long)(n_tile * WN + wn) * S * 512 + lane * 4;   // this wave's piece stream [S][512]
 
   auto stage_a = [&](int chunk, float* dst) {
 #pragma unroll
     for (int r = 0; r < AROUNDS; r++) {
-      if (r * 64 < PLIVE) {
+      if (r * 64 < PLIVE && r * 64 + lane < PMAX) {
         const float* src = (aoff[r] >= 0) ? (x + (long)aoff[r] + chunk * 16) : g_zero_page;
         glds16(src, dst + wave * PLANE + r * 256);
       }
     }
   };
-  auto stage_w = [&](int s, float* dst) {
-#pragma unroll
-    for (int r = 0; r < (WCHUNKS + 255) / 256; r++) {
-      int q = r * 256 + tid;
-      if (WCHUNKS >= 256 || tid < WCHUNKS) {
-        int piece = q >> 7, within = q & 127;
-        glds16(wsrc + ((long)piece * S + s) * 512 + within * 4, dst + (r * 256 + wave * 64) * 4);
-      }
-    }
+  auto stage_w = [&](int s, float* dst) {            // 2 KB = 2 wave-instructions, private to this wave
+    glds16(wsrc + (long)s * 512, dst);
+    glds16(wsrc + (long)s * 512 + 256, dst + 256);
   };
 
   f32x16 acc[MT];
@@ -163,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 
   stage_a(0, abuf);
   stage_w(0, wbuf);
+  if (WBUFS == 3 && S > 1) stage_w(1, wbuf + 512);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -171,24 +170,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const float* ab = abuf + (chunk & 1) * ASZ;
 #pragma unroll
     for (int tap = 0; tap < 9; tap++, s++) {
-      if (s + 1 < S) stage_w(s + 1, wbuf + ((s + 1) & 1) * WSZ);
+      // prefetch: next halo chunk (once per chunk) first, then the weight piece two steps ahead,
+      // so that the two youngest VMEM ops are always that weight piece (counted vmcnt below)
       if (tap == 0 && chunk + 1 < NCH) stage_a(chunk + 1, abuf + ((chunk + 1) & 1) * ASZ);
-      const float* wb = wbuf + (s & 1) * WSZ + bbase;
+      const bool more = (s + WBUFS - 1 < S);
+      if (more) stage_w(s + WBUFS - 1, wbuf + ((WBUFS == 3) ? ((tap + 2) % 3) : ((s + 1) & 1)) * 512);
+      const float* wb = wbuf + ((WBUFS == 3) ? (tap % 3) : (s & 1)) * 512 + bbase;
       const int tapoff = ((tap / 3) * TWP + (tap % 3)) * 4;
 #pragma unroll
       for (int kk = 0; kk < 2; kk++) {
         const f32x4 bf = *(const f32x4*)(wb + kk * 256);
+        f32x4 af[MT];
 #pragma unroll
-        for (int m = 0; m < MT; m++) {
-          const f32x4 af = *(const f32x4*)(ab + base[m] + tapoff + kk * 2 * PLANE);
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], acc[m], 0, 0, 0);
-        }
+        for (int m = 0; m < MT; m++) af[m] = *(const f32x4*)(ab + base[m] + tapoff + kk * 2 * PLANE);
+        // e outer / m inner: consecutive MFMAs hit independent accumulators
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+          for (int m = 0; m < MT; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][e], bf[e], acc[m], 0, 0, 0);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      // end of step: the weight piece of step s+1 (and, at tap 0, the next halo chunk) must have
+      // landed; the piece of step s+2 stays in flight.  (The compiler may slide register-only MFMAs
+      // across this wait; with a prefetch distance of two steps the wait never stalls either way.)
+      if (more && WBUFS == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tap == 8) __syncthreads();                      // halo buffers swap roles
     }
   }
 
@@ -276,35 +282,65 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restr
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ y, int B, int H, int W,
                                                             int Cout, int relu) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [3 ch][3 rows][W+2]
-  const int WP = W + 2;
-  const int R = blockIdx.x;             // stacked row n*H + y
+  constexpr int PX = 8;                  // output pixels per wave iteration (register blocking)
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [3 ch][3 rows][WP], index i <-> x = i-1
+  const int WP = (W + 2 + PX + 3) & ~3;  // padded (multiple of 4 floats: rows stay 16-B aligned; tail over-reads zeros)
+  const int R = blockIdx.x;              // stacked row n*H + y
   const int n = R / H, yy = R % H;
-  for (int i = threadIdx.x; i < 9 * WP; i += blockDim.x) {
-    int c = i / (3 * WP), r = (i / WP) % 3, xx = i % WP - 1;
-    int iy = yy + r - 1;
-    float v = 0.f;
-    if (iy >= 0 && iy < H && xx >= 0 && xx < W) v = x[(((long)n * 3 + c) * H + iy) * W + xx];
-    smem[i] = v;
+  for (int i0 = 0; i0 < WP; i0 += blockDim.x) {       // all 9 row loads in flight before the first LDS store
+    const int i = i0 + threadIdx.x, xx = i - 1;
+    float v[9];
+#pragma unroll
+    for (int cr = 0; cr < 9; cr++) {
+      const int c = cr / 3, iy = yy + (cr % 3) - 1;
+      const bool ok = (iy >= 0) && (iy < H) && (xx >= 0) && (xx < W);
+      const long off = (((long)n * 3 + c) * H + (ok ? iy : 0)) * W + (ok ? xx : 0);
+      const float t = x[off];
+      v[cr] = ok ? t : 0.f;
+    }
+    if (i < WP) {
+#pragma unroll
+      for (int cr = 0; cr < 9; cr++) smem[cr * WP + i] = v[cr];
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  float* wsm = smem + 9 * WP;            // [27][64] weights of the current 64-channel group, cout fastest
   for (int cg = 0; cg < Cout; cg += 64) {
     const int co = cg + lane;
-    float wr[27];
-#pragma unroll
-    for (int k = 0; k < 27; k++) wr[k] = (co < Cout) ? w[co * 27 + k] : 0.f;   // [co][ci][ky][kx]
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * 64; i += blockDim.x) {
+      const int k = i >> 6, c = min(cg + (i & 63), Cout - 1);
+      wsm[i] = w[c * 27 + k];                                      // [co][ci][ky][kx]
+    }
+    __syncthreads();
     const float bv = (bias && co < Cout) ? bias[co] : 0.f;
-    for (int xx = wave; xx < W; xx += nw) {
-      float a = bv;
+    for (int x0 = wave * PX; x0 < W; x0 += nw * PX) {
+      float a[PX];
 #pragma unroll
-      for (int c = 0; c < 3; c++)
+      for (int i = 0; i < PX; i++) a[i] = bv;
+#pragma unroll 1
+      for (int cr = 0; cr < 9; cr++) {                   // rolled: keeps ~30 live VGPRs -> 8 waves/SIMD
+        const float* row = smem + cr * WP + x0;          // wave-uniform, 16-B aligned: 3 broadcast LDS reads
+        const f32x4 i0 = *(const f32x4*)row, i1 = *(const f32x4*)(row + 4), i2 = *(const f32x4*)(row + 8);
+        float in[12];
 #pragma unroll
-        for (int r = 0; r < 3; r++)
+        for (int i = 0; i < 4; i++) { in[i] = i0[i]; in[4 + i] = i1[i]; in[8 + i] = i2[i]; }
 #pragma unroll
-          for (int k = 0; k < 3; k++) a = fmaf(smem[(c * 3 + r) * WP + xx + k], wr[c * 9 + r * 3 + k], a);
-      if (relu) a = fmaxf(a, 0.f);
-      if (co < Cout) y[((long)R * W + xx) * Cout + co] = a;
+        for (int k = 0; k < 3; k++) {
+          const float wv = wsm[(cr * 3 + k) * 64 + lane];
+#pragma unroll
+          for (int i = 0; i < PX; i++) a[i] = fmaf(in[i + k], wv, a[i]);
+        }
+      }
+      if (co < Cout) {
+#pragma unroll
+        for (int i = 0; i < PX; i++)
+          if (x0 + i < W) {
+            float v = relu ? fmaxf(a[i], 0.f) : a[i];
+            y[((long)R * W + x0 + i) * Cout + co] = v;
+          }
+      }
     }
   }
 }
@@ -362,24 +398,23 @@ static int max_boundaries(int H, int TH, long Rtot) {
   return best;
 }
 
-template <int TH, int TW, int SH, int SW, int WM, int WN, int MT>
+template <int TH, int TW, int RS, int SH, int SW, int WM, int WN, int MT>
 static int launch_conv(const float* x, const float* wp, const float* bias, float* y, int B, int H, int W, int Cin,
                        int Cout, int relu, int pool, int G, hipStream_t st) {
-  constexpr int TWP = TW + 2;
-  constexpr int AROUNDS = ((TH + 4) * TWP + 63) / 64;
-  constexpr int ASZ = AROUNDS * 64 * 16;
-  constexpr int WSZ = WN * 512;
-  size_t lds = (size_t)(2 * ASZ + 2 * WSZ) * sizeof(float);
+  constexpr int TWP = RS;
+  constexpr int ASZ = (TH + 4) * TWP * 16;
+  constexpr int WSZ = 4 * CONV_WBUFS * 512;
+  size_t lds = (size_t)(2 * ASZ + WSZ) * sizeof(float);
   long Rtot = (long)B * H;
   int mtiles = cdiv(Rtot, TH) * (W / TW);
   int ntiles = Cout / (32 * WN);
   dim3 grid(mtiles * ntiles);
   if (pool) {
-    auto k = conv3x3_mfma_kernel<TH, TW, SH, SW, WM, WN, MT, true>;
+    auto k = conv3x3_mfma_kernel<TH, TW, RS, SH, SW, WM, WN, MT, true>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, wp, bias, y, B, H, W, Cin, Cout, relu, G);
   } else {
-    auto k = conv3x3_mfma_kernel<TH, TW, SH, SW, WM, WN, MT, false>;
+    auto k = conv3x3_mfma_kernel<TH, TW, RS, SH, SW, WM, WN, MT, false>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, wp, bias, y, B, H, W, Cin, Cout, relu, G);
   }
@@ -446,19 +481,19 @@ int lctvqa_conv3x3_nhwc(const float* x, const float* w_oihw, const float* w_pack
   LCT_REQUIRE(w_packed != nullptr, "conv3x3_nhwc: packed weights required");
   long Rtot = (long)B * H;
   const bool n4 = (Cout % 128 == 0);
-#define LAUNCH(TH, TW, SH, SW)                                                                                          \
+#define LAUNCH(TH, TW, RS, SH, SW)                                                                                          \
   do {                                                                                                          \
     int G = max_boundaries(H, TH, Rtot);                                                                        \
     constexpr int BMs = (TH * TW) / 32;                                                                         \
-    if (n4) return launch_conv<TH, TW, SH, SW, 1, 4, BMs>(x, w_packed, bias, y, B, H, W, Cin, Cout, relu, pool, G, st); \
+    if (n4) return launch_conv<TH, TW, RS, SH, SW, 1, 4, BMs>(x, w_packed, bias, y, B, H, W, Cin, Cout, relu, pool, G, st); \
     if constexpr (BMs % 2 == 0)                                                                                 \
-      return launch_conv<TH, TW, SH, SW, 2, 2, BMs / 2>(x, w_packed, bias, y, B, H, W, Cin, Cout, relu, pool, G, st);   \
+      return launch_conv<TH, TW, RS, SH, SW, 2, 2, BMs / 2>(x, w_packed, bias, y, B, H, W, Cin, Cout, relu, pool, G, st);   \
   } while (0)
-  if (W % 32 == 0) LAUNCH(8, 32, 2, 16);
-  else if (W % 28 == 0) LAUNCH(8, 28, 8, 4);
-  else if (W % 16 == 0) LAUNCH(16, 16, 2, 16);
-  else if (W % 14 == 0) LAUNCH(16, 14, 16, 2);
-  else if (W % 8 == 0) LAUNCH(32, 8, 4, 8);
+  if (W % 32 == 0) LAUNCH(8, 32, 34, 2, 16);
+  else if (W % 28 == 0) LAUNCH(8, 28, 36, 8, 4);
+  else if (W % 16 == 0) LAUNCH(16, 16, 18, 2, 16);
+  else if (W % 14 == 0) LAUNCH(16, 14, 18, 16, 2);
+  else if (W % 8 == 0) LAUNCH(32, 8, 10, 4, 8);
 #undef LAUNCH
   lct_set_error("conv3x3_nhwc: no tiling for H=%d W=%d Cin=%d Cout=%d", H, W, Cin, Cout);
   return LCT_EUNSUPPORTED;
@@ -467,7 +502,7 @@ int lctvqa_conv3x3_nhwc(const float* x, const float* w_oihw, const float* w_pack
 int lctvqa_conv3x3_first_nchw(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc, int B,
                               int H, int W, int Cout, int relu, void* stream) {
   LCT_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_first: bad shape");
-  size_t lds = (size_t)9 * (W + 2) * sizeof(float);
+  size_t lds = (size_t)(9 * ((W + 2 + 8 + 3) & ~3) + 27 * 64) * sizeof(float);
   LCT_REQUIRE(lds <= 64 * 1024, "conv3x3_first: W too large");
   hipLaunchKernelGGL(conv3x3_first_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, x_nchw, w_oihw, bias,
                      y_nhwc, B, H, W, Cout, relu);

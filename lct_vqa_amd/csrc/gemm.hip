@@ -170,17 +170,27 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ ws, int spli
   }
 }
 
-// column sums: out[n] = sum_m X[m][n]  (bias gradients)
-__global__ void colsum_kernel(const float* __restrict__ X, long ld, int M, int N, float* __restrict__ out) {
-  __shared__ float part[4][64];
+// column sums: out[n] = sum_m X[m][n]  (bias gradients), deterministic two-stage reduction.
+// stage 1: block (cb, rb) sums rows [rb*rows_per, ...) of 64 columns -> part[rb][n]; stage 2 sums the parts.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long ld, int M, int N, int rows_per,
+                                                            float* __restrict__ part) {
+  __shared__ float red[4][64];
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   const int w = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
   float a = 0.f;
   if (n < N)
-    for (int m = w; m < M; m += 4) a += X[(long)m * ld + n];
-  part[w][threadIdx.x & 63] = a;
+    for (int m = r0 + w; m < r1; m += 4) a += X[(long)m * ld + n];
+  red[w][threadIdx.x & 63] = a;
   __syncthreads();
-  if (w == 0 && n < N) out[n] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+  if (w == 0 && n < N) part[(long)blockIdx.y * N + n] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void colsum_finish_kernel(const float* __restrict__ part, int S, int N, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float a = 0.f;
+  for (int s = 0; s < S; s++) a += part[(long)s * N + n];
+  out[n] = a;
 }
 
 static int pick_mode(const float* P, long rs, long ks, int K) {
@@ -246,10 +256,23 @@ int lctvqa_gemm_f32(const float* A, long a_ms, long a_ks, const float* B, long b
   return lct_check_launch("gemm_splitk_reduce");
 }
 
-int lctvqa_colsum_f32(const float* X, long ld, int M, int N, float* out, void* stream) {
-  LCT_REQUIRE(M > 0 && N > 0, "colsum: bad shape");
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, X, ld, M, N, out);
-  return lct_check_launch("colsum");
+long lctvqa_colsum_scratch_elems(int M, int N) {
+  int S = cdiv(M, 64);
+  if (S > 64) S = 64;
+  return (long)S * N;
+}
+
+int lctvqa_colsum_f32(const float* X, long ld, int M, int N, float* out, float* scratch, void* stream) {
+  LCT_REQUIRE(M > 0 && N > 0 && scratch != nullptr, "colsum: bad args");
+  int S = cdiv(M, 64);
+  if (S > 64) S = 64;
+  int rows_per = cdiv(M, S);
+  S = cdiv(M, rows_per);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), S), dim3(256), 0, (hipStream_t)stream, X, ld, M, N, rows_per, scratch);
+  int rc = lct_check_launch("colsum_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, scratch, S, N, out);
+  return lct_check_launch("colsum_finish");
 }
 
 }  // extern "C"

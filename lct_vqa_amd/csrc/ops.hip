@@ -304,7 +304,13 @@ __global__ void dropout_mask_kernel(uint8_t* __restrict__ mask, long n, uint64_t
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
   __shared__ float red[4];
   float s = 0.f;
-  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) { float v = g[o]; s += v * v; }
+  const long n4 = n >> 2;
+  const f32x4* g4 = (const f32x4*)g;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n4; o += (long)gridDim.x * blockDim.x) {
+    f32x4 v = g4[o];
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { float v = g[(n4 << 2) + threadIdx.x]; s += v * v; }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -320,7 +326,15 @@ __global__ void norm_finish_kernel(const float* __restrict__ part, int np, float
   __syncthreads();
   if (threadIdx.x == 0) norm_out[0] = sqrtf(red[0] + red[1] + red[2] + red[3]);
 }
-__global__ void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__device__ __forceinline__ void adam_one(float& pp, float gg, float& mm, float& vv, float coef, float wd, float b1, float b2,
+                                         float step, float rs2, float eps) {
+  gg *= coef;
+  if (wd != 0.f) gg += wd * pp;
+  mm = b1 * mm + (1.f - b1) * gg;
+  vv = b2 * vv + (1.f - b2) * gg * gg;
+  pp = pp - step * mm / (sqrtf(vv) * rs2 + eps);
+}
+__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, long n, const float* __restrict__ total_norm, float max_norm,
                                  float lr, float b1, float b2, float eps, float bc1, float bc2, float wd) {
   float coef = 1.f;
@@ -329,14 +343,23 @@ __global__ void adam_clip_kernel(float* __restrict__ p, const float* __restrict_
     coef = coef < 1.f ? coef : 1.f;
   }
   const float step = lr / bc1, rs2 = 1.f / sqrtf(bc2);
-  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
-    float gg = g[o] * coef;
-    float pp = p[o];
-    if (wd != 0.f) gg += wd * pp;
-    float mm = b1 * m[o] + (1.f - b1) * gg;
-    float vv = b2 * v[o] + (1.f - b2) * gg * gg;
-    m[o] = mm; v[o] = vv;
-    p[o] = pp - step * mm / (sqrtf(vv) * rs2 + eps);
+  const long n4 = n >> 2;
+  f32x4* p4 = (f32x4*)p; const f32x4* g4 = (const f32x4*)g; f32x4* m4 = (f32x4*)m; f32x4* v4 = (f32x4*)v;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n4; o += (long)gridDim.x * blockDim.x) {
+    f32x4 pp = p4[o], gg = g4[o], mm = m4[o], vv = v4[o];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      float a = pp[k], b = mm[k], c = vv[k];
+      adam_one(a, gg[k], b, c, coef, wd, b1, b2, step, rs2, eps);
+      pp[k] = a; mm[k] = b; vv[k] = c;
+    }
+    p4[o] = pp; m4[o] = mm; v4[o] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long o = (n4 << 2) + threadIdx.x;
+    float pp = p[o], mm = m[o], vv = v[o];
+    adam_one(pp, g[o], mm, vv, coef, wd, b1, b2, step, rs2, eps);
+    p[o] = pp; m[o] = mm; v[o] = vv;
   }
 }
 // y = a*x + y  (architect vector ops on the flat arena: architect_lct.py:112-116,194-207)
@@ -440,7 +463,8 @@ int lctvqa_dropout_mask(uint8_t* mask, long n, unsigned long long seed, unsigned
 }
 // total_norm_out[0] = ||g||_2 over the flat arena;  scratch: >= 1024 floats
 int lctvqa_grad_norm(const float* g, long n, float* scratch, float* total_norm_out, void* stream) {
-  int nb = ew_blocks(n, 1024);
+  LCT_REQUIRE(((uintptr_t)g & 15) == 0, "grad_norm: arena must be 16-B aligned");
+  int nb = ew_blocks(n, 2048);
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, n, scratch);
   int rc = lct_check_launch("sumsq_partial");
@@ -452,8 +476,9 @@ int lctvqa_grad_norm(const float* g, long n, float* scratch, float* total_norm_o
 int lctvqa_adam_step(float* p, const float* g, float* m, float* v, long n, const float* total_norm, float max_norm,
                      float lr, float b1, float b2, float eps, int step, float weight_decay, void* stream) {
   LCT_REQUIRE(step >= 1, "adam_step: step counts from 1");
-  float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
-  hipLaunchKernelGGL(adam_clip_kernel, dim3(ew_blocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, total_norm, max_norm, lr, b1, b2, eps, bc1, bc2, weight_decay);
+  LCT_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: buffers must be 16-B aligned");
+  float bc1 = (float)(1.0 - pow((double)b1, (double)step)), bc2 = (float)(1.0 - pow((double)b2, (double)step));
+  hipLaunchKernelGGL(adam_clip_kernel, dim3(ew_blocks(n, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, total_norm, max_norm, lr, b1, b2, eps, bc1, bc2, weight_decay);
   return lct_check_launch("adam_step");
 }
 int lctvqa_axpy(float a, const float* x, float* y, long n, void* stream) {

@@ -71,7 +71,8 @@ def linear_bwd_weight(dY, X):
 def colsum(X):
     M, N = X.shape
     out = torch.empty(N, dtype=torch.float32, device=X.device)
-    lib('colsum_f32', X, X.stride(0), M, N, out)
+    scratch = torch.empty(lib.query('colsum_scratch_elems', M, N), dtype=torch.float32, device=X.device)
+    lib('colsum_f32', X, X.stride(0), M, N, out, scratch)
     return out
 
 

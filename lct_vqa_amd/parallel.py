@@ -101,3 +101,18 @@ def init_distributed():
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, world, local
+
+
+def make_flat_grad(params):
+    """Allocate one flat fp32 gradient buffer and point every p.grad at its slice (any device).
+    optim.FusedAdam(flatten=True) does the same for the HBM arena; this helper serves callers that
+    bring their own optimizer (and the CPU/gloo tests)."""
+    params = list(params)
+    n = sum(p.numel() for p in params)
+    flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+    o = 0
+    for p in params:
+        k = p.numel()
+        p.grad = flat[o:o + k].view_as(p.data)
+        o += k
+    return flat

@@ -99,7 +99,7 @@ def test_train_step_matches_oracle(pkg):
     m = _build(models.VqaModel, fx).train()
     P = full_params(fx)
     img, qst, lab = fx['image'], fx['question'], fx['label']
-    opt = FusedAdam([p for p in m.parameters()], lr=1e-3, flatten=True)
+    opt = FusedAdam(m.trainable_parameters(), lr=1e-3, flatten=True)
     state = {}
     for it in range(2):
         masks = [mk.float() for mk in fx['train_masks']]

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the conv3x3 kernels on the VGG19 layer shapes at batch B (random data).
+    python tools/bench_conv.py [--batch 256] [--iters 5] [--only 224,14]
+Prints ms and TFLOP/s per layer (HIP events on the launch stream) and the total."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lct_vqa_amd._lib import lib  # noqa: E402
+
+LAYERS = [(224, 64, 64, 1), (112, 64, 128, 0), (112, 128, 128, 1), (56, 128, 256, 0), (56, 256, 256, 0), (56, 256, 256, 0),
+          (56, 256, 256, 1), (28, 256, 512, 0), (28, 512, 512, 0), (28, 512, 512, 0), (28, 512, 512, 1),
+          (14, 512, 512, 0), (14, 512, 512, 0), (14, 512, 512, 0), (14, 512, 512, 1)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--only', default='')
+    args = ap.parse_args()
+    lib.load()
+    dev = torch.device('cuda')
+    B = args.batch
+    only = [int(v) for v in args.only.split(',')] if args.only else None
+    tot_ms = tot_fl = 0.0
+    # first layer
+    x = torch.randn(B, 3, 224, 224, device=dev)
+    w = torch.randn(64, 3, 3, 3, device=dev) * 0.2
+    b = torch.zeros(64, device=dev)
+    y = torch.empty(B, 224, 224, 64, device=dev)
+    for it in range(args.iters + 1):
+        if it == 1:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+        lib('conv3x3_first_nchw', x, w, b, y, B, 224, 224, 64, 1)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.iters
+    print(f'first 3->64 @224: {ms:.3f} ms  ({y.numel() * 4 / ms / 1e6:.0f} GB/s written)')
+    del x, y
+    seen = {}
+    for (H, Cin, Cout, pool) in LAYERS:
+        if only and H not in only:
+            continue
+        key = (H, Cin, Cout, pool)
+        if key not in seen:
+            xin = torch.randn(B, H, H, Cin, device=dev)
+            wt = torch.randn(Cout, Cin, 3, 3, device=dev) * (2.0 / (9 * Cin)) ** 0.5
+            bs = torch.zeros(Cout, device=dev)
+            wp = torch.empty(Cout * Cin * 9, device=dev)
+            lib('conv3x3_pack_weights', wt, wp, Cout, Cin)
+            Ho = H // 2 if pool else H
+            out = torch.empty(B, Ho, Ho, Cout, device=dev)
+            for it in range(args.iters + 1):
+                if it == 1:
+                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+                lib('conv3x3_nhwc', xin, wt, wp, bs, out, None, B, H, H, Cin, Cout, 1, pool)
+            e1.record(); torch.cuda.synchronize()
+            seen[key] = e0.elapsed_time(e1) / args.iters
+            del xin, out
+        ms = seen[key]
+        fl = 2.0 * B * H * H * Cout * Cin * 9
+        tot_ms += ms; tot_fl += fl
+        print(f'conv {H:3d}x{H:<3d} {Cin:3d}->{Cout:3d}{"+pool" if pool else "     "}: {ms:7.3f} ms  {fl / ms / 1e9:6.1f} TFLOP/s')
+    print(f'TOTAL mfma conv: {tot_ms:.3f} ms  {tot_fl / tot_ms / 1e9:.1f} TFLOP/s  ({tot_fl / tot_ms / 1e9 / 157.3 * 100:.1f}% of 157.3)')
+
+
+if __name__ == '__main__':
+    main()
