@@ -53,6 +53,20 @@ int lctvqa_maxpool2x2_nhwc(const float* x, float* y, int B, int H, int W, int C,
 /* AdaptiveAvgPool2d((7,7)) + torch.flatten(x,1) in NCHW feature order: NHWC -> [B, C*49] */
 int lctvqa_adaptive_avgpool7_flatten(const float* x_nhwc, float* y, int B, int H, int W, int C, void* stream);
 
+/* ---- backward of the VGG19 conv blocks (trainable trunk: models_lct.py:62-63, pretrained=False) ------- */
+/* weights of the dgrad convolution (run lctvqa_conv3x3_nhwc on dZ with these; Cin/Cout swap roles) */
+int lctvqa_conv3x3_pack_weights_dgrad(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream);
+/* dZ = relu'(act) * unpool(dout): act [B,H,W,C] post-ReLU; dout [B,H/2,W/2,C] if pool else [B,H,W,C] */
+int lctvqa_relu_pool_bwd_nhwc(const float* dout, const float* act, float* dz, int B, int H, int W, int C, int pool, void* stream);
+int lctvqa_adaptive_avgpool7_flatten_bwd(const float* dy, float* dx_nhwc, int B, int H, int W, int C, void* stream);
+/* dW (OIHW) = sum_pixels dz[p][co] * x[p+tap][ci];  x, dz NHWC; scratch: ..._scratch_elems floats */
+long lctvqa_conv3x3_wgrad_scratch_elems(int B, int H, int W, int Cin, int Cout);
+int lctvqa_conv3x3_wgrad_nhwc(const float* x, const float* dz, float* dw_oihw, float* scratch, int B, int H, int W, int Cin,
+                              int Cout, void* stream);
+long lctvqa_conv3x3_first_wgrad_scratch_elems(int B, int H, int W, int Cout);
+int lctvqa_conv3x3_first_wgrad(const float* x_nchw, const float* dz_nhwc, float* dw, float* db, float* scratch, int B, int H,
+                               int W, int Cout, void* stream);
+
 /* ---- GEMM: every nn.Linear on the path (models.py:29,37,53,66,80,81; models_lct.py:87-88)
  *      and both of its backward products, via operand strides.
  *      C[m][n] = mask*mask_scale*act(sum_k A[m*a_ms+k*a_ks]*B[n*b_ns+k*b_ks] + bias[n] + addend[m][n])
@@ -62,6 +76,12 @@ int lctvqa_gemm_f32(const float* A, long a_ms, long a_ks, const float* B, long b
                     int M, int N, int K, const float* bias, const float* addend, long ld_add, int act,
                     const uint8_t* mask, long ld_mask, float mask_scale, float* workspace, long workspace_bytes,
                     void* stream);
+/* same with ReLU fused into the operand loads: relu_ab bit 0 -> A, bit 1 -> B (PC-DARTS ReLU->Conv1x1 blocks,
+ * pcdarts/operations.py:27-28,43,58-61, and their weight gradients) */
+int lctvqa_gemm_f32_ex(const float* A, long a_ms, long a_ks, const float* B, long b_ns, long b_ks, float* C, long ldc,
+                       int M, int N, int K, const float* bias, const float* addend, long ld_add, int act,
+                       const uint8_t* mask, long ld_mask, float mask_scale, float* workspace, long workspace_bytes,
+                       int relu_ab, void* stream);
 /* out[n] = sum_m X[m][n]  (bias gradients); scratch: lctvqa_colsum_scratch_elems(M,N) floats */
 long lctvqa_colsum_scratch_elems(int M, int N);
 int lctvqa_colsum_f32(const float* X, long ld, int M, int N, float* out, float* scratch, void* stream);
@@ -93,14 +113,57 @@ int lctvqa_scale_rows(const float* x, const float* s, float* y, int M, int N, vo
 
 /* ---- losses: nn.CrossEntropyLoss (kind 0) and softXEnt (kind 1), models.py:7-10,89,115-125.
  *      loss_out[0] = loss_scale * sum_rows;  dlogits (optional) = gscale * d(row loss)/d logits */
+/*      dtarget (optional, kind 1, dense [M][N]) = gscale * d(row loss)/d target = gscale * -(log_softmax) */
 int lctvqa_xent(const float* logits, long ld, const long* labels, const float* target, long ldt, float* row_loss,
-                float* loss_out, float loss_scale, float* dlogits, long ldd, float gscale, int M, int N, int kind, void* stream);
+                float* loss_out, float loss_scale, float* dlogits, long ldd, float gscale, float* dtarget, int M, int N, int kind,
+                void* stream);
 /* F.softmax(x * inv_temp, dim=1)  (experiment.py:245, architect_lct.py:55) */
 int lctvqa_softmax_rows(const float* x, float* y, int M, int N, float inv_temp, void* stream);
+int lctvqa_softmax_rows_bwd(const float* dy, const float* y, float* dx, int M, int N, float inv_temp, void* stream);
 /* torch.argmax(x, 1) (first maximal index) -> int64  (models_lct.py:161, experiment.py:218) */
 int lctvqa_argmax_rows(const float* x, long ld, int M, int N, long* out, void* stream);
 /* nn.Dropout keep mask from a counter-based generator: mask[i] = U(seed, offset+i) >= p */
 int lctvqa_dropout_mask(uint8_t* mask, long n, unsigned long long seed, unsigned long long offset, float p, void* stream);
+
+/* ---- PC-DARTS search-cell primitives on NHWC activations (pcdarts/operations.py:4-104,
+ *      pcdarts/model_search.py:11-91).  x dense [B,H,W,C] unless a row stride ld* is given. -------------- */
+int lctvqa_slice_channels(const float* x, long ldx, int c0, float* y, int Cn, long P, void* stream);
+int lctvqa_slice_channels_bwd(const float* dy, int Cn, int c0, float* dx, int C, long P, void* stream);
+int lctvqa_copy_into_channels(const float* x, int Cn, float* y, long ldy, int c0, long P, void* stream);
+/* depthwise KxK conv (groups=C), w [C][K][K], optional ReLU on the input (ReLU->dwconv of SepConv/DilConv) */
+int lctvqa_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int K, int stride, int pad, int dil,
+                      int relu_in, void* stream);
+int lctvqa_dwconv_bwd_input(const float* dy, const float* w, const float* x, float* dx, int B, int H, int W, int C, int K,
+                            int stride, int pad, int dil, int relu_in, void* stream);
+long lctvqa_dwconv_bwd_weight_scratch_elems(int B, int H, int W, int C, int K, int stride, int pad, int dil);
+int lctvqa_dwconv_bwd_weight(const float* dy, const float* x, float* dw, float* scratch, int B, int H, int W, int C, int K,
+                             int stride, int pad, int dil, int relu_in, void* stream);
+/* 3x3 pooling pad 1: kind 0 = MaxPool2d, 1 = AvgPool2d(count_include_pad=False) */
+int lctvqa_pool3x3_fwd(const float* x, float* y, int B, int H, int W, int C, int stride, int kind, void* stream);
+int lctvqa_pool3x3_bwd(const float* dy, const float* x, float* dx, int B, int H, int W, int C, int stride, int kind, void* stream);
+/* y = relu?(x[:, off::2, off::2, :])  (FactorizedReduce taps) and the joint backward of both taps */
+int lctvqa_subsample2_fwd(const float* x, float* y, int B, int H, int W, int C, int off, int relu, void* stream);
+int lctvqa_subsample2_bwd(const float* dy0, const float* dy1, const float* x, float* dx, int B, int H, int W, int C, int relu,
+                          void* stream);
+/* BatchNorm2d over P = B*H*W rows of C channels (row strides ldx/ldy): batch statistics when training, else running */
+long lctvqa_bn_scratch_doubles(long P, int C);
+int lctvqa_batchnorm_fwd(const float* x, long ldx, float* y, long ldy, long P, int C, const float* gamma, const float* beta,
+                         float* run_mean, float* run_var, float* mean, float* invstd, double* scratch, int training, float momentum,
+                         float eps, void* stream);
+int lctvqa_batchnorm_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* invstd,
+                         const float* gamma, float* dx, float* dgamma, float* dbeta, float* sums, double* scratch, long P, int C,
+                         int training, void* stream);
+/* MixedOp tail: out (+)= beta * channel_shuffle(cat(sum_k w_k branch_k, bypass(x)), 4)  (model_search.py:41-55,87) */
+int lctvqa_mixed_combine_fwd(const float* const* branches, int nbr, const float* wts, const float* beta, const float* x, int B,
+                             int Ho, int Wo, int C, int reduce, float* out, long ldo, int accumulate, void* stream);
+int lctvqa_mixed_combine_bwd_branch(const float* dout, long ldd, const float* wts, int k, const float* beta, float* dbr, long P, int Cq,
+                                    void* stream);
+int lctvqa_mixed_combine_bwd_x(const float* dout, long ldd, const float* beta, const float* x, float* dx, int B, int H, int W, int C,
+                               int reduce, void* stream);
+long lctvqa_mixed_combine_scratch_elems(int B, int Ho, int Wo);
+int lctvqa_mixed_combine_bwd_scalars(const float* dout, long ldd, const float* const* branches, int nbr, const float* wts,
+                                     const float* beta, const float* x, int B, int Ho, int Wo, int C, int reduce, float* dw,
+                                     float* dbeta, float* scratch, void* stream);
 
 /* ---- optimiser on a flat parameter arena: clip_grad_norm_(5) + Adam (experiment.py:226-227,
  *      model_factory.py:20-21) and the architects' vector ops (architect_lct.py:112-116) ---- */

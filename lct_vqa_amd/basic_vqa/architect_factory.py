@@ -1,6 +1,7 @@
-"""Reference basic_vqa/architect_factory.py:5-16: None for ARCH_TYPE 'fixed'; the PC-DARTS
-architects ('darts') arrive with the DARTS encoder kernels."""
+"""Reference basic_vqa/architect_factory.py:5-16."""
 from . import config as _config
+from .pcdarts.architect import Architect
+from .pcdarts.architect_lct import ArchitectLct
 
 
 def get_architect(ef_model, w_model, ef_optimizer, w_optimizer):
@@ -8,7 +9,9 @@ def get_architect(ef_model, w_model, ef_optimizer, w_optimizer):
     if config.ARCH_TYPE == 'fixed':
         return None
     elif config.ARCH_TYPE == 'darts':
-        raise NotImplementedError(
-            "lct_vqa_amd: ARCH_TYPE='darts' (PC-DARTS encoder + Architect/ArchitectLct) is not built yet")
+        if config.SKIP_STAGE2:
+            return Architect(ef_model)
+        else:
+            return ArchitectLct(ef_model, w_model, ef_optimizer, w_optimizer)
     else:
         assert False and 'unrecognized ARCH_TYPE'

@@ -75,7 +75,7 @@ class VqaModel(nn.Module):
     def _head(self, img_feature, qst_feature):
         """mul -> tanh -> dropout -> fc1 -> tanh -> dropout -> fc2 (reference models.py:96-102)."""
         p = self.dropout.p
-        train = self.training and p > 0
+        train = ops.dropout_active(self.dropout.training, p)
         dev = img_feature.device
         scale = 1.0 / (1.0 - p) if train else 1.0
         m1 = ops.dropout_mask(tuple(img_feature.shape), dev, p) if train else None

@@ -425,20 +425,27 @@ extern "C" {
 
 long lctvqa_conv3x3_packed_elems(int Cout, int Cin) { return (long)Cout * Cin * 9; }
 
+// patch selection: 0 none, 1 (8,32), 2 (8,28), 3 (16,16), 4 (16,14), 5 (32,8).  The 7-sub-tile patches
+// (224 pixels) only exist in the 1x4 wave layout, i.e. for Cout % 128 == 0.
+static int select_patch(int W, int Cout) {
+  const bool n4 = (Cout % 128 == 0);
+  if (W % 32 == 0) return 1;
+  if (n4 && W % 28 == 0) return 2;
+  if (W % 16 == 0) return 3;
+  if (n4 && W % 14 == 0) return 4;
+  if (W % 8 == 0) return 5;
+  return 0;
+}
+static int patch_th(int sel) { return sel == 1 || sel == 2 ? 8 : (sel == 5 ? 32 : 16); }
+
 // returns 1 when the MFMA kernel tiles this shape, 0 when the direct fallback is used
 int lctvqa_conv3x3_uses_mfma(int B, int H, int W, int Cin, int Cout, int pool) {
   if (Cin % 16 || Cout % 64) return 0;
   if (pool && ((H & 1) || (W & 1))) return 0;
-  long Rtot = (long)B * H;
-  int TH, TW;
-  if (W % 32 == 0) { TH = 8; TW = 32; }
-  else if (W % 28 == 0) { TH = 8; TW = 28; }
-  else if (W % 16 == 0) { TH = 16; TW = 16; }
-  else if (W % 14 == 0) { TH = 16; TW = 14; }
-  else if (W % 8 == 0) { TH = 32; TW = 8; }
-  else return 0;
-  if ((TH * TW) % 64 && Cout % 128) return 0;    // 224-pixel tiles only exist in the WN=4 layout
-  if (max_boundaries(H, TH, Rtot) > 2) return 0;
+  const int sel = select_patch(W, Cout);
+  if (!sel) return 0;
+  if (max_boundaries(H, patch_th(sel), (long)B * H) > 2) return 0;
+  if ((long)B * H * W * Cin >= (1L << 31)) return 0;      // 32-bit element offsets in the halo staging
   return 1;
 }
 
@@ -489,11 +496,14 @@ int lctvqa_conv3x3_nhwc(const float* x, const float* w_oihw, const float* w_pack
     if constexpr (BMs % 2 == 0)                                                                                 \
       return launch_conv<TH, TW, RS, SH, SW, 2, 2, BMs / 2>(x, w_packed, bias, y, B, H, W, Cin, Cout, relu, pool, G, st);   \
   } while (0)
-  if (W % 32 == 0) LAUNCH(8, 32, 34, 2, 16);
-  else if (W % 28 == 0) LAUNCH(8, 28, 36, 8, 4);
-  else if (W % 16 == 0) LAUNCH(16, 16, 18, 2, 16);
-  else if (W % 14 == 0) LAUNCH(16, 14, 18, 16, 2);
-  else if (W % 8 == 0) LAUNCH(32, 8, 10, 4, 8);
+  switch (select_patch(W, Cout)) {
+    case 1: LAUNCH(8, 32, 34, 2, 16); break;
+    case 2: LAUNCH(8, 28, 36, 8, 4); break;
+    case 3: LAUNCH(16, 16, 18, 2, 16); break;
+    case 4: LAUNCH(16, 14, 18, 16, 2); break;
+    case 5: LAUNCH(32, 8, 10, 4, 8); break;
+    default: break;
+  }
 #undef LAUNCH
   lct_set_error("conv3x3_nhwc: no tiling for H=%d W=%d Cin=%d Cout=%d", H, W, Cin, Cout);
   return LCT_EUNSUPPORTED;

@@ -1,0 +1,611 @@
+// PC-DARTS search-cell primitives (reference basic_vqa/pcdarts/operations.py:4-104, model_search.py:11-91)
+// on NHWC fp32 activations.  Channel counts are tiny (C/4 = 4..16 per mixed op, <= 256 per cell output), so
+// every kernel here is HBM-bound VALU work: one pass, channel-fastest thread mapping (coalesced NHWC rows),
+// no reshaping into MFMA tiles (the 1x1 convolutions go through the strided GEMM with fused input ReLU).
+// Reductions over pixels (BatchNorm statistics, depthwise-weight / architecture-weight gradients) are
+// two-stage and deterministic: per-workgroup partials, then a fixed-order finish.
+#include "common.h"
+
+static inline int gs_blocks(long n, int cap = 8192) {
+  long b = (n + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+#define GRID_STRIDE(o, total) for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < (total); o += (long)gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------------------------------------------------
+// channel slice copy  y[p][0:Cn] = x[p][c0:c0+Cn]   and its backward (dx[p][c] = c in slice ? dy : 0)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void slice_channels_kernel(const float* __restrict__ x, long ldx, int c0, float* __restrict__ y, int Cn, long P) {
+  GRID_STRIDE(o, P * Cn) { long p = o / Cn; int c = o % Cn; y[o] = x[p * ldx + c0 + c]; }
+}
+__global__ void slice_channels_bwd_kernel(const float* __restrict__ dy, int Cn, int c0, float* __restrict__ dx, int C, long P) {
+  GRID_STRIDE(o, P * C) { long p = o / C; int c = o % C; dx[o] = (c >= c0 && c < c0 + Cn) ? dy[p * Cn + c - c0] : 0.f; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// depthwise KxK convolution (groups = C), stride s, padding p, dilation d, optional ReLU on the input
+// (operations.py:41-42,56-61: ReLU -> depthwise conv).  x [B,H,W,C] dense, w [C][K][K], y [B,Ho,Wo,C]
+// ---------------------------------------------------------------------------------------------------------
+__global__ void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int B, int H,
+                                  int W, int C, int K, int s, int p, int d, int Ho, int Wo, int relu_in) {
+  GRID_STRIDE(o, (long)B * Ho * Wo * C) {
+    int c = o % C; long q = o / C; int ox = q % Wo; int oy = (q / Wo) % Ho; int n = q / ((long)Wo * Ho);
+    float a = 0.f;
+    for (int ky = 0; ky < K; ky++) {
+      int iy = oy * s - p + ky * d;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < K; kx++) {
+        int ix = ox * s - p + kx * d;
+        if (ix < 0 || ix >= W) continue;
+        float v = x[(((long)n * H + iy) * W + ix) * C + c];
+        if (relu_in) v = fmaxf(v, 0.f);
+        a = fmaf(v, w[(c * K + ky) * K + kx], a);
+      }
+    }
+    y[o] = a;
+  }
+}
+__global__ void dwconv_bwd_input_kernel(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ x,
+                                        float* __restrict__ dx, int B, int H, int W, int C, int K, int s, int p, int d, int Ho,
+                                        int Wo, int relu_in) {
+  GRID_STRIDE(o, (long)B * H * W * C) {
+    int c = o % C; long q = o / C; int ix = q % W; int iy = (q / W) % H; int n = q / ((long)W * H);
+    float a = 0.f;
+    if (!relu_in || x[o] > 0.f) {
+      for (int ky = 0; ky < K; ky++) {
+        int ty = iy + p - ky * d;
+        if (ty < 0 || ty % s) continue;
+        int oy = ty / s;
+        if (oy >= Ho) continue;
+        for (int kx = 0; kx < K; kx++) {
+          int tx = ix + p - kx * d;
+          if (tx < 0 || tx % s) continue;
+          int ox = tx / s;
+          if (ox >= Wo) continue;
+          a = fmaf(dy[(((long)n * Ho + oy) * Wo + ox) * C + c], w[(c * K + ky) * K + kx], a);
+        }
+      }
+    }
+    dx[o] = a;
+  }
+}
+// partial[blk][tap*C + c] = sum over the block's output pixels of dy[p][c] * relu?(x[p shifted by tap][c])
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                float* __restrict__ part, int B, int H, int W, int C, int K,
+                                                                int s, int p, int d, int Ho, int Wo, int relu_in, long per_blk) {
+  const int KK = K * K, NW = KK * C;
+  const long P = (long)B * Ho * Wo;
+  const long q0 = blockIdx.x * per_blk, q1 = min(P, q0 + per_blk);
+  for (int t = threadIdx.x; t < NW; t += blockDim.x) {
+    const int c = t % C, tap = t / C, ky = tap / K, kx = tap % K;
+    float a = 0.f;
+    for (long q = q0; q < q1; q++) {
+      int ox = q % Wo; int oy = (q / Wo) % Ho; int n = q / ((long)Wo * Ho);
+      int iy = oy * s - p + ky * d, ix = ox * s - p + kx * d;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      float v = x[(((long)n * H + iy) * W + ix) * C + c];
+      if (relu_in) v = fmaxf(v, 0.f);
+      a = fmaf(dy[q * C + c], v, a);
+    }
+    part[(long)blockIdx.x * NW + t] = a;
+  }
+}
+// dw[c][ky][kx] = sum_blk part[blk][tap*C + c]
+__global__ void dwconv_bwd_weight_finish_kernel(const float* __restrict__ part, int nblk, int C, int KK, float* __restrict__ dw) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= C * KK) return;
+  const int c = t % C, tap = t / C;
+  float a = 0.f;
+  for (int b = 0; b < nblk; b++) a += part[(long)b * C * KK + t];
+  dw[c * KK + tap] = a;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 3x3 pooling, padding 1, stride s (operations.py:6-7): kind 0 = max, 1 = avg (count_include_pad=False)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void pool3x3_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int s, int Ho,
+                                   int Wo, int kind) {
+  GRID_STRIDE(o, (long)B * Ho * Wo * C) {
+    int c = o % C; long q = o / C; int ox = q % Wo; int oy = (q / Wo) % Ho; int n = q / ((long)Wo * Ho);
+    float a = kind ? 0.f : -INFINITY;
+    int cnt = 0;
+    for (int ky = 0; ky < 3; ky++) {
+      int iy = oy * s - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; kx++) {
+        int ix = ox * s - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        float v = x[(((long)n * H + iy) * W + ix) * C + c];
+        if (kind) a += v; else a = fmaxf(a, v);
+        cnt++;
+      }
+    }
+    y[o] = kind ? a / (float)cnt : a;
+  }
+}
+// thread per INPUT element: gathers the gradient of every window that selected it (max: first maximal element in
+// scan order, like PyTorch) or covers it (avg)
+__global__ void pool3x3_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int B,
+                                   int H, int W, int C, int s, int Ho, int Wo, int kind) {
+  GRID_STRIDE(o, (long)B * H * W * C) {
+    int c = o % C; long q = o / C; int ix = q % W; int iy = (q / W) % H; int n = q / ((long)W * H);
+    float a = 0.f;
+    for (int oy = (iy + 1 - 2 + s - 1) / s; oy * s - 1 <= iy && oy < Ho; oy++) {
+      if (oy < 0) continue;
+      for (int ox = (ix + 1 - 2 + s - 1) / s; ox * s - 1 <= ix && ox < Wo; ox++) {
+        if (ox < 0) continue;
+        const float g = dy[(((long)n * Ho + oy) * Wo + ox) * C + c];
+        if (kind) {
+          int y0 = max(oy * s - 1, 0), y1 = min(oy * s + 1, H - 1), x0 = max(ox * s - 1, 0), x1 = min(ox * s + 1, W - 1);
+          a += g / (float)((y1 - y0 + 1) * (x1 - x0 + 1));
+        } else {
+          // is (iy,ix) the first maximum of window (oy,ox)?
+          float best = -INFINITY; int by = -1, bx = -1;
+          for (int ky = 0; ky < 3; ky++) {
+            int yy = oy * s - 1 + ky;
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < 3; kx++) {
+              int xx = ox * s - 1 + kx;
+              if (xx < 0 || xx >= W) continue;
+              float v = x[(((long)n * H + yy) * W + xx) * C + c];
+              if (v > best) { best = v; by = yy; bx = xx; }
+            }
+          }
+          if (by == iy && bx == ix) a += g;
+        }
+      }
+    }
+    dx[o] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// spatial subsample with optional ReLU (FactorizedReduce, operations.py:100-104):
+//   y[n,oy,ox,:] = relu?(x[n, 2*oy+off, 2*ox+off, :])   and its backward (scatter, zero elsewhere)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void subsample2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int off,
+                                      int relu) {
+  const int Ho = H / 2, Wo = W / 2;
+  GRID_STRIDE(o, (long)B * Ho * Wo * C) {
+    int c = o % C; long q = o / C; int ox = q % Wo; int oy = (q / Wo) % Ho; int n = q / ((long)Wo * Ho);
+    float v = x[(((long)n * H + 2 * oy + off) * W + 2 * ox + off) * C + c];
+    y[o] = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+// dx = sum over the two taps (off 0 from dy0, off 1 from dy1), masked by relu'(x)
+__global__ void subsample2_bwd_kernel(const float* __restrict__ dy0, const float* __restrict__ dy1, const float* __restrict__ x,
+                                      float* __restrict__ dx, int B, int H, int W, int C, int relu) {
+  const int Ho = H / 2, Wo = W / 2;
+  GRID_STRIDE(o, (long)B * H * W * C) {
+    int c = o % C; long q = o / C; int ix = q % W; int iy = (q / W) % H; int n = q / ((long)W * H);
+    float a = 0.f;
+    if ((iy & 1) == (ix & 1)) {
+      const int off = iy & 1;
+      const float* src = off ? dy1 : dy0;
+      if (src) a = src[(((long)n * Ho + (iy >> 1)) * Wo + (ix >> 1)) * C + c];
+    }
+    if (relu && !(x[o] > 0.f)) a = 0.f;
+    dx[o] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm2d (operations.py:29,43,62,98; model_search.py:37,113): training = batch statistics over B*H*W per
+// channel (biased variance for normalisation, unbiased for the running estimate), eval = running statistics.
+// x may be a channel slice: row stride ldx.  Statistics in fp64 partials (12.8 M pixels per channel at 224^2).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, long ldx, long P, int C, long per_blk,
+                                                               double* __restrict__ part) {
+  __shared__ double s1[256], s2[256];
+  const int nrl = 256 / C;                  // row lanes (C <= 256)
+  const int c = threadIdx.x % C, rl = threadIdx.x / C;
+  const long q0 = blockIdx.x * per_blk, q1 = min(P, q0 + per_blk);
+  double a = 0.0, b = 0.0;
+  if (rl < nrl)
+    for (long q = q0 + rl; q < q1; q += nrl) { double v = x[q * ldx + c]; a += v; b += v * v; }
+  s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double ta = 0.0, tb = 0.0;
+    for (int r = 0; r < nrl; r++) { ta += s1[r * C + threadIdx.x]; tb += s2[r * C + threadIdx.x]; }
+    part[((long)blockIdx.x * 2 + 0) * C + threadIdx.x] = ta;
+    part[((long)blockIdx.x * 2 + 1) * C + threadIdx.x] = tb;
+  }
+}
+// mean/invstd (+ running stats update: momentum m, unbiased variance)
+__global__ void bn_stats_finish_kernel(const double* __restrict__ part, int nblk, int C, long P, float eps, float momentum,
+                                       float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
+                                       float* __restrict__ run_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < nblk; k++) { a += part[((long)k * 2) * C + c]; b += part[((long)k * 2 + 1) * C + c]; }
+  const double m = a / (double)P;
+  double var = b / (double)P - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (run_mean) {
+    const double unb = P > 1 ? var * (double)P / (double)(P - 1) : var;
+    run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * m);
+    run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+  }
+}
+__global__ void bn_eval_stats_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var, float eps, int C,
+                                     float* __restrict__ mean, float* __restrict__ invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) { mean[c] = run_mean[c]; invstd[c] = 1.f / sqrtf(run_var[c] + eps); }
+}
+__global__ void bn_apply_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                float* __restrict__ y, long ldy, long P, int C) {
+  GRID_STRIDE(o, P * C) {
+    long p = o / C; int c = o % C;
+    float v = (x[p * ldx + c] - mean[c]) * invstd[c];
+    if (gamma) v = v * gamma[c] + beta[c];
+    y[p * ldy + c] = v;
+  }
+}
+// partial sums of dy and dy*xhat per channel (xhat recomputed from x)
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x,
+                                                             long ldx, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, long P, int C, long per_blk,
+                                                             double* __restrict__ part) {
+  __shared__ double s1[256], s2[256];
+  const int nrl = 256 / C;
+  const int c = threadIdx.x % C, rl = threadIdx.x / C;
+  const long q0 = blockIdx.x * per_blk, q1 = min(P, q0 + per_blk);
+  double a = 0.0, b = 0.0;
+  if (rl < nrl) {
+    const float m = mean[c], is = invstd[c];
+    for (long q = q0 + rl; q < q1; q += nrl) {
+      double g = dy[q * lddy + c];
+      a += g; b += g * (double)((x[q * ldx + c] - m) * is);
+    }
+  }
+  s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double ta = 0.0, tb = 0.0;
+    for (int r = 0; r < nrl; r++) { ta += s1[r * C + threadIdx.x]; tb += s2[r * C + threadIdx.x]; }
+    part[((long)blockIdx.x * 2 + 0) * C + threadIdx.x] = ta;
+    part[((long)blockIdx.x * 2 + 1) * C + threadIdx.x] = tb;
+  }
+}
+__global__ void bn_bwd_finish_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ sum_dy,
+                                     float* __restrict__ sum_dy_xhat) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < nblk; k++) { a += part[((long)k * 2) * C + c]; b += part[((long)k * 2 + 1) * C + c]; }
+  sum_dy[c] = (float)a; sum_dy_xhat[c] = (float)b;
+}
+// training: dx = g*invstd*(dy - sum_dy/P - xhat*sum_dy_xhat/P);  eval: dx = g*invstd*dy
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ sum_dy,
+                                    const float* __restrict__ sum_dy_xhat, float* __restrict__ dx, long P, int C, int training) {
+  const float invP = 1.f / (float)P;
+  GRID_STRIDE(o, P * C) {
+    long p = o / C; int c = o % C;
+    const float g = gamma ? gamma[c] : 1.f;
+    float v = dy[p * lddy + c];
+    if (training) {
+      const float xh = (x[p * ldx + c] - mean[c]) * invstd[c];
+      v = v - sum_dy[c] * invP - xh * sum_dy_xhat[c] * invP;
+    }
+    dx[o] = v * g * invstd[c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MixedOp tail (model_search.py:41-55) + edge accumulation (model_search.py:87):
+//   out[p][4i+0] (+)= beta * sum_k w_k * branch_k[p][i]
+//   out[p][4i+g] (+)= beta * bypass[p'][g*Cq+i]         g = 1..3   (bypass = x, or MaxPool2d(2,2)(x) in a reduction edge)
+// = beta * channel_shuffle(cat(temp1, xtemp2), 4) accumulated into the node state (row stride ldo: the state may
+// be a channel slice of the cell's concatenated output).
+// ---------------------------------------------------------------------------------------------------------
+struct BranchPtrs { const float* p[8]; };
+__global__ void mixed_combine_fwd_kernel(BranchPtrs br, int nbr, const float* __restrict__ wts /* [nbr] device */,
+                                         const float* __restrict__ beta, const float* __restrict__ x, int B, int Ho, int Wo, int C,
+                                         int reduce, float* __restrict__ out, long ldo, int accumulate) {
+  const int Cq = C / 4;
+  const float bt = beta[0];
+  GRID_STRIDE(o, (long)B * Ho * Wo * C) {
+    int oc = o % C; long q = o / C;
+    int g = oc & 3, i = oc >> 2;
+    float v;
+    if (g == 0) {
+      v = 0.f;
+      for (int k = 0; k < nbr; k++) v = fmaf(wts[k], br.p[k][q * Cq + i], v);
+    } else {
+      const int c = g * Cq + i;
+      if (!reduce) v = x[q * C + c];
+      else {
+        int ox = q % Wo; int oy = (q / Wo) % Ho; int n = q / ((long)Wo * Ho);
+        const int H = Ho * 2, W = Wo * 2;
+        const float* b0 = x + (((long)n * H + 2 * oy) * W + 2 * ox) * C + c;
+        v = fmaxf(fmaxf(b0[0], b0[C]), fmaxf(b0[(long)W * C], b0[(long)W * C + C]));
+      }
+    }
+    v *= bt;
+    float* dst = out + q * ldo + oc;
+    *dst = accumulate ? *dst + v : v;
+  }
+}
+// gradients w.r.t. the branches:  dbr_k[p][i] = beta * w_k * dout[p][4i]
+__global__ void mixed_combine_bwd_branch_kernel(const float* __restrict__ dout, long ldd, const float* __restrict__ wts, int k,
+                                                const float* __restrict__ beta, float* __restrict__ dbr, long P, int Cq) {
+  const float s = beta[0] * wts[k];
+  GRID_STRIDE(o, P * Cq) { long p = o / Cq; int i = o % Cq; dbr[o] = s * dout[p * ldd + 4 * i]; }
+}
+// gradient w.r.t. x through the bypass channels (first Cq channels get 0 here: they flow through the branches)
+__global__ void mixed_combine_bwd_x_kernel(const float* __restrict__ dout, long ldd, const float* __restrict__ beta,
+                                           const float* __restrict__ x, float* __restrict__ dx, int B, int H, int W, int C,
+                                           int reduce) {
+  const int Cq = C / 4;
+  const float bt = beta[0];
+  GRID_STRIDE(o, (long)B * H * W * C) {
+    int c = o % C; long q = o / C;
+    float v = 0.f;
+    if (c >= Cq) {
+      const int g = c / Cq, i = c % Cq;
+      if (!reduce) v = bt * dout[q * ldd + 4 * i + g];
+      else {
+        int ix = q % W; int iy = (q / W) % H; int n = q / ((long)W * H);
+        const int Ho = H / 2, Wo = W / 2, oy = iy >> 1, ox = ix >> 1;
+        const float* b0 = x + (((long)n * H + 2 * oy) * W + 2 * ox) * C + c;
+        const float v00 = b0[0], v01 = b0[C], v10 = b0[(long)W * C], v11 = b0[(long)W * C + C];
+        int best = 0; float bv = v00;
+        if (v01 > bv) { bv = v01; best = 1; }
+        if (v10 > bv) { bv = v10; best = 2; }
+        if (v11 > bv) { bv = v11; best = 3; }
+        if (best == (iy & 1) * 2 + (ix & 1)) v = bt * dout[(((long)n * Ho + oy) * Wo + ox) * ldd + 4 * i + g];
+      }
+    }
+    dx[o] = v;
+  }
+}
+// scalar reductions: part[blk][0..nbr-1] = sum dout[p][4i]*br_k[p][i];  part[blk][8] = sum over bypass channels of
+// dout[p][4i+g]*bypass[p][gCq+i]  (deterministic two-stage; finish on the host side via colsum of [nblk][9])
+__global__ __launch_bounds__(256) void mixed_combine_bwd_scalars_kernel(const float* __restrict__ dout, long ldd, BranchPtrs br,
+                                                                        int nbr, const float* __restrict__ x, int B, int Ho, int Wo,
+                                                                        int C, int reduce, long per_blk, float* __restrict__ part) {
+  __shared__ float red[9][4];
+  const int Cq = C / 4;
+  const long P = (long)B * Ho * Wo;
+  const long q0 = blockIdx.x * per_blk, q1 = min(P, q0 + per_blk);
+  float acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) acc[k] = 0.f;
+  for (long o = q0 * C + threadIdx.x; o < q1 * C; o += blockDim.x) {
+    int oc = o % C; long q = o / C;
+    int g = oc & 3, i = oc >> 2;
+    const float d = dout[q * ldd + oc];
+    if (g == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (k < nbr) acc[k] = fmaf(d, br.p[k][q * Cq + i], acc[k]);
+    } else {
+      const int c = g * Cq + i;
+      float v;
+      if (!reduce) v = x[q * C + c];
+      else {
+        int ox = q % Wo; int oy = (q / Wo) % Ho; int n = q / ((long)Wo * Ho);
+        const int H = Ho * 2, W = Wo * 2;
+        const float* b0 = x + (((long)n * H + 2 * oy) * W + 2 * ox) * C + c;
+        v = fmaxf(fmaxf(b0[0], b0[C]), fmaxf(b0[(long)W * C], b0[(long)W * C + C]));
+      }
+      acc[8] = fmaf(d, v, acc[8]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    float s = wave_sum(acc[k]);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) part[(long)blockIdx.x * 9 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+// dw[k] = beta * S_k ;  dbeta = sum_k w_k S_k + S_8
+__global__ void mixed_combine_bwd_scalars_finish_kernel(const float* __restrict__ part, int nblk, int nbr,
+                                                        const float* __restrict__ wts, const float* __restrict__ beta,
+                                                        float* __restrict__ dw, float* __restrict__ dbeta) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double S[9];
+  for (int k = 0; k < 9; k++) S[k] = 0.0;
+  for (int b = 0; b < nblk; b++)
+    for (int k = 0; k < 9; k++) S[k] += part[(long)b * 9 + k];
+  double db = S[8];
+  for (int k = 0; k < nbr; k++) { dw[k] = (float)(beta[0] * S[k]); db += wts[k] * S[k]; }
+  dbeta[0] = (float)db;
+}
+
+// y[p][c0:c0+Cn] of a strided destination = x dense   (channel concat of the two FactorizedReduce halves)
+__global__ void copy_into_channels_kernel(const float* __restrict__ x, int Cn, float* __restrict__ y, long ldy, int c0, long P) {
+  GRID_STRIDE(o, P * Cn) { long p = o / Cn; int c = o % Cn; y[p * ldy + c0 + c] = x[o]; }
+}
+
+static int red_blocks(long P, long* per_blk) {
+  long nb = (P + 511) / 512;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  *per_blk = (P + nb - 1) / nb;
+  return (int)((P + *per_blk - 1) / *per_blk);
+}
+
+extern "C" {
+
+int lctvqa_slice_channels(const float* x, long ldx, int c0, float* y, int Cn, long P, void* stream) {
+  hipLaunchKernelGGL(slice_channels_kernel, dim3(gs_blocks(P * Cn)), dim3(256), 0, (hipStream_t)stream, x, ldx, c0, y, Cn, P);
+  return lct_check_launch("slice_channels");
+}
+int lctvqa_slice_channels_bwd(const float* dy, int Cn, int c0, float* dx, int C, long P, void* stream) {
+  hipLaunchKernelGGL(slice_channels_bwd_kernel, dim3(gs_blocks(P * C)), dim3(256), 0, (hipStream_t)stream, dy, Cn, c0, dx, C, P);
+  return lct_check_launch("slice_channels_bwd");
+}
+int lctvqa_copy_into_channels(const float* x, int Cn, float* y, long ldy, int c0, long P, void* stream) {
+  hipLaunchKernelGGL(copy_into_channels_kernel, dim3(gs_blocks(P * Cn)), dim3(256), 0, (hipStream_t)stream, x, Cn, y, ldy, c0, P);
+  return lct_check_launch("copy_into_channels");
+}
+
+int lctvqa_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int K, int stride, int pad, int dil,
+                      int relu_in, void* stream) {
+  LCT_REQUIRE(K >= 1 && stride >= 1 && dil >= 1, "dwconv: bad args");
+  int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(gs_blocks((long)B * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, w, y, B, H, W,
+                     C, K, stride, pad, dil, Ho, Wo, relu_in);
+  return lct_check_launch("dwconv_fwd");
+}
+int lctvqa_dwconv_bwd_input(const float* dy, const float* w, const float* x, float* dx, int B, int H, int W, int C, int K,
+                            int stride, int pad, int dil, int relu_in, void* stream) {
+  int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  hipLaunchKernelGGL(dwconv_bwd_input_kernel, dim3(gs_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, w, x, dx,
+                     B, H, W, C, K, stride, pad, dil, Ho, Wo, relu_in);
+  return lct_check_launch("dwconv_bwd_input");
+}
+long lctvqa_dwconv_bwd_weight_scratch_elems(int B, int H, int W, int C, int K, int stride, int pad, int dil) {
+  int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  long per;
+  int nb = red_blocks((long)B * Ho * Wo, &per);
+  return (long)nb * C * K * K;
+}
+int lctvqa_dwconv_bwd_weight(const float* dy, const float* x, float* dw, float* scratch, int B, int H, int W, int C, int K,
+                             int stride, int pad, int dil, int relu_in, void* stream) {
+  int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  long per;
+  int nb = red_blocks((long)B * Ho * Wo, &per);
+  hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, x, scratch, B, H, W, C, K, stride,
+                     pad, dil, Ho, Wo, relu_in, per);
+  int rc = lct_check_launch("dwconv_bwd_weight");
+  if (rc) return rc;
+  hipLaunchKernelGGL(dwconv_bwd_weight_finish_kernel, dim3(cdiv(C * K * K, 256)), dim3(256), 0, (hipStream_t)stream, scratch, nb, C,
+                     K * K, dw);
+  return lct_check_launch("dwconv_bwd_weight_finish");
+}
+
+int lctvqa_pool3x3_fwd(const float* x, float* y, int B, int H, int W, int C, int stride, int kind, void* stream) {
+  int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  hipLaunchKernelGGL(pool3x3_fwd_kernel, dim3(gs_blocks((long)B * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C,
+                     stride, Ho, Wo, kind);
+  return lct_check_launch("pool3x3_fwd");
+}
+int lctvqa_pool3x3_bwd(const float* dy, const float* x, float* dx, int B, int H, int W, int C, int stride, int kind, void* stream) {
+  int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  hipLaunchKernelGGL(pool3x3_bwd_kernel, dim3(gs_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, B, H, W,
+                     C, stride, Ho, Wo, kind);
+  return lct_check_launch("pool3x3_bwd");
+}
+
+int lctvqa_subsample2_fwd(const float* x, float* y, int B, int H, int W, int C, int off, int relu, void* stream) {
+  LCT_REQUIRE(!(H & 1) && !(W & 1) && (off == 0 || off == 1), "subsample2: need even H,W and off in {0,1}");
+  hipLaunchKernelGGL(subsample2_fwd_kernel, dim3(gs_blocks((long)B * (H / 2) * (W / 2) * C)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     B, H, W, C, off, relu);
+  return lct_check_launch("subsample2_fwd");
+}
+int lctvqa_subsample2_bwd(const float* dy0, const float* dy1, const float* x, float* dx, int B, int H, int W, int C, int relu,
+                          void* stream) {
+  hipLaunchKernelGGL(subsample2_bwd_kernel, dim3(gs_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy0, dy1, x, dx,
+                     B, H, W, C, relu);
+  return lct_check_launch("subsample2_bwd");
+}
+
+// scratch: doubles; elems = lctvqa_bn_scratch_doubles(P, C)
+long lctvqa_bn_scratch_doubles(long P, int C) {
+  long per;
+  int nb = red_blocks(P, &per);
+  return (long)nb * 2 * C;
+}
+// training != 0: batch statistics (+ running update when run_mean != NULL); else running statistics.
+// writes mean[C], invstd[C] (saved for backward) and y.
+int lctvqa_batchnorm_fwd(const float* x, long ldx, float* y, long ldy, long P, int C, const float* gamma, const float* beta,
+                         float* run_mean, float* run_var, float* mean, float* invstd, double* scratch, int training, float momentum,
+                         float eps, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  LCT_REQUIRE(C >= 1 && C <= 256 && P >= 1, "batchnorm: need 1 <= C <= 256");
+  if (training) {
+    long per;
+    int nb = red_blocks(P, &per);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(256), 0, st, x, ldx, P, C, per, scratch);
+    int rc = lct_check_launch("bn_stats_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, scratch, nb, C, P, eps, momentum, mean, invstd,
+                       run_mean, run_var);
+  } else {
+    LCT_REQUIRE(run_mean && run_var, "batchnorm eval: running statistics required");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, run_mean, run_var, eps, C, mean, invstd);
+  }
+  int rc = lct_check_launch("bn_stats");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(gs_blocks(P * C)), dim3(256), 0, st, x, ldx, mean, invstd, gamma, beta, y, ldy, P, C);
+  return lct_check_launch("bn_apply");
+}
+// dx dense [P][C]; dgamma/dbeta [C] (may be NULL when gamma is NULL); sums: 2*C floats of scratch
+int lctvqa_batchnorm_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* invstd,
+                         const float* gamma, float* dx, float* dgamma, float* dbeta, float* sums, double* scratch, long P, int C,
+                         int training, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  LCT_REQUIRE(C >= 1 && C <= 256, "batchnorm_bwd: need 1 <= C <= 256");
+  long per;
+  int nb = red_blocks(P, &per);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(256), 0, st, dy, lddy, x, ldx, mean, invstd, P, C, per, scratch);
+  int rc = lct_check_launch("bn_bwd_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, scratch, nb, C, sums, sums + C);
+  rc = lct_check_launch("bn_bwd_finish");
+  if (rc) return rc;
+  if (dgamma) {
+    hipMemcpyAsync(dbeta, sums, C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(dgamma, sums + C, C * sizeof(float), hipMemcpyDeviceToDevice, st);
+  }
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gs_blocks(P * C)), dim3(256), 0, st, dy, lddy, x, ldx, mean, invstd, gamma, sums,
+                     sums + C, dx, P, C, training);
+  return lct_check_launch("bn_bwd_apply");
+}
+
+// branches: array of nbr (<= 8) device pointers (host array); wts: device [nbr]; beta: device scalar
+int lctvqa_mixed_combine_fwd(const float* const* branches, int nbr, const float* wts, const float* beta, const float* x, int B,
+                             int Ho, int Wo, int C, int reduce, float* out, long ldo, int accumulate, void* stream) {
+  LCT_REQUIRE(nbr >= 0 && nbr <= 8 && C % 4 == 0, "mixed_combine: need nbr <= 8 and C %% 4 == 0");
+  BranchPtrs bp;
+  for (int k = 0; k < 8; k++) bp.p[k] = k < nbr ? branches[k] : nullptr;
+  hipLaunchKernelGGL(mixed_combine_fwd_kernel, dim3(gs_blocks((long)B * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, bp, nbr, wts,
+                     beta, x, B, Ho, Wo, C, reduce, out, ldo, accumulate);
+  return lct_check_launch("mixed_combine_fwd");
+}
+int lctvqa_mixed_combine_bwd_branch(const float* dout, long ldd, const float* wts, int k, const float* beta, float* dbr, long P, int Cq,
+                                    void* stream) {
+  hipLaunchKernelGGL(mixed_combine_bwd_branch_kernel, dim3(gs_blocks(P * Cq)), dim3(256), 0, (hipStream_t)stream, dout, ldd, wts, k,
+                     beta, dbr, P, Cq);
+  return lct_check_launch("mixed_combine_bwd_branch");
+}
+int lctvqa_mixed_combine_bwd_x(const float* dout, long ldd, const float* beta, const float* x, float* dx, int B, int H, int W, int C,
+                               int reduce, void* stream) {
+  hipLaunchKernelGGL(mixed_combine_bwd_x_kernel, dim3(gs_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dout, ldd,
+                     beta, x, dx, B, H, W, C, reduce);
+  return lct_check_launch("mixed_combine_bwd_x");
+}
+long lctvqa_mixed_combine_scratch_elems(int B, int Ho, int Wo) {
+  long per;
+  int nb = red_blocks((long)B * Ho * Wo, &per);
+  return (long)nb * 9;
+}
+int lctvqa_mixed_combine_bwd_scalars(const float* dout, long ldd, const float* const* branches, int nbr, const float* wts,
+                                     const float* beta, const float* x, int B, int Ho, int Wo, int C, int reduce, float* dw,
+                                     float* dbeta, float* scratch, void* stream) {
+  BranchPtrs bp;
+  for (int k = 0; k < 8; k++) bp.p[k] = k < nbr ? branches[k] : nullptr;
+  long per;
+  int nb = red_blocks((long)B * Ho * Wo, &per);
+  hipLaunchKernelGGL(mixed_combine_bwd_scalars_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dout, ldd, bp, nbr, x, B, Ho, Wo, C,
+                     reduce, per, scratch);
+  int rc = lct_check_launch("mixed_combine_bwd_scalars");
+  if (rc) return rc;
+  hipLaunchKernelGGL(mixed_combine_bwd_scalars_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, nb, nbr, wts, beta, dw,
+                     dbeta);
+  return lct_check_launch("mixed_combine_bwd_scalars_finish");
+}
+
+}  // extern "C"

@@ -82,7 +82,7 @@ template <int AMODE, int BMODE>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, long a_ms, long a_ks,
                                                           const float* __restrict__ B, long b_ns, long b_ks,
                                                           float* __restrict__ C, long ldc, int M, int N, int K,
-                                                          int kper, GemmEpi epi, int direct) {
+                                                          int kper, GemmEpi epi, int direct, int relu_ab) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][128 * 16];   // [buf][A|B][row][16]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
@@ -105,6 +105,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
   if (nk > 0) {
     load_tile<AMODE>(A, a_ms, a_ks, m0, M, kbeg, kend, tid, ra);
     load_tile<BMODE>(B, b_ns, b_ks, n0, N, kbeg, kend, tid, rb);
+    if (relu_ab & 1) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) ra[i] = fmaxf(ra[i], 0.f);
+    }
+    if (relu_ab & 2) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) rb[i] = fmaxf(rb[i], 0.f);
+    }
     store_tile<AMODE>(lds[0][0], tid, ra);
     store_tile<BMODE>(lds[0][1], tid, rb);
   }
@@ -114,6 +122,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
     if (kt + 1 < nk) {
       load_tile<AMODE>(A, a_ms, a_ks, m0, M, kbeg + (kt + 1) * 16, kend, tid, ra);
       load_tile<BMODE>(B, b_ns, b_ks, n0, N, kbeg + (kt + 1) * 16, kend, tid, rb);
+      if (relu_ab & 1) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) ra[i] = fmaxf(ra[i], 0.f);
+      }
+      if (relu_ab & 2) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) rb[i] = fmaxf(rb[i], 0.f);
+      }
     }
     const float* la = lds[cur][0];
     const float* lb = lds[cur][1];
@@ -203,7 +219,7 @@ static int pick_mode(const float* P, long rs, long ks, int K) {
 }
 
 typedef void (*gemm_kern_t)(const float*, long, long, const float*, long, long, float*, long, int, int, int, int,
-                            GemmEpi, int);
+                            GemmEpi, int, int);
 static gemm_kern_t gemm_table[3][3] = {
     {gemm_f32_kernel<0, 0>, gemm_f32_kernel<0, 1>, gemm_f32_kernel<0, 2>},
     {gemm_f32_kernel<1, 0>, gemm_f32_kernel<1, 1>, gemm_f32_kernel<1, 2>},
@@ -225,10 +241,12 @@ long lctvqa_gemm_workspace_bytes(int M, int N, int K) {
   return splits > 1 ? (long)splits * M * N * (long)sizeof(float) : 0;
 }
 
-int lctvqa_gemm_f32(const float* A, long a_ms, long a_ks, const float* B, long b_ns, long b_ks, float* C, long ldc,
-                    int M, int N, int K, const float* bias, const float* addend, long ld_add, int act,
-                    const uint8_t* mask, long ld_mask, float mask_scale, float* workspace, long workspace_bytes,
-                    void* stream) {
+// relu_ab: bit 0 = apply ReLU to A elements as they are loaded, bit 1 = to B elements (PC-DARTS ReLU->Conv1x1
+// blocks and their weight gradients, operations.py:27-28,43,58-61)
+int lctvqa_gemm_f32_ex(const float* A, long a_ms, long a_ks, const float* B, long b_ns, long b_ks, float* C, long ldc,
+                       int M, int N, int K, const float* bias, const float* addend, long ld_add, int act,
+                       const uint8_t* mask, long ld_mask, float mask_scale, float* workspace, long workspace_bytes,
+                       int relu_ab, void* stream) {
   LCT_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_f32: bad shape %d %d %d", M, N, K);
   LCT_REQUIRE(act >= 0 && act <= 2, "gemm_f32: bad act %d", act);
   hipStream_t st = (hipStream_t)stream;
@@ -242,11 +260,11 @@ int lctvqa_gemm_f32(const float* A, long a_ms, long a_ks, const float* B, long b
   int am = pick_mode(A, a_ms, a_ks, K), bm = pick_mode(B, b_ns, b_ks, K);
   gemm_kern_t k = gemm_table[am][bm];
   if (splits == 1) {
-    hipLaunchKernelGGL(k, dim3(tiles, 1, 1), dim3(256), 0, st, A, a_ms, a_ks, B, b_ns, b_ks, C, ldc, M, N, K, kper, epi, 1);
+    hipLaunchKernelGGL(k, dim3(tiles, 1, 1), dim3(256), 0, st, A, a_ms, a_ks, B, b_ns, b_ks, C, ldc, M, N, K, kper, epi, 1, relu_ab);
     return lct_check_launch("gemm_f32");
   }
   hipLaunchKernelGGL(k, dim3(tiles, 1, splits), dim3(256), 0, st, A, a_ms, a_ks, B, b_ns, b_ks, workspace, (long)N, M, N, K,
-                     kper, epi, 0);
+                     kper, epi, 0, relu_ab);
   int rc = lct_check_launch("gemm_f32(splitk)");
   if (rc) return rc;
   long total = (long)M * N;
@@ -256,16 +274,27 @@ int lctvqa_gemm_f32(const float* A, long a_ms, long a_ks, const float* B, long b
   return lct_check_launch("gemm_splitk_reduce");
 }
 
-long lctvqa_colsum_scratch_elems(int M, int N) {
+static int colsum_splits(int M, int N) {
+  int cap = 2048 / cdiv(N, 64);            // aim at <= ~2048 workgroups
+  if (cap < 64) cap = 64;
   int S = cdiv(M, 64);
-  if (S > 64) S = 64;
-  return (long)S * N;
+  if (S > cap) S = cap;
+  return S;
 }
+
+int lctvqa_gemm_f32(const float* A, long a_ms, long a_ks, const float* B, long b_ns, long b_ks, float* C, long ldc,
+                    int M, int N, int K, const float* bias, const float* addend, long ld_add, int act,
+                    const uint8_t* mask, long ld_mask, float mask_scale, float* workspace, long workspace_bytes,
+                    void* stream) {
+  return lctvqa_gemm_f32_ex(A, a_ms, a_ks, B, b_ns, b_ks, C, ldc, M, N, K, bias, addend, ld_add, act, mask, ld_mask, mask_scale,
+                            workspace, workspace_bytes, 0, stream);
+}
+
+long lctvqa_colsum_scratch_elems(int M, int N) { return (long)colsum_splits(M, N) * N; }
 
 int lctvqa_colsum_f32(const float* X, long ld, int M, int N, float* out, float* scratch, void* stream) {
   LCT_REQUIRE(M > 0 && N > 0 && scratch != nullptr, "colsum: bad args");
-  int S = cdiv(M, 64);
-  if (S > 64) S = 64;
+  int S = colsum_splits(M, N);
   int rows_per = cdiv(M, S);
   S = cdiv(M, rows_per);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), S), dim3(256), 0, (hipStream_t)stream, X, ld, M, N, rows_per, scratch);

@@ -177,7 +177,8 @@ __global__ void scale_rows_kernel(const float* __restrict__ x, const float* __re
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ labels,
                                                        const float* __restrict__ target, long ldt, float* __restrict__ row_loss,
-                                                       float* __restrict__ dlogits, long ldd, float gscale, int N, int kind) {
+                                                       float* __restrict__ dlogits, long ldd, float gscale, int N, int kind,
+                                                       float* __restrict__ dtarget) {
   __shared__ float red[4];
   __shared__ float red2[4];
   const long row = blockIdx.x;
@@ -217,6 +218,22 @@ __global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict_
       dlogits[row * ldd + e] = g * gscale;
     }
   }
+  if (dtarget && kind == 1)                       // d(-sum t*logp)/dt = -(x - lse)
+    for (int e = threadIdx.x; e < N; e += blockDim.x) dtarget[row * (long)N + e] = (lse - x[e]) * gscale;
+}
+
+// backward of y = softmax(x * inv_temp) per row: dx = inv_temp * y * (dy - sum(dy*y))
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                               float* __restrict__ dx, int N, float inv_temp) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  float s = 0.f;
+  for (int e = threadIdx.x; e < N; e += blockDim.x) s += dy[row * N + e] * y[row * N + e];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  s = red[0] + red[1] + red[2] + red[3];
+  for (int e = threadIdx.x; e < N; e += blockDim.x) dx[row * N + e] = inv_temp * y[row * N + e] * (dy[row * N + e] - s);
 }
 
 // deterministic sum of n floats scaled (single workgroup): out[0] = scale * sum(x)
@@ -439,10 +456,11 @@ int lctvqa_scale_rows(const float* x, const float* s, float* y, int M, int N, vo
 }
 // loss_out[0] = loss_scale * sum_rows(row loss);  dlogits = gscale * d(row loss)/d(logits) (may be null)
 int lctvqa_xent(const float* logits, long ld, const long* labels, const float* target, long ldt, float* row_loss,
-                float* loss_out, float loss_scale, float* dlogits, long ldd, float gscale, int M, int N, int kind, void* stream) {
+                float* loss_out, float loss_scale, float* dlogits, long ldd, float gscale, float* dtarget, int M, int N, int kind,
+                void* stream) {
   LCT_REQUIRE(M > 0 && N > 0 && (kind == 0 || kind == 1), "xent: bad args");
   LCT_REQUIRE(kind == 0 ? labels != nullptr : target != nullptr, "xent: missing labels/target");
-  hipLaunchKernelGGL(xent_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, target, ldt, row_loss, dlogits, ldd, gscale, N, kind);
+  hipLaunchKernelGGL(xent_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, target, ldt, row_loss, dlogits, ldd, gscale, N, kind, dtarget);
   int rc = lct_check_launch("xent_rows");
   if (rc) return rc;
   hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_loss, (long)M, loss_scale, loss_out);
@@ -451,6 +469,10 @@ int lctvqa_xent(const float* logits, long ld, const long* labels, const float* t
 int lctvqa_softmax_rows(const float* x, float* y, int M, int N, float inv_temp, void* stream) {
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, y, N, inv_temp);
   return lct_check_launch("softmax_rows");
+}
+int lctvqa_softmax_rows_bwd(const float* dy, const float* y, float* dx, int M, int N, float inv_temp, void* stream) {
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, dy, y, dx, N, inv_temp);
+  return lct_check_launch("softmax_rows_bwd");
 }
 int lctvqa_argmax_rows(const float* x, long ld, int M, int N, long* out, void* stream) {
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ld, N, out);

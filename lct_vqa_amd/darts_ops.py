@@ -1,0 +1,337 @@
+"""autograd.Function wrappers of the PC-DARTS primitives (csrc/darts.hip) on NHWC fp32 activations
+[B,H,W,C], plus ``run_seq`` which executes a reference-shaped ``nn.Sequential`` of standard torch
+modules (ReLU / Conv2d / BatchNorm2d / AvgPool2d / MaxPool2d used purely as parameter+buffer holders,
+so state_dict keys equal the reference's) through those Functions."""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from ._lib import lib
+from .ops import _chk, _workspace, colsum  # noqa: F401
+
+
+def _gemm_ex(A, a_ms, a_ks, Bm, b_ns, b_ks, M, N, K, relu_ab):
+    C = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    need = lib.query('gemm_workspace_bytes', M, N, K)
+    ws = _workspace(need, A.device) if need else None
+    lib('gemm_f32_ex', A, a_ms, a_ks, Bm, b_ns, b_ks, C, N, M, N, K, None, None, 0, 0, None, 0, 1.0, ws, need, relu_ab)
+    return C
+
+
+class SliceChannelsFn(torch.autograd.Function):
+    """x[..., c0:c0+cn] as a dense tensor (model_search.py:44-45)."""
+
+    @staticmethod
+    def forward(ctx, x, c0, cn):
+        x = _chk(x)
+        B, H, W, C = x.shape
+        y = torch.empty((B, H, W, cn), dtype=torch.float32, device=x.device)
+        lib('slice_channels', x, C, c0, y, cn, B * H * W)
+        ctx.c0, ctx.C = c0, C
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _chk(dy)
+        B, H, W, cn = dy.shape
+        dx = torch.empty((B, H, W, ctx.C), dtype=torch.float32, device=dy.device)
+        lib('slice_channels_bwd', dy, cn, ctx.c0, dx, ctx.C, B * H * W)
+        return dx, None, None
+
+
+class DwConvFn(torch.autograd.Function):
+    """(ReLU ->) depthwise conv (operations.py:41,56,60)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad, dil, relu_in):
+        x, w = _chk(x), _chk(w)
+        B, H, W, C = x.shape
+        K = w.shape[-1]
+        Ho = (H + 2 * pad - dil * (K - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (K - 1) - 1) // stride + 1
+        y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+        lib('dwconv_fwd', x, w, y, B, H, W, C, K, stride, pad, dil, int(relu_in))
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, dil, int(relu_in))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, dil, relu_in = ctx.cfg
+        dy = _chk(dy)
+        B, H, W, C = x.shape
+        K = w.shape[-1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            lib('dwconv_bwd_input', dy, w, x, dx, B, H, W, C, K, stride, pad, dil, relu_in)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            n = lib.query('dwconv_bwd_weight_scratch_elems', B, H, W, C, K, stride, pad, dil)
+            scratch = torch.empty(n, dtype=torch.float32, device=x.device)
+            lib('dwconv_bwd_weight', dy, x, dw, scratch, B, H, W, C, K, stride, pad, dil, relu_in)
+        return dx, dw, None, None, None, None
+
+
+class PwConvFn(torch.autograd.Function):
+    """(ReLU ->) 1x1 conv, no bias (operations.py:28,42,57,61) as a strided GEMM over pixels."""
+
+    @staticmethod
+    def forward(ctx, x, w, relu_in):
+        x, w = _chk(x), _chk(w)
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        P = B * H * W
+        y = _gemm_ex(x, Cin, 1, w, Cin, 1, P, Cout, Cin, 1 if relu_in else 0)
+        ctx.save_for_backward(x, w)
+        ctx.relu_in = bool(relu_in)
+        return y.reshape(B, H, W, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _chk(dy)
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        P = B * H * W
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = _gemm_ex(dy, Cout, 1, w, 1, Cin, P, Cin, Cout, 0)            # dY . W
+            if ctx.relu_in:
+                out = torch.empty_like(dx)
+                lib('act_bwd', dx, x, None, 1.0, out, dx.numel(), 1)          # * (x > 0)
+                dx = out
+            dx = dx.reshape(B, H, W, Cin)
+        if ctx.needs_input_grad[1]:
+            dw = _gemm_ex(dy, 1, Cout, x, 1, Cin, Cout, Cin, P, 2 if ctx.relu_in else 0).reshape(w.shape)
+        return dx, dw, None
+
+
+class BatchNormFn(torch.autograd.Function):
+    """nn.BatchNorm2d: batch statistics + running update in train mode, running statistics in eval."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, training, momentum, eps):
+        x = _chk(x)
+        B, H, W, C = x.shape
+        P = B * H * W
+        dev = x.device
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        scratch = torch.empty(lib.query('bn_scratch_doubles', P, C), dtype=torch.float64, device=dev)
+        lib('batchnorm_fwd', x, C, y, C, P, C, gamma, beta, run_mean, run_var, mean, invstd, scratch, int(training),
+            float(momentum), float(eps))
+        ctx.save_for_backward(x, mean, invstd, gamma)
+        ctx.training = int(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, invstd, gamma = ctx.saved_tensors
+        dy = _chk(dy)
+        B, H, W, C = x.shape
+        P = B * H * W
+        dev = x.device
+        dx = torch.empty_like(x)
+        sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        scratch = torch.empty(lib.query('bn_scratch_doubles', P, C), dtype=torch.float64, device=dev)
+        dg = db = None
+        if gamma is not None:
+            dg = torch.empty(C, dtype=torch.float32, device=dev)
+            db = torch.empty(C, dtype=torch.float32, device=dev)
+        lib('batchnorm_bwd', dy, C, x, C, mean, invstd, gamma, dx, dg, db, sums, scratch, P, C, ctx.training)
+        return dx, dg, db, None, None, None, None, None
+
+
+class Pool3x3Fn(torch.autograd.Function):
+    """MaxPool2d(3,s,1) (kind 0) / AvgPool2d(3,s,1,count_include_pad=False) (kind 1), operations.py:6-7."""
+
+    @staticmethod
+    def forward(ctx, x, stride, kind):
+        x = _chk(x)
+        B, H, W, C = x.shape
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+        lib('pool3x3_fwd', x, y, B, H, W, C, stride, kind)
+        ctx.save_for_backward(x)
+        ctx.cfg = (stride, kind)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        stride, kind = ctx.cfg
+        B, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        lib('pool3x3_bwd', _chk(dy), x, dx, B, H, W, C, stride, kind)
+        return dx, None, None
+
+
+class Subsample2Fn(torch.autograd.Function):
+    """relu(x)[:, 0::2, 0::2] and relu(x)[:, 1::2, 1::2] (FactorizedReduce, operations.py:100-102)."""
+
+    @staticmethod
+    def forward(ctx, x, relu):
+        x = _chk(x)
+        B, H, W, C = x.shape
+        y0 = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+        y1 = torch.empty_like(y0)
+        lib('subsample2_fwd', x, y0, B, H, W, C, 0, int(relu))
+        lib('subsample2_fwd', x, y1, B, H, W, C, 1, int(relu))
+        ctx.save_for_backward(x)
+        ctx.relu = int(relu)
+        ctx.set_materialize_grads(False)
+        return y0, y1
+
+    @staticmethod
+    def backward(ctx, d0, d1):
+        (x,) = ctx.saved_tensors
+        B, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        lib('subsample2_bwd', _chk(d0) if d0 is not None else None, _chk(d1) if d1 is not None else None, x, dx,
+            B, H, W, C, ctx.relu)
+        return dx, None
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * max(len(tensors), 1))(*[t.data_ptr() for t in tensors])
+
+
+class MixedCombineFn(torch.autograd.Function):
+    """state (+)= beta * channel_shuffle(cat(sum_k w_k branch_k, bypass(x)), 4)  (model_search.py:41-55,87).
+    ``prev`` (or None) is updated IN PLACE and returned; ``reduce`` = stride-2 edge (bypass = MaxPool2d(2,2))."""
+
+    @staticmethod
+    def forward(ctx, prev, x, wsel, beta, reduce, *branches):
+        x, wsel, beta = _chk(x), _chk(wsel), _chk(beta)
+        branches = [_chk(b) for b in branches]
+        B, H, W, C = x.shape
+        Ho, Wo = (H // 2, W // 2) if reduce else (H, W)
+        if prev is None:
+            out = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+            acc = 0
+        else:
+            out = prev
+            acc = 1
+            ctx.mark_dirty(prev)
+        lib('mixed_combine_fwd', _ptr_array(branches), len(branches), wsel, beta, x, B, Ho, Wo, C, int(reduce), out,
+            out.stride(2), acc)
+        ctx.save_for_backward(x, wsel, beta, *branches)
+        ctx.reduce, ctx.has_prev = int(reduce), prev is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wsel, beta = ctx.saved_tensors[:3]
+        branches = list(ctx.saved_tensors[3:])
+        dout = _chk(dout)
+        B, H, W, C = x.shape
+        Ho, Wo = (H // 2, W // 2) if ctx.reduce else (H, W)
+        P, Cq, dev = B * Ho * Wo, C // 4, x.device
+        ldd = dout.stride(2)
+        dx = torch.empty_like(x)
+        lib('mixed_combine_bwd_x', dout, ldd, beta, x, dx, B, H, W, C, ctx.reduce)
+        dbr = []
+        for k, b in enumerate(branches):
+            g = torch.empty_like(b)
+            lib('mixed_combine_bwd_branch', dout, ldd, wsel, k, beta, g, P, Cq)
+            dbr.append(g)
+        dw = torch.zeros(max(len(branches), 1), dtype=torch.float32, device=dev)
+        dbeta = torch.empty(1, dtype=torch.float32, device=dev)
+        scratch = torch.empty(lib.query('mixed_combine_scratch_elems', B, Ho, Wo), dtype=torch.float32, device=dev)
+        lib('mixed_combine_bwd_scalars', dout, ldd, _ptr_array(branches), len(branches), wsel, beta, x, B, Ho, Wo, C,
+            ctx.reduce, dw, dbeta, scratch)
+        dw = dw[:len(branches)]
+        return (dout if ctx.has_prev else None, dx, dw, dbeta, None) + tuple(dbr)
+
+
+class StemConvFn(torch.autograd.Function):
+    """Conv2d(3, C, 3, padding=1, bias=False) on the NCHW image -> NHWC (model_search.py:111-113)."""
+
+    @staticmethod
+    def forward(ctx, image, w):
+        image, w = _chk(image), _chk(w)
+        B, _, H, W = image.shape
+        Cout = w.shape[0]
+        y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=image.device)
+        lib('conv3x3_first_nchw', image, w, None, y, B, H, W, Cout, 0)
+        ctx.save_for_backward(image, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        image, w = ctx.saved_tensors
+        dy = _chk(dy)
+        B, _, H, W = image.shape
+        Cout = w.shape[0]
+        dw = torch.empty_like(w)
+        scratch = torch.empty(lib.query('conv3x3_first_wgrad_scratch_elems', B, H, W, Cout), dtype=torch.float32, device=dy.device)
+        lib('conv3x3_first_wgrad', image, dy, dw, None, scratch, B, H, W, Cout)
+        return None, dw
+
+
+class AvgPool7FlattenFn(torch.autograd.Function):
+    """AdaptiveAvgPool2d(7) + flatten(start_dim=1) in NCHW feature order (model_search.py:130,178-180)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x)
+        B, H, W, C = x.shape
+        y = torch.empty((B, C * 49), dtype=torch.float32, device=x.device)
+        lib('adaptive_avgpool7_flatten', x, y, B, H, W, C)
+        ctx.shape = (B, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C = ctx.shape
+        dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
+        lib('adaptive_avgpool7_flatten_bwd', _chk(dy), dx, B, H, W, C)
+        return dx
+
+
+# ------------------------------------------------------------------------------------------ interpreter
+def batchnorm(bn, x):
+    """Run an nn.BatchNorm2d holder on an NHWC tensor through the HIP kernels (buffers updated in place)."""
+    training = bn.training or not bn.track_running_stats
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return BatchNormFn.apply(x, bn.weight if bn.affine else None, bn.bias if bn.affine else None, rm, rv, training,
+                             bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+
+
+def run_seq(seq, x):
+    """Execute a reference-shaped Sequential (ReLU / Conv2d(depthwise or 1x1, bias=False) / BatchNorm2d /
+    AvgPool2d(3) / MaxPool2d(3)) on an NHWC tensor.  A ReLU is fused into the convolution that follows it."""
+    relu = False
+    for m in seq:
+        if isinstance(m, nn.ReLU):
+            relu = True
+        elif isinstance(m, nn.Conv2d):
+            if m.bias is not None:
+                raise NotImplementedError('conv bias in a DARTS op')
+            k = m.kernel_size[0]
+            if k == 1 and m.groups == 1 and m.stride[0] == 1:
+                x = PwConvFn.apply(x, m.weight, relu)
+            elif m.groups == m.in_channels == m.out_channels:
+                x = DwConvFn.apply(x, m.weight, m.stride[0], m.padding[0], m.dilation[0], relu)
+            else:
+                raise NotImplementedError(f'conv {m} in a DARTS op')
+            relu = False
+        elif isinstance(m, nn.BatchNorm2d):
+            x = batchnorm(m, x)
+        elif isinstance(m, nn.AvgPool2d):
+            x = Pool3x3Fn.apply(x, m.stride if isinstance(m.stride, int) else m.stride[0], 1)
+        elif isinstance(m, nn.MaxPool2d):
+            x = Pool3x3Fn.apply(x, m.stride if isinstance(m.stride, int) else m.stride[0], 0)
+        elif isinstance(m, nn.Sequential):
+            x = run_seq(m, x)
+        else:
+            raise NotImplementedError(f'module {type(m).__name__} in a DARTS op')
+    if relu:
+        raise NotImplementedError('trailing ReLU')
+    return x

@@ -1,0 +1,214 @@
+"""darts_vqa models (reference darts_vqa/vqa_model.py:8-364): VGG or PC-DARTS image encoder chosen by string,
+LSTM encoder-decoder whose fc1 is the TOKEN head and fc2 the FEATURE head (swapped w.r.t. basic_vqa/models_lct),
+fusion head, ``_loss(..., qst_only)``.  ``VqaModelUnified``/``QstAnsEncoder`` (QA-string variant) are not named by
+the north star and are not built."""
+import torch
+import torch.nn as nn
+
+from .. import ops, vgg
+from ..basic_vqa.models import VqaModel as _WModel, _single_layer
+from ..basic_vqa.pcdarts.model_search import Network
+from . import config as _config
+
+
+class VggEncoder(nn.Module):
+    """reference vqa_model.py:8-46"""
+
+    def __init__(self, embed_size):
+        super(VggEncoder, self).__init__()
+        model = vgg.vgg19(pretrained=True)
+        in_features = model.classifier[-1].in_features
+        model.classifier = nn.Sequential(*list(model.classifier.children())[:-1])
+        self.model = model
+        self.fc = nn.Linear(in_features, embed_size)
+
+    def forward(self, image):
+        with torch.no_grad():
+            img_feature = self.model(image)
+        img_feature = ops.linear(img_feature, self.fc.weight, self.fc.bias)
+        return ops.L2NormFn.apply(img_feature)
+
+
+class DartsEncoder(nn.Module):
+    """reference vqa_model.py:48-66"""
+
+    def __init__(self, embed_size, init_ch=16, layers=4):
+        super(DartsEncoder, self).__init__()
+        self.darts = Network(init_ch, embed_size, layers)
+        in_features = self.darts.output_ch * (self.darts.output_size ** 2)
+        self.fc = nn.Linear(in_features, embed_size)
+
+    def forward(self, image):
+        img_feature = self.darts(image)
+        img_feature = ops.linear(img_feature, self.fc.weight, self.fc.bias)
+        return ops.L2NormFn.apply(img_feature)
+
+
+def get_img_encoder(img_encoder_type, embed_size):
+    if img_encoder_type == 'vgg':
+        return VggEncoder(embed_size)
+    elif img_encoder_type == 'darts':
+        return DartsEncoder(embed_size)
+    else:
+        raise Exception(f'Unrecognized encoder type: {img_encoder_type}')
+
+
+class QstEncoderBase(nn.Module):
+    """reference vqa_model.py:77-151 (fc1 = token head)."""
+
+    def __init__(self, vocab_size, word_embed_size, embed_size, num_layers, hidden_size, deterministic=True,
+                 temperature=0.1, max_length=30):
+        super(QstEncoderBase, self).__init__()
+        self.hidden_size = hidden_size
+        self.deterministic = deterministic
+        self.temperature = temperature
+        self.max_length = max_length
+        self.word2vec = nn.Embedding(vocab_size, word_embed_size)
+        self.tanh = nn.Tanh()
+        self.lstm = nn.LSTM(word_embed_size, hidden_size, num_layers)
+        self.fc1 = nn.Linear(hidden_size, vocab_size)
+        self.softmax = torch.nn.Softmax(dim=2)
+        torch.nn.init.xavier_uniform_(self.fc1.weight.data)
+        torch.nn.init.zeros_(self.fc1.bias)
+
+    def forward(self, qst, image_embedding):
+        raise NotImplementedError()
+
+    def generate(self, image_embedding):
+        B = len(image_embedding)
+        dev = image_embedding.device
+        h = image_embedding.reshape(B, self.hidden_size)
+        c = h
+        start_word = torch.full((B, 1), 2, dtype=torch.long, device=dev)
+        current_word = ops.embed(start_word, self.word2vec.weight, True)
+        qst_out = torch.zeros((B, self.max_length), dtype=torch.long, device=dev)
+        params = _single_layer(self.lstm)
+        for t in range(self.max_length):
+            out, h, c = ops.lstm(current_word, *params, h, c)
+            prob = ops.linear(ops.TanhFn.apply(out), self.fc1.weight, self.fc1.bias)
+            pred = self.sample(prob.transpose(0, 1))
+            current_word = ops.embed(pred, self.word2vec.weight, False)
+            qst_out[:, t] = pred[:, 0]
+        return qst_out
+
+    def sample(self, prob):
+        B = prob.shape[0]
+        if self.deterministic:
+            return ops.argmax_rows(prob.reshape(B, -1)).reshape(B, 1)
+        # the reference's stochastic branch references an un-imported WeightedRandomSampler (latent NameError,
+        # vqa_model.py:146); sampling from the same distribution instead
+        soft = ops.softmax_rows(prob.reshape(B, -1), 1.0 / self.temperature)
+        return torch.multinomial(soft, 1)
+
+
+class QstEncoder(QstEncoderBase):
+    """reference vqa_model.py:153-198 (fc2 = feature head)."""
+
+    def __init__(self, qst_vocab_size, word_embed_size, embed_size, num_layers, hidden_size, deterministic=True,
+                 temperature=0.1, max_length=30):
+        super(QstEncoder, self).__init__(qst_vocab_size, word_embed_size, embed_size, num_layers, hidden_size,
+                                         deterministic, temperature, max_length)
+        self.fc2 = nn.Linear(2 * num_layers * hidden_size, embed_size)
+        torch.nn.init.xavier_uniform_(self.fc2.weight.data)
+        torch.nn.init.zeros_(self.fc2.bias)
+
+    def forward(self, question, image_embedding):
+        B = image_embedding.shape[0]
+        h0 = image_embedding.reshape(B, self.hidden_size)
+        qst_vec = ops.embed(question, self.word2vec.weight, True)
+        out, hidden, cell = ops.lstm(qst_vec, *_single_layer(self.lstm), h0, h0)
+        qst_feature = ops.linear(ops.CatTanhFn.apply(hidden, cell), self.fc2.weight, self.fc2.bias)
+        qst_out = ops.linear(ops.TanhFn.apply(out), self.fc1.weight, self.fc1.bias)
+        return qst_feature, qst_out.transpose(0, 1)
+
+
+class VqaModelBase(nn.Module):
+    """reference vqa_model.py:235-281"""
+
+    def __init__(self, embed_size, qst_vocab_size, ans_vocab_size, word_embed_size, num_layers, hidden_size,
+                 img_encoder_type='vgg'):
+        super(VqaModelBase, self).__init__()
+        self.embed_size = embed_size
+        self.qst_vocab_size = qst_vocab_size
+        self.ans_vocab_size = ans_vocab_size
+        self.word_embed_size = word_embed_size
+        self.num_layers = num_layers
+        self.hidden_size = hidden_size
+        self.criterion = nn.CrossEntropyLoss()
+        self.img_encoder_type = img_encoder_type
+        self.img_encoder = get_img_encoder(img_encoder_type, embed_size)
+
+    def forward(self, img, qst):
+        raise NotImplementedError()
+
+    def generate(self, img):
+        raise NotImplementedError()
+
+    def genotype(self):
+        return self.img_encoder.darts.genotype()
+
+    def arch_parameters(self):
+        return self.img_encoder.darts.arch_parameters()
+
+    def save_arch_parameters(self, save_path):
+        if self.img_encoder_type != 'darts':
+            return
+        self.img_encoder.darts.save_arch_parameters(save_path)
+
+    def load_arch_parameters(self, load_path):
+        if self.img_encoder_type != 'darts':
+            return
+        self.img_encoder.darts.load_arch_parameters(load_path)
+
+
+class VqaModel(VqaModelBase):
+    """reference vqa_model.py:283-364"""
+
+    def __init__(self, embed_size, qst_vocab_size, ans_vocab_size, word_embed_size, num_layers, hidden_size,
+                 img_encoder_type='vgg'):
+        super(VqaModel, self).__init__(embed_size, qst_vocab_size, ans_vocab_size, word_embed_size, num_layers,
+                                       hidden_size, img_encoder_type)
+        self.qst_encoder = QstEncoder(qst_vocab_size, word_embed_size, embed_size, num_layers, hidden_size)
+        self.tanh = nn.Tanh()
+        self.dropout = nn.Dropout(0.5)
+        self.fc1 = nn.Linear(embed_size, ans_vocab_size)
+        self.fc2 = nn.Linear(ans_vocab_size, ans_vocab_size)
+
+    _head = _WModel._head
+
+    def forward(self, img, qst):
+        img_feature = self.img_encoder(img)
+        qst_feature, qst_out = self.qst_encoder(qst, img_feature)
+        return self._head(img_feature, qst_feature), qst_out
+
+    def generate(self, img):
+        img_feature = self.img_encoder(img)
+        qst = self.qst_encoder.generate(img_feature)
+        qst_feature, _ = self.qst_encoder(qst, img_feature)
+        return qst, self._head(img_feature, qst_feature)
+
+    def trainable_parameters(self):
+        frozen = self.img_encoder_type == 'vgg'
+        return [p for n, p in self.named_parameters() if not (frozen and n.startswith('img_encoder.model.'))]
+
+    def new(self):
+        new_model = VqaModel(self.embed_size, self.qst_vocab_size, self.ans_vocab_size, self.word_embed_size,
+                             self.num_layers, self.hidden_size, self.img_encoder_type)
+        if self.img_encoder_type == 'darts':
+            new_model.img_encoder.darts = self.img_encoder.darts.new()
+        new_model.to(_config.active().DEVICE)
+        return new_model
+
+    def _loss(self, images, questions, labels, qst_only=False):
+        ans_out, qst_out = self(images, questions)
+        ans_loss = ops.cross_entropy(ans_out, labels)
+        qst = questions[:, 1:].flatten()
+        qst_out = qst_out[:, :-1].flatten(end_dim=1)
+        qst_loss = ops.cross_entropy(qst_out, qst)
+        return qst_loss if qst_only else ans_loss + qst_loss
+
+
+class VqaModelUnified(VqaModelBase):
+    def __init__(self, *a, **k):
+        raise NotImplementedError('lct_vqa_amd: VqaModelUnified (QA-string variant, reference vqa_model.py:366-422) '
+                                  'is outside the hot path named by BASELINE.json and is not built')

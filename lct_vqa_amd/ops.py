@@ -82,6 +82,7 @@ class _MaskState(threading.local):
         self.injected = None
         self.seed = None
         self.offset = 0
+        self.disabled = False
 
 
 _mask_state = _MaskState()
@@ -97,6 +98,22 @@ def inject_masks(masks):
         yield
     finally:
         _mask_state.injected = prev
+
+
+@contextlib.contextmanager
+def dropout_disabled():
+    """Make every nn.Dropout on the path the identity (parity runs of the architect steps, whose freshly built
+    ``new()`` models have their Dropout holders in training mode)."""
+    prev = _mask_state.disabled
+    _mask_state.disabled = True
+    try:
+        yield
+    finally:
+        _mask_state.disabled = prev
+
+
+def dropout_active(holder_training, p):
+    return bool(holder_training) and p > 0 and not _mask_state.disabled
 
 
 def manual_seed(seed):
@@ -341,7 +358,8 @@ class MulTanhDropFn(torch.autograd.Function):
 
 class XentFn(torch.autograd.Function):
     """nn.CrossEntropyLoss() (kind 0, int64 labels) / softXEnt (kind 1, soft targets):
-    reference basic_vqa/models.py:7-10,89.  Both are sum_rows / M."""
+    reference basic_vqa/models.py:7-10,89.  Both are sum_rows / M.  softXEnt is differentiable in the
+    target too (the LCT architect back-propagates through the pseudo answers, architect_lct.py:67-77)."""
 
     @staticmethod
     def forward(ctx, logits, target, kind):
@@ -352,25 +370,53 @@ class XentFn(torch.autograd.Function):
         row = torch.empty(M, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         dl = torch.empty_like(lg)
+        dt = None
         if kind == 0:
             labels = target.reshape(-1).contiguous()
             if labels.dtype != torch.int64:
                 raise RuntimeError('labels must be int64')
-            lib('xent', lg, lg.stride(0), labels, None, 0, row, loss, 1.0 / M, dl, dl.stride(0), 1.0 / M, M, N, 0)
+            lib('xent', lg, lg.stride(0), labels, None, 0, row, loss, 1.0 / M, dl, dl.stride(0), 1.0 / M, None, M, N, 0)
         else:
             tg = _chk(target).reshape(-1, N)
-            lib('xent', lg, lg.stride(0), None, tg, tg.stride(0), row, loss, 1.0 / M, dl, dl.stride(0), 1.0 / M, M, N, 1)
-        ctx.save_for_backward(dl)
-        ctx.shp = shp
+            if target.requires_grad:
+                dt = torch.empty_like(tg)
+            lib('xent', lg, lg.stride(0), None, tg, tg.stride(0), row, loss, 1.0 / M, dl, dl.stride(0), 1.0 / M, dt, M, N, 1)
+        ctx.save_for_backward(dl, dt)
+        ctx.shp, ctx.tshape = shp, target.shape
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        (dl,) = ctx.saved_tensors
+        dl, dt = ctx.saved_tensors
         g = _chk(g.reshape(1))
         out = torch.empty_like(dl)
         lib('scale_by_device_scalar', g, dl, out, dl.numel())
-        return out.reshape(ctx.shp), None, None
+        gt = None
+        if dt is not None:
+            gt = torch.empty_like(dt)
+            lib('scale_by_device_scalar', g, dt, gt, dt.numel())
+            gt = gt.reshape(ctx.tshape)
+        return out.reshape(ctx.shp), gt, None
+
+
+class SoftmaxRowsFn(torch.autograd.Function):
+    """F.softmax(x * inv_temp, dim=1), differentiable (pseudo answers: architect_lct.py:54-55,70)."""
+
+    @staticmethod
+    def forward(ctx, x, inv_temp):
+        x = _chk(x)
+        y = torch.empty_like(x)
+        lib('softmax_rows', x, y, x.shape[0], x.shape[1], float(inv_temp))
+        ctx.save_for_backward(y)
+        ctx.inv_temp = float(inv_temp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        lib('softmax_rows_bwd', _chk(dy), y, dx, y.shape[0], y.shape[1], ctx.inv_temp)
+        return dx, None
 
 
 def cross_entropy(logits, labels):
@@ -378,7 +424,7 @@ def cross_entropy(logits, labels):
 
 
 def soft_xent(pred, target):
-    return XentFn.apply(pred, target.detach(), 1)
+    return XentFn.apply(pred, target, 1)
 
 
 def softmax_rows(x, inv_temp=1.0):
@@ -415,57 +461,159 @@ def conv_timer_stop():
     return [dict(name=n, ms=a.elapsed_time(b), flops=f) for (n, a, b, f) in rec]
 
 
-# ----------------------------------------------------------------------------- VGG19 trunk (forward)
-def vgg_trunk_forward(image, convs, fcs, train):
-    """torchvision vgg19 (reference basic_vqa/models.py:23-28,36), forward only.
-    image: NCHW fp32 [B,3,H,W].  convs: list of (weight OIHW, bias) in layer order with the
-    string 'M' marking MaxPool2d(2,2).  fcs: list of (weight, bias, act, drop_p) for the classifier.
-    Returns [B, fcs[-1] out features]."""
+# ----------------------------------------------------------------------------- VGG19 trunk
+def _conv_block(cur, w, b, B, H, W, pool, name_timer=True):
+    """conv3x3 + bias + ReLU (+ fused 2x2 max pool) on an NHWC activation -> NHWC output."""
+    dev = cur.device
+    Cout, Cin = w.shape[0], w.shape[1]
+    mfma = lib.query('conv3x3_uses_mfma', B, H, W, Cin, Cout, pool)
+    wp = tmp = None
+    if mfma:
+        wp = torch.empty(Cout * Cin * 9, dtype=torch.float32, device=dev)
+        lib('conv3x3_pack_weights', w, wp, Cout, Cin)
+    elif pool:
+        tmp = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
+    if _conv_timer is not None and mfma:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib('conv3x3_nhwc', cur, w, wp, b, out, tmp, B, H, W, Cin, Cout, 1, pool)
+        e1.record()
+        _conv_timer.append((f'conv{H}x{W}_{Cin}->{Cout}{"+pool" if pool else ""}', e0, e1,
+                            2.0 * B * H * W * Cout * Cin * 9))
+    else:
+        lib('conv3x3_nhwc', cur, w, wp, b, out, tmp, B, H, W, Cin, Cout, 1, pool)
+    return out
+
+
+def _pool(cur, B, H, W):
+    out = torch.empty((B, H // 2, W // 2, cur.shape[3]), dtype=torch.float32, device=cur.device)
+    lib('maxpool2x2_nhwc', cur, out, B, H, W, cur.shape[3])
+    return out
+
+
+def vgg_features_forward(image, convs, fuse_pool=True, keep=None):
+    """vgg19.features + avgpool + flatten.  image NCHW [B,3,H,W]; convs: list of (weight OIHW, bias) with 'M'
+    marking MaxPool2d(2,2).  When ``keep`` (a list) is given it receives, per conv layer,
+    (activation after ReLU [un-pooled], H, W, pooled_after) for the backward pass; pools are then NOT
+    fused into the conv epilogue because the pre-pool activation is needed."""
     image = _chk(image, 'image')
     B, C, H, W = image.shape
     if C != 3:
         raise RuntimeError('VGG19 expects 3 input channels')
     dev = image.device
-    w0, b0 = convs[0]
-    cur = torch.empty((B, H, W, w0.shape[0]), dtype=torch.float32, device=dev)
-    lib('conv3x3_first_nchw', image, _chk(w0), b0, cur, B, H, W, w0.shape[0], 1)
-    i = 1
-    while i < len(convs):
+    fuse = fuse_pool and keep is None
+    cur, i, n = None, 0, len(convs)
+    while i < n:
         item = convs[i]
-        if isinstance(item, str):                       # a pool that could not be fused
-            out = torch.empty((B, H // 2, W // 2, cur.shape[3]), dtype=torch.float32, device=dev)
-            lib('maxpool2x2_nhwc', cur, out, B, H, W, cur.shape[3])
-            cur, H, W = out, H // 2, W // 2
+        if isinstance(item, str):                            # un-fused MaxPool2d(2,2)
+            cur = _pool(cur, B, H, W)
+            H, W = H // 2, W // 2
             i += 1
             continue
         w, b = item
         w = _chk(w)
-        Cout, Cin = w.shape[0], w.shape[1]
-        pool = 1 if (i + 1 < len(convs) and isinstance(convs[i + 1], str) and H % 2 == 0 and W % 2 == 0) else 0
-        mfma = lib.query('conv3x3_uses_mfma', B, H, W, Cin, Cout, pool)
-        wp = tmp = None
-        if mfma:
-            wp = torch.empty(Cout * Cin * 9, dtype=torch.float32, device=dev)
-            lib('conv3x3_pack_weights', w, wp, Cout, Cin)
-        elif pool:
-            tmp = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
-        Ho, Wo = (H // 2, W // 2) if pool else (H, W)
-        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
-        if _conv_timer is not None and mfma:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            lib('conv3x3_nhwc', cur, w, wp, b, out, tmp, B, H, W, Cin, Cout, 1, pool)
-            e1.record()
-            _conv_timer.append((f'conv{H}x{W}_{Cin}->{Cout}{"+pool" if pool else ""}', e0, e1,
-                                2.0 * B * H * W * Cout * Cin * 9))
+        pool_next = (i + 1 < n) and isinstance(convs[i + 1], str)
+        if cur is None:                                      # first layer: NCHW image -> NHWC
+            out = torch.empty((B, H, W, w.shape[0]), dtype=torch.float32, device=dev)
+            lib('conv3x3_first_nchw', image, w, b, out, B, H, W, w.shape[0], 1)
+            fused = 0
         else:
-            lib('conv3x3_nhwc', cur, w, wp, b, out, tmp, B, H, W, Cin, Cout, 1, pool)
-        cur, H, W = out, Ho, Wo
-        i += 2 if pool else 1
+            fused = 1 if (fuse and pool_next and H % 2 == 0 and W % 2 == 0) else 0
+            out = _conv_block(cur, w, b, B, H, W, fused)
+        if keep is not None:
+            keep.append((out, H, W, 1 if pool_next else 0))
+        cur = out
+        if fused:
+            H, W = H // 2, W // 2
+            i += 2
+        else:
+            i += 1
     Cl = cur.shape[3]
-    x = torch.empty((B, Cl * 49), dtype=torch.float32, device=dev)
-    lib('adaptive_avgpool7_flatten', cur, x, B, H, W, Cl)
+    flat = torch.empty((B, Cl * 49), dtype=torch.float32, device=dev)
+    lib('adaptive_avgpool7_flatten', cur, flat, B, H, W, Cl)
+    return flat, (H, W, Cl)
+
+
+def vgg_trunk_forward(image, convs, fcs, train):
+    """torchvision vgg19 (reference basic_vqa/models.py:23-28,36), forward only (frozen trunk).
+    fcs: list of (weight, bias, act, drop_p) for the classifier.  Returns [B, fcs[-1] out features]."""
+    x, _ = vgg_features_forward(image, convs, fuse_pool=True, keep=None)
+    B, dev = x.shape[0], x.device
     for (w, b, act, drop_p) in fcs:
         m = dropout_mask((B, w.shape[0]), dev, drop_p) if (train and drop_p > 0) else None
         x = linear_fwd(x, _chk(w), b, act, m, 1.0 / (1.0 - drop_p) if m is not None else 1.0)
     return x
+
+
+class VggFeaturesFn(torch.autograd.Function):
+    """Trainable vgg19.features + avgpool + flatten (reference models_lct.py:62-63, pretrained=False).
+    Backward per block: fused ReLU/MaxPool backward -> bias grad (column sum) -> wgrad (MFMA, pixels = K)
+    -> dgrad (the forward MFMA kernel on dZ with flipped/transposed weights)."""
+
+    @staticmethod
+    def forward(ctx, image, plan, *params):
+        convs, k = [], 0
+        for item in plan:
+            if item == 'M':
+                convs.append('M')
+            else:
+                convs.append((params[k], params[k + 1]))
+                k += 2
+        keep = []
+        flat, (Hl, Wl, Cl) = vgg_features_forward(image, convs, fuse_pool=False, keep=keep)
+        ctx.plan, ctx.last = plan, (Hl, Wl, Cl)
+        ctx.meta = [(H, W, pool) for (_, H, W, pool) in keep]
+        saved = [image] + [act for (act, _, _, _) in keep]
+        ctx.save_for_backward(*saved, *params)
+        ctx.nl = len(keep)
+        return flat
+
+    @staticmethod
+    def backward(ctx, dflat):
+        saved = ctx.saved_tensors
+        nl = ctx.nl
+        image, acts, params = saved[0], saved[1:1 + nl], saved[1 + nl:]
+        dflat = _chk(dflat)
+        B, dev = image.shape[0], image.device
+        Hl, Wl, Cl = ctx.last
+        d = torch.empty((B, Hl, Wl, Cl), dtype=torch.float32, device=dev)
+        lib('adaptive_avgpool7_flatten_bwd', dflat, d, B, Hl, Wl, Cl)
+        grads = [None] * len(params)
+        for li in range(nl - 1, -1, -1):
+            H, W, pool = ctx.meta[li]
+            act = acts[li]
+            w, b = params[2 * li], params[2 * li + 1]
+            Cout, Cin = w.shape[0], w.shape[1]
+            dz = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
+            lib('relu_pool_bwd_nhwc', d, act, dz, B, H, W, Cout, pool)
+            if li == 0:
+                scratch = torch.empty(lib.query('conv3x3_first_wgrad_scratch_elems', B, H, W, Cout), dtype=torch.float32, device=dev)
+                dw = torch.empty_like(w)
+                db = torch.empty_like(b)
+                lib('conv3x3_first_wgrad', image, dz, dw, db, scratch, B, H, W, Cout)
+                grads[0], grads[1] = dw, db
+                break
+            x_in = acts[li - 1] if ctx.meta[li - 1][2] == 0 else None
+            if x_in is None:                       # input was the pooled previous activation: recompute the pool
+                Hp, Wp, _ = ctx.meta[li - 1]
+                x_in = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+                lib('maxpool2x2_nhwc', acts[li - 1], x_in, B, Hp, Wp, Cin)
+            grads[2 * li + 1] = colsum(dz.reshape(B * H * W, Cout))
+            dw = torch.empty_like(w)
+            ns = lib.query('conv3x3_wgrad_scratch_elems', B, H, W, Cin, Cout)
+            scratch = torch.empty(max(ns, 1), dtype=torch.float32, device=dev)
+            lib('conv3x3_wgrad_nhwc', x_in, dz, dw, scratch, B, H, W, Cin, Cout)
+            grads[2 * li] = dw
+            # dgrad: conv3x3(dz) with W'[ci][co] = flip(W[co][ci])
+            dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+            if lib.query('conv3x3_uses_mfma', B, H, W, Cout, Cin, 0):
+                wp = torch.empty(Cout * Cin * 9, dtype=torch.float32, device=dev)
+                lib('conv3x3_pack_weights_dgrad', w, wp, Cout, Cin)
+                lib('conv3x3_nhwc', dz, w, wp, None, dx, None, B, H, W, Cout, Cin, 0, 0)
+            else:
+                wt = w.flip(2, 3).transpose(0, 1).contiguous()       # layout glue for the direct fallback kernel
+                lib('conv3x3_nhwc', dz, wt, None, None, dx, None, B, H, W, Cout, Cin, 0, 0)
+            d = dx
+        return (None, None) + tuple(grads)

@@ -59,19 +59,26 @@ class VGG(nn.Module):
                 act = ops.ACT_RELU
                 i += 1
             if i < len(mods) and isinstance(mods[i], nn.Dropout):
-                p = mods[i].p
+                p = mods[i].p if ops.dropout_active(mods[i].training, mods[i].p) else 0.0   # the holder's own mode
                 i += 1
             fcs.append((lin.weight, lin.bias, act, p))
         return convs, fcs
 
     def forward(self, x):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                'lct_vqa_amd: backward through the VGG19 trunk (ImgEncoderFixed with pretrained=False, '
-                'reference models_lct.py:62-63) is not built yet; freeze it or call under no_grad')
         convs, fcs = self._plan()
-        with torch.no_grad():
-            return ops.vgg_trunk_forward(x, convs, fcs, self.training)
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if not needs_grad:
+            with torch.no_grad():
+                return ops.vgg_trunk_forward(x, convs, fcs, True)
+        # trainable trunk (reference models_lct.py:62-63): autograd through the HIP backward kernels
+        plan = ['M' if isinstance(c, str) else 'C' for c in convs]
+        params = [t for c in convs if not isinstance(c, str) for t in c]
+        h = ops.VggFeaturesFn.apply(x, plan, *params)
+        for (w, b, act, p) in fcs:
+            train = p > 0
+            m = ops.dropout_mask((h.shape[0], w.shape[0]), h.device, p) if train else None
+            h = ops.linear(h, w, b, act, m, 1.0 / (1.0 - p) if train else 1.0)
+        return h
 
 
 def vgg19(pretrained=False, **kw):

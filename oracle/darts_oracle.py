@@ -1,0 +1,121 @@
+"""TEST INFRASTRUCTURE -- CPU oracle of the PC-DARTS search network.  NOT the product.
+
+Functional torch fp32 restatement of reference basic_vqa/pcdarts/operations.py:4-104 and
+model_search.py:11-181 over a state_dict with the reference's keys.  Pinned by tests/make_golden.py
+against the reference's own ``Network`` (tests/golden/darts_net.pt).
+BatchNorm: train=True uses batch statistics (and returns the updated running statistics in ``new_stats``),
+train=False uses the running statistics of the state_dict."""
+import torch
+import torch.nn.functional as F
+
+PRIMITIVES = ['none', 'max_pool_3x3', 'avg_pool_3x3', 'skip_connect', 'sep_conv_3x3', 'sep_conv_5x5',
+              'dil_conv_3x3', 'dil_conv_5x5']
+
+
+def _bn(x, P, key, train, new_stats, affine=False):
+    """nn.BatchNorm2d(momentum 0.1, eps 1e-5)."""
+    w = P.get(key + '.weight') if affine else None
+    b = P.get(key + '.bias') if affine else None
+    rm, rv = P[key + '.running_mean'].clone(), P[key + '.running_var'].clone()
+    y = F.batch_norm(x, rm, rv, w, b, train, 0.1, 1e-5)
+    if train and new_stats is not None:
+        new_stats[key + '.running_mean'], new_stats[key + '.running_var'] = rm, rv
+    return y
+
+
+def _relu_conv_bn(x, P, key, train, ns):
+    """operations.py:22-33 (kernel 1, affine False)."""
+    return _bn(F.conv2d(torch.relu(x), P[key + '.op.1.weight']), P, key + '.op.2', train, ns)
+
+
+def _dil_conv(x, P, key, k, stride, pad, train, ns):
+    """operations.py:35-47."""
+    C = x.shape[1]
+    y = F.conv2d(torch.relu(x), P[key + '.op.1.weight'], None, stride, pad, 2, C)
+    y = F.conv2d(y, P[key + '.op.2.weight'])
+    return _bn(y, P, key + '.op.3', train, ns)
+
+
+def _sep_conv(x, P, key, k, stride, pad, train, ns):
+    """operations.py:50-67."""
+    C = x.shape[1]
+    y = F.conv2d(torch.relu(x), P[key + '.op.1.weight'], None, stride, pad, 1, C)
+    y = _bn(F.conv2d(y, P[key + '.op.2.weight']), P, key + '.op.3', train, ns)
+    y = F.conv2d(torch.relu(y), P[key + '.op.5.weight'], None, 1, pad, 1, C)
+    return _bn(F.conv2d(y, P[key + '.op.6.weight']), P, key + '.op.7', train, ns)
+
+
+def _fact_reduce(x, P, key, train, ns):
+    """operations.py:90-104."""
+    x = torch.relu(x)
+    out = torch.cat([F.conv2d(x, P[key + '.conv_1.weight'], None, 2), F.conv2d(x[:, :, 1:, 1:], P[key + '.conv_2.weight'], None, 2)], 1)
+    return _bn(out, P, key + '.bn', train, ns)
+
+
+def _mixed_op(x, w, P, key, stride, train, ns):
+    """model_search.py:41-55 (k = 4)."""
+    C = x.shape[1]
+    xt, x2 = x[:, :C // 4], x[:, C // 4:]
+    outs = []
+    for k, prim in enumerate(PRIMITIVES):
+        kk = f'{key}._ops.{k}'
+        if prim == 'none':
+            o = (xt if stride == 1 else xt[:, :, ::stride, ::stride]).mul(0.)
+        elif prim == 'max_pool_3x3':
+            o = _bn(F.max_pool2d(xt, 3, stride, 1), P, kk + '.1', train, ns)
+        elif prim == 'avg_pool_3x3':
+            o = _bn(F.avg_pool2d(xt, 3, stride, 1, count_include_pad=False), P, kk + '.1', train, ns)
+        elif prim == 'skip_connect':
+            o = xt if stride == 1 else _fact_reduce(xt, P, kk, train, ns)
+        elif prim == 'sep_conv_3x3':
+            o = _sep_conv(xt, P, kk, 3, stride, 1, train, ns)
+        elif prim == 'sep_conv_5x5':
+            o = _sep_conv(xt, P, kk, 5, stride, 2, train, ns)
+        elif prim == 'dil_conv_3x3':
+            o = _dil_conv(xt, P, kk, 3, stride, 2, train, ns)
+        else:
+            o = _dil_conv(xt, P, kk, 5, stride, 4, train, ns)
+        outs.append(w[k] * o)
+    t1 = sum(outs)
+    ans = torch.cat([t1, x2 if stride == 1 else F.max_pool2d(x2, 2, 2)], 1)
+    B, Cc, H, W = ans.shape
+    return ans.view(B, 4, Cc // 4, H, W).transpose(1, 2).reshape(B, Cc, H, W)       # channel_shuffle(ans, 4)
+
+
+def _edge_weights(alphas, betas, steps=4):
+    """model_search.py:154-175."""
+    w = F.softmax(alphas, dim=-1)
+    n, start = 3, 2
+    w2 = F.softmax(betas[0:2], dim=-1)
+    for _ in range(steps - 1):
+        end = start + n
+        w2 = torch.cat([w2, F.softmax(betas[start:end], dim=-1)], 0)
+        start, n = end, n + 1
+    return w, w2
+
+
+def network_forward(image, P, arch, train=False, new_stats=None, layers=4, steps=4, multiplier=4, prefix=''):
+    """model_search.py:147-181.  arch = [alphas_normal, alphas_reduce, betas_normal, betas_reduce]."""
+    N, _, H, W = image.shape
+    x = image.expand(N, 3, H, W)
+    s = _bn(F.conv2d(x, P[prefix + 'stem.0.weight'], None, 1, 1), P, prefix + 'stem.1', train, new_stats, affine=True)
+    s0 = s1 = s
+    reduction_prev = False
+    for ci in range(layers):
+        reduction = ci in [layers // 3, 2 * layers // 3]
+        key = f'{prefix}cells.{ci}'
+        w, w2 = _edge_weights(arch[1], arch[3], steps) if reduction else _edge_weights(arch[0], arch[2], steps)
+        p0 = _fact_reduce(s0, P, key + '.preprocess0', train, new_stats) if reduction_prev else \
+            _relu_conv_bn(s0, P, key + '.preprocess0', train, new_stats)
+        p1 = _relu_conv_bn(s1, P, key + '.preprocess1', train, new_stats)
+        states, offset = [p0, p1], 0
+        for i in range(steps):
+            acc = 0
+            for j, h in enumerate(states):
+                stride = 2 if reduction and j < 2 else 1
+                acc = acc + w2[offset + j] * _mixed_op(h, w[offset + j], P, f'{key}._ops.{offset + j}', stride, train, new_stats)
+            offset += len(states)
+            states.append(acc)
+        s0, s1 = s1, torch.cat(states[-multiplier:], 1)
+        reduction_prev = reduction
+    return F.adaptive_avg_pool2d(s1, 7).flatten(1)

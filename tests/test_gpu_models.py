@@ -112,3 +112,26 @@ def test_train_step_matches_oracle(pkg):
         assert rel_err(loss, loss_o) < 1e-4
     for k, v in m.state_dict().items():
         assert rel_err(v, P[k]) < 1e-3, k
+
+
+def test_ef_small_trainable_vgg_against_reference_goldens(pkg):
+    """EF model with pretrained=False (trainable VGG19, reference models_lct.py:62-63): loss, every small gradient,
+    and sum / abs-sum checksums of the VGG gradients produced by the reference."""
+    ops, _, models_lct, config = pkg
+    from _util import checksum
+    fx = load('ef_small_trainvgg.pt')
+    config.ARCH_TYPE = 'fixed'
+    m = _build(models_lct.VqaModel, fx, pretrained=False).eval()
+    img, qst, lab = fx['image'].to(DEV), fx['question'].to(DEV), fx['label'].to(DEV)
+    loss = m._loss(img, qst, lab)
+    assert rel_err(loss, fx['loss']) < 1e-4
+    grads = torch.autograd.grad(loss, list(m.parameters()), allow_unused=True)
+    assert sum(g is None for g in grads) == fx['num_none_grads'] == 0
+    for (k, _), g in zip(m.named_parameters(), grads):
+        if k in fx['grads']:
+            assert rel_err(g, fx['grads'][k]) < 1e-3, k
+        else:
+            s, a = checksum(g)
+            rs, ra = fx['vgg_grad_checksums'][k]
+            assert abs(a - ra) <= 2e-3 * max(ra, 1e-12), (k, a, ra)
+            assert abs(s - rs) <= 2e-3 * max(ra, 1e-12), (k, s, rs)

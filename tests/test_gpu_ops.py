@@ -223,3 +223,59 @@ def test_dropout_mask_statistics(ops):
     assert abs(m.float().mean().item() - 0.5) < 5e-3
     ops.manual_seed(123)
     assert torch.equal(m, ops.dropout_mask((1000, 1000), torch.device(DEV), 0.5))
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 16, 16, 64, 64), (3, 8, 8, 64, 128), (2, 28, 28, 128, 64), (3, 14, 14, 64, 64),
+                                            (2, 56, 56, 64, 64), (1, 6, 6, 16, 32)])
+def test_conv3x3_wgrad_dgrad(ops, hip_lib, B, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1).requires_grad_()
+    dz = torch.randn(B, Cout, H, W, generator=g)
+    y = F.conv2d(x, w, None, padding=1)
+    gx, gw = torch.autograd.grad(y, [x, w], dz)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dzd = dz.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = w.detach().to(DEV)
+    dw = torch.full_like(wd, float('nan'))
+    ns = hip_lib.query('conv3x3_wgrad_scratch_elems', B, H, W, Cin, Cout)
+    scratch = torch.empty(max(ns, 1), device=DEV)
+    hip_lib('conv3x3_wgrad_nhwc', xd, dzd, dw, scratch, B, H, W, Cin, Cout)
+    assert rel_err(dw, gw) < 5e-5
+    dx = torch.full((B, H, W, Cin), float('nan'), device=DEV)
+    if hip_lib.query('conv3x3_uses_mfma', B, H, W, Cout, Cin, 0):
+        wp = torch.empty(Cout * Cin * 9, device=DEV)
+        hip_lib('conv3x3_pack_weights_dgrad', wd, wp, Cout, Cin)
+        hip_lib('conv3x3_nhwc', dzd, wd, wp, None, dx, None, B, H, W, Cout, Cin, 0, 0)
+    else:
+        wt = wd.flip(2, 3).transpose(0, 1).contiguous()
+        hip_lib('conv3x3_nhwc', dzd, wt, None, None, dx, None, B, H, W, Cout, Cin, 0, 0)
+    assert rel_err(dx.permute(0, 3, 1, 2), gx) < 5e-5
+
+
+def test_trainable_vgg_trunk_backward(ops):
+    """vgg19 trunk with gradients (reference models_lct.py:62-63) at 32x32: every parameter gradient vs torch."""
+    from lct_vqa_amd import vgg
+    torch.manual_seed(8)
+    m = vgg.vgg19()
+    m.classifier = torch.nn.Sequential(*list(m.classifier.children())[:-1])
+    m.eval()
+    x = torch.randn(2, 3, 32, 32)
+    # torch reference of the same module structure
+    h = x
+    for mod in m.features:
+        h = mod(h) if not isinstance(mod, torch.nn.ReLU) else torch.relu(h)
+    h = torch.flatten(m.avgpool(h), 1)
+    for mod in m.classifier:
+        h = mod(h) if not isinstance(mod, torch.nn.ReLU) else torch.relu(h)
+    wgt = torch.randn_like(h)
+    ref = torch.autograd.grad((h * wgt).sum(), list(m.parameters()))
+    md = vgg.vgg19()
+    md.classifier = torch.nn.Sequential(*list(md.classifier.children())[:-1])
+    md.load_state_dict(m.state_dict())
+    md = md.to(DEV).eval()
+    out = md(x.to(DEV))
+    assert rel_err(out, h) < 1e-4
+    got = torch.autograd.grad((out * wgt.to(DEV)).sum(), list(md.parameters()))
+    for (k, _), a, r in zip(md.named_parameters(), got, ref):
+        assert rel_err(a, r) < 2e-3, k

@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--only', default='')
+    ap.add_argument('--bwd', action='store_true', help='also time wgrad and dgrad')
     args = ap.parse_args()
     lib.load()
     dev = torch.device('cuda')
@@ -59,6 +60,24 @@ def main():
                 lib('conv3x3_nhwc', xin, wt, wp, bs, out, None, B, H, H, Cin, Cout, 1, pool)
             e1.record(); torch.cuda.synchronize()
             seen[key] = e0.elapsed_time(e1) / args.iters
+            if args.bwd:
+                dz = torch.randn(B, H, H, Cout, device=dev)
+                dw = torch.empty_like(wt)
+                ns = lib.query('conv3x3_wgrad_scratch_elems', B, H, H, Cin, Cout)
+                scratch = torch.empty(max(ns, 1), device=dev)
+                dx = torch.empty(B, H, H, Cin, device=dev)
+                wpd = torch.empty(Cout * Cin * 9, device=dev)
+                lib('conv3x3_pack_weights_dgrad', wt, wpd, Cout, Cin)
+                for nm, fn in (('wgrad', lambda: lib('conv3x3_wgrad_nhwc', xin, dz, dw, scratch, B, H, H, Cin, Cout)),
+                               ('dgrad', lambda: lib('conv3x3_nhwc', dz, wt, wpd, None, dx, None, B, H, H, Cout, Cin, 0, 0))):
+                    for it in range(args.iters + 1):
+                        if it == 1:
+                            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+                        fn()
+                    e1.record(); torch.cuda.synchronize()
+                    t = e0.elapsed_time(e1) / args.iters
+                    print(f'   {nm} {H}x{H} {Cin}->{Cout}: {t:7.3f} ms  {2.0 * B * H * H * Cout * Cin * 9 / t / 1e9:6.1f} TFLOP/s')
+                del dz, dx
             del xin, out
         ms = seen[key]
         fl = 2.0 * B * H * H * Cout * Cin * 9
