@@ -95,6 +95,10 @@ int lctvqa_embed_scatter_add(const long* idx, const float* dy, const float* y, f
 /* one LSTM time step, gate order i,f,g,o.  pre-activations = xp + hp, each [B][4H] */
 int lctvqa_lstm_cell_fwd(const float* xp, const float* hp, const float* c_prev, float* gates, float* c_out, float* h_out,
                          int B, int H, void* stream);
+/* fused time step: gates = xp + h_prev.W_hh^T + b_hh -> cell update, one launch, no split-K / pointwise passes */
+int lctvqa_lstm_step_fused_supported(int B, int H);
+int lctvqa_lstm_step_fused(const float* xp, const float* h_prev, const float* c_prev, const float* w_hh,
+                           const float* b_hh, float* gates, float* c_out, float* h_out, int B, int H, void* stream);
 int lctvqa_lstm_cell_bwd(const float* dh_rec, const float* dh_ext, const float* dc_next, const float* gates,
                          const float* c_prev, const float* c_cur, float* dgates, float* dc_prev, int B, int H, void* stream);
 /* tanh(cat(h,c)) of models.py:62-65 (num_layers = 1) and its backward */

@@ -22,10 +22,11 @@
 //    lanes read consecutive 16-B slots (bank-conflict free) and the inner loop carries no
 //    address arithmetic at all.  The four waves of a workgroup each gather one chunk plane
 //    of the same 64 pixels, so the 64-B pixel segments are fetched from L2 once;
-//  * every wave streams its OWN 2 KB weight piece per (chunk, tap) step into a private
-//    double buffer and waits only on its own vmcnt -> no workgroup barrier per step; the
-//    one barrier per 16-channel chunk (9 steps, ~500+ MFMAs per wave) guards the shared,
-//    double-buffered halo tile.  Two workgroups per CU cover each other's waits;
+//  * double-buffered halo + weight tiles, one barrier per (chunk, tap) step (56-64 MFMAs
+//    = ~4000 cycles per wave), two workgroups per CU so one computes while the other waits.
+//    (Measured A/B on one device, tools/ab_conv.py: per-wave private weight rings without the
+//    per-step barrier, a 3-deep ring with counted vmcnt, and e-outer MFMA ordering were all
+//    2-3 % SLOWER than this simple structure; they are not used.);
 //  * n-tile = blockIdx % NT, so (blocks are dealt round-robin over the 8 XCDs) every XCD
 //    streams the weights of a single n-tile and keeps them in its private 4 MiB L2.
 //  * epilogue fuses bias + ReLU (+ 2x2 max-pool when requested) and writes NHWC.
@@ -79,24 +80,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
   static_assert(TW % SW == 0 && TH % SH == 0, "sub-tile must tile the patch");
   static_assert(WM * WN == 4, "4 waves");
   static_assert(RS >= TW + 2, "LDS row stride must cover the halo row");
-  constexpr int TWP = RS;                             // LDS row stride in pixels (>= TW+2; padded to dodge bank conflicts)
+  constexpr int TWP = RS;                             // LDS row stride in pixels (>= TW+2; padded where it dodges bank conflicts)
   constexpr int HRMAX = TH + 4;                       // TH + 2 halo + up to 2 gap rows
   constexpr int PMAX = HRMAX * TWP;                   // halo pixels
   constexpr int AROUNDS = (PMAX + 63) / 64;           // each wave gathers one chunk plane of 64 pixels per round
-  constexpr int PLANE = PMAX * 4;                     // floats per chunk plane (last round is lane-masked)
+  constexpr int PPAD = AROUNDS * 64;                  // pixels per plane (padded)
+  constexpr int PLANE = PPAD * 4;                     // floats per chunk plane
   constexpr int ASZ = 4 * PLANE;                      // floats per halo buffer
-#ifndef CONV_WBUFS
-#define CONV_WBUFS 3
-#endif
-  constexpr int WBUFS = CONV_WBUFS;                   // private weight ring: 3 = prefetch distance 2 steps, 2 = distance 1
+  constexpr int WSZ = WN * 512;                       // floats per weight step tile
+  constexpr int WCHUNKS = WN * 128;                   // 16-B chunks per weight step tile
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* abuf = smem;                // [2][ASZ]
+  float* wbuf = smem + 2 * ASZ;      // [2][WSZ]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* wbuf = smem + 2 * ASZ + wave * (WBUFS * 512);   // this wave's private [3][512] weight ring
   const int wm = wave / WN, wn = wave % WN;
   const int j = lane & 31, h = lane >> 5;
 
@@ -136,21 +136,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     int g = (yy >= H) + (yy >= 2 * H);
     base[m] = ((ty + g) * TWP + tx) * 4 + h * PLANE;     // float offset inside a halo buffer
   }
-  const int bbase = h * 128 + j * 4;                      // float offset inside this wave's weight piece
-  const float* wsrc = wp + (long)(n_tile * WN + wn) * S * 512 + lane * 4;   // this wave's piece stream [S][512]
+  const int bbase = wn * 512 + h * 128 + j * 4;           // float offset inside a weight step tile
+  const float* wsrc = wp + (long)(n_tile * WN) * S * 512;   // [WN pieces][S][512] -> piece stride S*512
 
   auto stage_a = [&](int chunk, float* dst) {
 #pragma unroll
     for (int r = 0; r < AROUNDS; r++) {
-      if (r * 64 < PLIVE && r * 64 + lane < PMAX) {
+      if (r * 64 < PLIVE) {
         const float* src = (aoff[r] >= 0) ? (x + (long)aoff[r] + chunk * 16) : g_zero_page;
         glds16(src, dst + wave * PLANE + r * 256);
       }
     }
   };
-  auto stage_w = [&](int s, float* dst) {            // 2 KB = 2 wave-instructions, private to this wave
-    glds16(wsrc + (long)s * 512, dst);
-    glds16(wsrc + (long)s * 512 + 256, dst + 256);
+  auto stage_w = [&](int s, float* dst) {
+#pragma unroll
+    for (int r = 0; r < (WCHUNKS + 255) / 256; r++) {
+      int q = r * 256 + tid;
+      if (WCHUNKS >= 256 || tid < WCHUNKS) {
+        int piece = q >> 7, within = q & 127;
+        glds16(wsrc + ((long)piece * S + s) * 512 + within * 4, dst + (r * 256 + wave * 64) * 4);
+      }
+    }
   };
 
   f32x16 acc[MT];
@@ -161,7 +167,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 
   stage_a(0, abuf);
   stage_w(0, wbuf);
-  if (WBUFS == 3 && S > 1) stage_w(1, wbuf + 512);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -170,31 +175,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const float* ab = abuf + (chunk & 1) * ASZ;
 #pragma unroll
     for (int tap = 0; tap < 9; tap++, s++) {
-      // prefetch: next halo chunk (once per chunk) first, then the weight piece two steps ahead,
-      // so that the two youngest VMEM ops are always that weight piece (counted vmcnt below)
+      if (s + 1 < S) stage_w(s + 1, wbuf + ((s + 1) & 1) * WSZ);
       if (tap == 0 && chunk + 1 < NCH) stage_a(chunk + 1, abuf + ((chunk + 1) & 1) * ASZ);
-      const bool more = (s + WBUFS - 1 < S);
-      if (more) stage_w(s + WBUFS - 1, wbuf + ((WBUFS == 3) ? ((tap + 2) % 3) : ((s + 1) & 1)) * 512);
-      const float* wb = wbuf + ((WBUFS == 3) ? (tap % 3) : (s & 1)) * 512 + bbase;
+      const float* wb = wbuf + (s & 1) * WSZ + bbase;
       const int tapoff = ((tap / 3) * TWP + (tap % 3)) * 4;
 #pragma unroll
       for (int kk = 0; kk < 2; kk++) {
         const f32x4 bf = *(const f32x4*)(wb + kk * 256);
-        f32x4 af[MT];
 #pragma unroll
-        for (int m = 0; m < MT; m++) af[m] = *(const f32x4*)(ab + base[m] + tapoff + kk * 2 * PLANE);
-        // e outer / m inner: consecutive MFMAs hit independent accumulators
-#pragma unroll
-        for (int e = 0; e < 4; e++)
-#pragma unroll
-          for (int m = 0; m < MT; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][e], bf[e], acc[m], 0, 0, 0);
+        for (int m = 0; m < MT; m++) {
+          const f32x4 af = *(const f32x4*)(ab + base[m] + tapoff + kk * 2 * PLANE);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], acc[m], 0, 0, 0);
+        }
       }
-      // end of step: the weight piece of step s+1 (and, at tap 0, the next halo chunk) must have
-      // landed; the piece of step s+2 stays in flight.  (The compiler may slide register-only MFMAs
-      // across this wait; with a prefetch distance of two steps the wait never stalls either way.)
-      if (more && WBUFS == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (tap == 8) __syncthreads();                      // halo buffers swap roles
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
   }
 
@@ -402,9 +400,10 @@ template <int TH, int TW, int RS, int SH, int SW, int WM, int WN, int MT>
 static int launch_conv(const float* x, const float* wp, const float* bias, float* y, int B, int H, int W, int Cin,
                        int Cout, int relu, int pool, int G, hipStream_t st) {
   constexpr int TWP = RS;
-  constexpr int ASZ = (TH + 4) * TWP * 16;
-  constexpr int WSZ = 4 * CONV_WBUFS * 512;
-  size_t lds = (size_t)(2 * ASZ + WSZ) * sizeof(float);
+  constexpr int AROUNDS = ((TH + 4) * TWP + 63) / 64;
+  constexpr int ASZ = AROUNDS * 64 * 16;
+  constexpr int WSZ = WN * 512;
+  size_t lds = (size_t)(2 * ASZ + 2 * WSZ) * sizeof(float);
   long Rtot = (long)B * H;
   int mtiles = cdiv(Rtot, TH) * (W / TW);
   int ntiles = Cout / (32 * WN);
@@ -498,7 +497,7 @@ int lctvqa_conv3x3_nhwc(const float* x, const float* w_oihw, const float* w_pack
   } while (0)
   switch (select_patch(W, Cout)) {
     case 1: LAUNCH(8, 32, 34, 2, 16); break;
-    case 2: LAUNCH(8, 28, 36, 8, 4); break;
+    case 2: LAUNCH(8, 28, 30, 8, 4); break;
     case 3: LAUNCH(16, 16, 18, 2, 16); break;
     case 4: LAUNCH(16, 14, 18, 16, 2); break;
     case 5: LAUNCH(32, 8, 10, 4, 8); break;

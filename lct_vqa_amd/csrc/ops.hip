@@ -523,3 +523,93 @@ extern "C" int lctvqa_scale_by_device_scalar(const float* a, const float* x, flo
   hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_blocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, a, x, y, n);
   return lct_check_launch("scale_by_device_scalar");
 }
+
+// ------------------------------------------------------------------------------------------
+// Fused LSTM time step (nn.LSTM, reference basic_vqa/models.py:61, models_lct.py:107-108):
+//   pre = xp[b][4H] (input projection + b_ih, precomputed for all t) + h_prev[b][:] . W_hh^T + b_hh
+//   i,f,g,o -> c = f*c_prev + i*g ; h = o*tanh(c)
+// One launch per step, no split-K slabs, no separate pointwise pass: a workgroup owns 32 batch rows x
+// 32 hidden units and ALL FOUR gates of those units (4 accumulator tiles per wave on
+// v_mfma_f32_32x32x2_f32), its 4 waves split K, partial tiles meet in LDS and the cell update is the
+// epilogue.  h rows and W_hh rows are read as 16-B vectors straight from L2 (W_hh = 4 MB stays L2/MALL
+// resident across the T steps).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_step_fused_kernel(const float* __restrict__ xp, const float* __restrict__ h_prev,
+                                                              const float* __restrict__ c_prev, const float* __restrict__ w_hh,
+                                                              const float* __restrict__ b_hh, float* __restrict__ gates,
+                                                              float* __restrict__ c_out, float* __restrict__ h_out, int B, int H) {
+  extern __shared__ __attribute__((aligned(16))) float red[];      // [4 waves][4 gates][16 regs][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  const int nut = H / 32;
+  const int ut = blockIdx.x % nut, bt = blockIdx.x / nut;
+  const int b0 = bt * 32, u0 = ut * 32;
+  f32x16 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[g][r] = 0.f;
+  const int arow = min(b0 + j, B - 1);                 // clamp: rows >= B are computed but never stored
+  const float* ap = h_prev + (long)arow * H;
+  const int ngroups = H / 16;
+  for (int grp = wave; grp < ngroups; grp += 4) {
+    const int k0 = grp * 16;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      const int kc = k0 + (2 * kk + hh) * 4;
+      const f32x4 af = *(const f32x4*)(ap + kc);
+      f32x4 bf[4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) bf[g] = *(const f32x4*)(w_hh + (long)(g * H + u0 + j) * H + kc);
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[g][e], acc[g], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[((wave * 4 + g) * 16 + r) * 64 + lane] = acc[g][r];
+  __syncthreads();
+  // wave w finishes accumulator registers 4w..4w+3 of all four gates
+#pragma unroll
+  for (int rr = 0; rr < 4; rr++) {
+    const int r = wave * 4 + rr;
+    const int row = b0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    const int u = u0 + j;
+    float pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; w++) s += red[((w * 4 + g) * 16 + r) * 64 + lane];
+      pre[g] = s;
+    }
+    if (row < B) {
+      const long g0 = (long)row * 4 * H + u;
+      const long o = (long)row * H + u;
+      const float i = sigmoidf_(pre[0] + xp[g0] + b_hh[u]);
+      const float f = sigmoidf_(pre[1] + xp[g0 + H] + b_hh[H + u]);
+      const float g = tanhf(pre[2] + xp[g0 + 2 * H] + b_hh[2 * H + u]);
+      const float oo = sigmoidf_(pre[3] + xp[g0 + 3 * H] + b_hh[3 * H + u]);
+      const float c = f * c_prev[o] + i * g;
+      gates[g0] = i; gates[g0 + H] = f; gates[g0 + 2 * H] = g; gates[g0 + 3 * H] = oo;
+      c_out[o] = c;
+      h_out[o] = oo * tanhf(c);
+    }
+  }
+}
+
+extern "C" int lctvqa_lstm_step_fused_supported(int B, int H) { return (H % 32 == 0 && H >= 32 && B >= 1) ? 1 : 0; }
+
+extern "C" int lctvqa_lstm_step_fused(const float* xp, const float* h_prev, const float* c_prev, const float* w_hh,
+                                      const float* b_hh, float* gates, float* c_out, float* h_out, int B, int H, void* stream) {
+  LCT_REQUIRE(lctvqa_lstm_step_fused_supported(B, H), "lstm_step_fused: need H %% 32 == 0 (got H=%d)", H);
+  LCT_REQUIRE((((uintptr_t)h_prev | (uintptr_t)w_hh) & 15) == 0, "lstm_step_fused: h_prev / w_hh must be 16-B aligned");
+  const size_t lds = 4 * 4 * 16 * 64 * sizeof(float);
+  hipFuncSetAttribute((const void*)lstm_step_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(lstm_step_fused_kernel, dim3(cdiv(B, 32) * (H / 32)), dim3(256), lds, (hipStream_t)stream, xp, h_prev, c_prev, w_hh,
+                     b_hh, gates, c_out, h_out, B, H);
+  return lct_check_launch("lstm_step_fused");
+}

@@ -230,10 +230,14 @@ class LSTMFn(torch.autograd.Function):
         else:
             h_all[0].copy_(h0.reshape(B, H))
             c_all[0].copy_(c0.reshape(B, H))
-        hp = torch.empty((B, 4 * H), dtype=torch.float32, device=dev)
-        for t in range(T):
-            linear_fwd(h_all[t], w_hh, b_hh, out=hp)
-            lib('lstm_cell_fwd', xp[t], hp, c_all[t], gates[t], c_all[t + 1], h_all[t + 1], B, H)
+        if lib.query('lstm_step_fused_supported', B, H):
+            for t in range(T):                       # one fused launch per time step
+                lib('lstm_step_fused', xp[t], h_all[t], c_all[t], w_hh, b_hh, gates[t], c_all[t + 1], h_all[t + 1], B, H)
+        else:
+            hp = torch.empty((B, 4 * H), dtype=torch.float32, device=dev)
+            for t in range(T):
+                linear_fwd(h_all[t], w_hh, b_hh, out=hp)
+                lib('lstm_cell_fwd', xp[t], hp, c_all[t], gates[t], c_all[t + 1], h_all[t + 1], B, H)
         ctx.save_for_backward(x, w_ih, w_hh, gates, h_all, c_all)
         ctx.has_init = h0 is not None
         return h_all[1:], h_all[T].clone(), c_all[T].clone()

@@ -65,3 +65,48 @@ def test_config_defaults_and_active():
     assert (config.IMG_EMBED_SIZE, config.WORD_EMBED_SIZE, config.LSTM_HIDDEN_SIZE, config.GRAD_CLIP) == (512, 300, 512, 5)
     assert config.SEED == 10 and config.W_LAMBDA == 1.0 and config.TEMPERATURE == 0.1
     assert config.active() is config
+
+
+def test_darts_network_shell_matches_reference_keys_and_init():
+    from lct_vqa_amd.basic_vqa import config
+    from lct_vqa_amd.basic_vqa.pcdarts.model_search import Network
+    from lct_vqa_amd.basic_vqa.pcdarts.genotypes import PRIMITIVES
+    fx = load('darts_net.pt')
+    old = config.DEVICE
+    try:
+        config.DEVICE = 'cpu'
+        torch.manual_seed(fx['seed'])
+        net = Network(fx['C'], 512, fx['layers'])
+    finally:
+        config.DEVICE = old
+    sd = net.state_dict()
+    assert set(sd) == set(fx['state']) and len(sd) == 2136
+    for k, v in fx['state'].items():
+        assert torch.equal(sd[k], v), k
+    assert [tuple(a.shape) for a in net.arch_parameters()] == [(14, 8), (14, 8), (14,), (14,)]
+    assert not any('alpha' in k or 'beta' in k for k in sd)          # arch parameters are NOT in the state_dict
+    assert PRIMITIVES[0] == 'none' and len(PRIMITIVES) == 8
+    assert sum(p.numel() for p in net.parameters()) == 158496
+    for a, r in zip(net.arch_parameters(), fx['arch']):
+        a.data.copy_(r)
+    assert str(net.genotype()) == fx['genotype']                      # host-side decode (model_search.py:205-250)
+
+
+def test_darts_vqa_factory_surface():
+    from lct_vqa_amd.darts_vqa import factory, vqa_model
+    for fn, args in [('get_vqa_model', ['args', 'dataset']), ('get_optimizer', ['args', 'model']),
+                     ('get_scheduler', ['args', 'optimizer']), ('get_architect', ['args', 'model'])]:
+        assert list(inspect.signature(getattr(factory, fn)).parameters) == args
+    args = types.SimpleNamespace(unified=False, embed_size=32, word_embed_size=16, num_layers=1, hidden_size=32,
+                                 arch_type='vgg', learn_rate=1e-3, step_size=10, gamma=0.1, arch_learn_rate=6e-4,
+                                 arch_wt_decay=1e-3, qst_only=False)
+    m = factory.get_vqa_model(args, _DS)
+    assert isinstance(m, vqa_model.VqaModel) and m.qst_encoder.fc1.out_features == 50 and m.qst_encoder.fc2.out_features == 32
+    assert factory.get_architect(args, m) is None
+    opt = factory.get_optimizer(args, m)
+    assert factory.get_scheduler(args, opt).gamma == 0.1
+    args.arch_type = 'bogus'
+    with pytest.raises(Exception):
+        factory.get_architect(args, m)
+    with pytest.raises(Exception):
+        vqa_model.get_img_encoder('resnet', 32)

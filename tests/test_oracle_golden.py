@@ -64,3 +64,24 @@ def test_w_full_b4_logits_and_argmax():
     lg = O.w_model_forward(img, fx['question'], P)
     assert rel_err(lg, fx['eval_logits']) < 1e-5
     assert torch.equal(lg.argmax(1), fx['argmax'])
+
+
+def test_darts_oracle_against_reference_network():
+    """oracle/darts_oracle.py vs the reference's pcdarts Network (tests/golden/darts_net.pt)."""
+    from oracle import darts_oracle as DO
+    fx = load('darts_net.pt')
+    P, arch, img = fx['state'], fx['arch'], fx['image']
+    assert rel_err(DO.network_forward(img, P, arch, False), fx['eval_out']) < 1e-5
+    names = list(fx['param_grads'])
+    Pg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in P.items()}
+    ag = [a.clone().requires_grad_(True) for a in arch]
+    ns = {}
+    tr = DO.network_forward(img, Pg, ag, True, ns)
+    assert rel_err(tr, fx['train_out']) < 1e-5
+    grads = torch.autograd.grad((tr * fx['loss_weight']).sum(), ag + [Pg[n] for n in names])
+    for a, r in zip(grads[:4], fx['arch_grads']):
+        assert rel_err(a, r) < 1e-4
+    for n, a in zip(names, grads[4:]):
+        assert rel_err(a, fx['param_grads'][n]) < 1e-4, n
+    for k, v in fx['running_after'].items():
+        assert rel_err(ns[k], v) < 1e-6, k
