@@ -82,6 +82,11 @@ int lctvqa_gemm_f32_ex(const float* A, long a_ms, long a_ks, const float* B, lon
                        int M, int N, int K, const float* bias, const float* addend, long ld_add, int act,
                        const uint8_t* mask, long ld_mask, float mask_scale, float* workspace, long workspace_bytes,
                        int relu_ab, void* stream);
+/* fusion head, first half (models.py:96-100) in ONE GEMM launch: the pointwise mul+tanh+dropout(mask1) is applied to the A
+ * operand while it is staged: h1 = mask2*scale2*tanh([mask1*scale1*tanh(img.qst)] . W1^T + b1); masks dense uint8 or NULL */
+int lctvqa_fusion_fc1(const float* img, const float* qst, const uint8_t* mask1, float scale1, const float* w1, const float* b1,
+                      const uint8_t* mask2, float scale2, float* h1, int B, int E, int A, float* workspace, long workspace_bytes,
+                      void* stream);
 /* out[n] = sum_m X[m][n]  (bias gradients); scratch: lctvqa_colsum_scratch_elems(M,N) floats */
 long lctvqa_colsum_scratch_elems(int M, int N);
 int lctvqa_colsum_f32(const float* X, long ld, int M, int N, float* out, float* scratch, void* stream);
@@ -99,6 +104,10 @@ int lctvqa_lstm_cell_fwd(const float* xp, const float* hp, const float* c_prev, 
 int lctvqa_lstm_step_fused_supported(int B, int H);
 int lctvqa_lstm_step_fused(const float* xp, const float* h_prev, const float* c_prev, const float* w_hh,
                            const float* b_hh, float* gates, float* c_out, float* h_out, int B, int H, void* stream);
+/* fused BPTT step: dh_rec = dgates_t . W_hh, then the cell backward of step t-1 in the epilogue */
+int lctvqa_lstm_step_bwd_fused(const float* dg_t, const float* w_hh, const float* dh_ext, const float* dc_next,
+                               const float* gates_p, const float* c_pp, const float* c_p, float* dg_p, float* dc_prev,
+                               int B, int H, void* stream);
 int lctvqa_lstm_cell_bwd(const float* dh_rec, const float* dh_ext, const float* dc_next, const float* gates,
                          const float* c_prev, const float* c_cur, float* dgates, float* dc_prev, int B, int H, void* stream);
 /* tanh(cat(h,c)) of models.py:62-65 (num_layers = 1) and its backward */

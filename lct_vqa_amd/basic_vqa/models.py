@@ -79,9 +79,9 @@ class VqaModel(nn.Module):
         dev = img_feature.device
         scale = 1.0 / (1.0 - p) if train else 1.0
         m1 = ops.dropout_mask(tuple(img_feature.shape), dev, p) if train else None
-        z = ops.MulTanhDropFn.apply(img_feature, qst_feature, m1, scale)
-        m2 = ops.dropout_mask((z.shape[0], self.fc1.out_features), dev, p) if train else None
-        z = ops.linear(z, self.fc1.weight, self.fc1.bias, ops.ACT_TANH, m2, scale)
+        m2 = ops.dropout_mask((img_feature.shape[0], self.fc1.out_features), dev, p) if train else None
+        # mul -> tanh -> dropout fused into the A-operand load of the fc1 GEMM (+ tanh + dropout epilogue)
+        z = ops.FusionFc1Fn.apply(img_feature, qst_feature, self.fc1.weight, self.fc1.bias, m1, scale, m2, scale)
         return ops.linear(z, self.fc2.weight, self.fc2.bias)
 
     def forward(self, img, qst):

@@ -60,6 +60,11 @@ __device__ __forceinline__ void store_tile(float* __restrict__ L, int tid, const
 }
 
 struct GemmEpi {
+  // fused A-operand prologue of the fusion head (reference basic_vqa/models.py:96-98 feeding fc1):
+  //   A(m,k) := amask[m][k] ? ascale * tanh(A(m,k) * a2[m*a_ms + k*a_ks]) : 0      (a2 == null: plain A)
+  const float* a2;
+  const uint8_t* amask;  // dense [M][K] or null
+  float ascale;
   const float* bias;     // [N] or null
   const float* addend;   // [M][ld_add] or null
   long ld_add;
@@ -68,6 +73,21 @@ struct GemmEpi {
   float mask_scale;
   int act;               // 0 none, 1 relu, 2 tanh
 };
+
+// A(m,k) := mask * scale * tanh(A * A2) applied to the 8 staged elements of this thread (K-contiguous modes only)
+template <int MODE>
+__device__ __forceinline__ void fuse_a(float (&r)[8], const GemmEpi& e, long rs, long ks, int row0, int nrows, int k0, int kend,
+                                       int K, int tid) {
+  float r2[8];
+  load_tile<MODE>(e.a2, rs, ks, row0, nrows, k0, kend, tid, r2);
+  const int row = row0 + (tid >> 1), k = k0 + (tid & 1) * 8;      // element mapping of LD_KVEC / LD_KSCALAR
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    float v = tanhf(r[i] * r2[i]);
+    if (e.amask) v = (row < nrows && k + i < kend && e.amask[(long)row * K + k + i]) ? v * e.ascale : 0.f;
+    r[i] = v;
+  }
+}
 
 __device__ __forceinline__ float apply_epi(float v, int m, int n, const GemmEpi& e) {
   if (e.bias) v += e.bias[n];
@@ -105,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
   if (nk > 0) {
     load_tile<AMODE>(A, a_ms, a_ks, m0, M, kbeg, kend, tid, ra);
     load_tile<BMODE>(B, b_ns, b_ks, n0, N, kbeg, kend, tid, rb);
+    if (epi.a2) fuse_a<AMODE>(ra, epi, a_ms, a_ks, m0, M, kbeg, kend, K, tid);
     if (relu_ab & 1) {
 #pragma unroll
       for (int i = 0; i < 8; i++) ra[i] = fmaxf(ra[i], 0.f);
@@ -122,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
     if (kt + 1 < nk) {
       load_tile<AMODE>(A, a_ms, a_ks, m0, M, kbeg + (kt + 1) * 16, kend, tid, ra);
       load_tile<BMODE>(B, b_ns, b_ks, n0, N, kbeg + (kt + 1) * 16, kend, tid, rb);
+      if (epi.a2) fuse_a<AMODE>(ra, epi, a_ms, a_ks, m0, M, kbeg + (kt + 1) * 16, kend, K, tid);
       if (relu_ab & 1) {
 #pragma unroll
         for (int i = 0; i < 8; i++) ra[i] = fmaxf(ra[i], 0.f);
@@ -218,6 +240,10 @@ static int pick_mode(const float* P, long rs, long ks, int K) {
   return LD_KSCALAR;   // fully general strides
 }
 
+static thread_local const float* g_fuse_a2 = nullptr;
+static thread_local const uint8_t* g_fuse_amask = nullptr;
+static thread_local float g_fuse_ascale = 1.f;
+
 typedef void (*gemm_kern_t)(const float*, long, long, const float*, long, long, float*, long, int, int, int, int,
                             GemmEpi, int, int);
 static gemm_kern_t gemm_table[3][3] = {
@@ -250,7 +276,12 @@ int lctvqa_gemm_f32_ex(const float* A, long a_ms, long a_ks, const float* B, lon
   LCT_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_f32: bad shape %d %d %d", M, N, K);
   LCT_REQUIRE(act >= 0 && act <= 2, "gemm_f32: bad act %d", act);
   hipStream_t st = (hipStream_t)stream;
-  GemmEpi epi{bias, addend, ld_add, mask, ld_mask, mask_scale, act};
+  GemmEpi epi{nullptr, nullptr, 1.f, bias, addend, ld_add, mask, ld_mask, mask_scale, act};
+  if (relu_ab & 4) {      // fused fusion-head prologue requested through lctvqa_fusion_fc1 (operands stashed thread-locally)
+    epi.a2 = g_fuse_a2; epi.amask = g_fuse_amask; epi.ascale = g_fuse_ascale;
+    relu_ab &= 3;
+    LCT_REQUIRE(a_ks == 1, "fused fusion-head prologue needs a K-contiguous A operand");
+  }
   int tiles = cdiv(M, 128) * cdiv(N, 128);
   long need = lctvqa_gemm_workspace_bytes(M, N, K);
   int splits = need ? (int)(need / ((long)M * N * sizeof(float))) : 1;
@@ -291,6 +322,19 @@ int lctvqa_gemm_f32(const float* A, long a_ms, long a_ks, const float* B, long b
 }
 
 long lctvqa_colsum_scratch_elems(int M, int N) { return (long)colsum_splits(M, N) * N; }
+
+// Fusion head, first half (reference basic_vqa/models.py:96-100): one GEMM launch computes
+//   h1 = mask2*scale2 * tanh( [mask1*scale1 * tanh(img (.) qst)] . W1^T + b1 )
+// with the pointwise mul+tanh+dropout applied to the A operand as it is staged (never materialised).
+int lctvqa_fusion_fc1(const float* img, const float* qst, const uint8_t* mask1, float scale1, const float* w1, const float* b1,
+                      const uint8_t* mask2, float scale2, float* h1, int B, int E, int A, float* workspace, long workspace_bytes,
+                      void* stream) {
+  g_fuse_a2 = qst; g_fuse_amask = mask1; g_fuse_ascale = scale1;
+  int rc = lctvqa_gemm_f32_ex(img, E, 1, w1, E, 1, h1, A, B, A, E, b1, nullptr, 0, 2, mask2, A, scale2, workspace, workspace_bytes, 4,
+                              stream);
+  g_fuse_a2 = nullptr; g_fuse_amask = nullptr;
+  return rc;
+}
 
 int lctvqa_colsum_f32(const float* X, long ld, int M, int N, float* out, float* scratch, void* stream) {
   LCT_REQUIRE(M > 0 && N > 0 && scratch != nullptr, "colsum: bad args");

@@ -552,20 +552,36 @@ __global__ __launch_bounds__(256) void lstm_step_fused_kernel(const float* __res
   const int arow = min(b0 + j, B - 1);                 // clamp: rows >= B are computed but never stored
   const float* ap = h_prev + (long)arow * H;
   const int ngroups = H / 16;
-  for (int grp = wave; grp < ngroups; grp += 4) {
-    const int k0 = grp * 16;
+  const float* bp = w_hh + (long)(u0 + j) * H;
+  // register double buffer over 16-deep k groups: the loads of group n+1 are in flight under the MFMAs of group n
+  f32x4 A0[2], B0[2][4], A1[2], B1[2][4];
+  auto ld = [&](int grp, f32x4 (&A)[2], f32x4 (&Bf)[2][4]) {
 #pragma unroll
     for (int kk = 0; kk < 2; kk++) {
-      const int kc = k0 + (2 * kk + hh) * 4;
-      const f32x4 af = *(const f32x4*)(ap + kc);
-      f32x4 bf[4];
+      const int kc = grp * 16 + (2 * kk + hh) * 4;
+      A[kk] = *(const f32x4*)(ap + kc);
 #pragma unroll
-      for (int g = 0; g < 4; g++) bf[g] = *(const f32x4*)(w_hh + (long)(g * H + u0 + j) * H + kc);
+      for (int g = 0; g < 4; g++) Bf[kk][g] = *(const f32x4*)(bp + (long)g * H * H + kc);
+    }
+  };
+  auto mm = [&](const f32x4 (&A)[2], const f32x4 (&Bf)[2][4]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++)
 #pragma unroll
       for (int e = 0; e < 4; e++)
 #pragma unroll
-        for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[g][e], acc[g], 0, 0, 0);
-    }
+        for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[kk][e], Bf[kk][g][e], acc[g], 0, 0, 0);
+  };
+  int grp = wave;
+  if (grp < ngroups) ld(grp, A0, B0);
+  while (grp < ngroups) {
+    if (grp + 4 < ngroups) ld(grp + 4, A1, B1);
+    mm(A0, B0);
+    grp += 4;
+    if (grp >= ngroups) break;
+    if (grp + 4 < ngroups) ld(grp + 4, A0, B0);
+    mm(A1, B1);
+    grp += 4;
   }
 #pragma unroll
   for (int g = 0; g < 4; g++)
@@ -612,4 +628,93 @@ extern "C" int lctvqa_lstm_step_fused(const float* xp, const float* h_prev, cons
   hipLaunchKernelGGL(lstm_step_fused_kernel, dim3(cdiv(B, 32) * (H / 32)), dim3(256), lds, (hipStream_t)stream, xp, h_prev, c_prev, w_hh,
                      b_hh, gates, c_out, h_out, B, H);
   return lct_check_launch("lstm_step_fused");
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused BPTT step: dh_rec = dgates_t . W_hh  (the recurrent gradient into step t-1), immediately followed by
+// the cell backward of step t-1 in the epilogue (same (row, unit) tile owns everything it needs).
+// Workgroup = 32 rows x 32 units, K = 4H split over the 4 waves, partials meet in LDS.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_step_bwd_fused_kernel(const float* __restrict__ dg_t, const float* __restrict__ w_hh,
+                                                                  const float* __restrict__ dh_ext, const float* __restrict__ dc_next,
+                                                                  const float* __restrict__ gates_p, const float* __restrict__ c_pp,
+                                                                  const float* __restrict__ c_p, float* __restrict__ dg_p,
+                                                                  float* __restrict__ dc_prev, int B, int H) {
+  __shared__ float red[4][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  const int nut = H / 32;
+  const int ut = blockIdx.x % nut, bt = blockIdx.x / nut;
+  const int b0 = bt * 32, u0 = ut * 32;
+  const int K = 4 * H;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.f;
+  const int arow = min(b0 + j, B - 1);
+  const float* ap = dg_t + (long)arow * K;
+  // super-groups of 64 k (4 x 16): enough MFMA work (32 per super-group) to cover the L2 latency of the next one
+  const int nsg = K / 64;                               // K = 4H, H % 32 == 0  =>  K % 64 == 0
+  const float* bp = w_hh + u0 + j;
+  f32x4 A0[8], A1[8];
+  float B0[8][4], B1[8][4];
+  auto ld = [&](int sg, f32x4 (&A)[8], float (&Bf)[8][4]) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int kc = sg * 64 + (q >> 1) * 16 + (2 * (q & 1) + hh) * 4;
+      A[q] = *(const f32x4*)(ap + kc);
+#pragma unroll
+      for (int e = 0; e < 4; e++) Bf[q][e] = bp[(long)(kc + e) * H];
+    }
+  };
+  auto mm = [&](const f32x4 (&A)[8], const float (&Bf)[8][4]) {
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[q][e], Bf[q][e], acc, 0, 0, 0);
+  };
+  int sg = wave;
+  if (sg < nsg) ld(sg, A0, B0);
+  while (sg < nsg) {
+    if (sg + 4 < nsg) ld(sg + 4, A1, B1);
+    mm(A0, B0);
+    sg += 4;
+    if (sg >= nsg) break;
+    if (sg + 4 < nsg) ld(sg + 4, A0, B0);
+    mm(A1, B1);
+    sg += 4;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r++) red[wave][r][lane] = acc[r];
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 4; rr++) {
+    const int r = wave * 4 + rr;
+    const int row = b0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    const int u = u0 + j;
+    float dh = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+    if (row < B) {
+      const long o = (long)row * H + u, g0 = (long)row * 4 * H + u;
+      if (dh_ext) dh += dh_ext[o];
+      const float i = gates_p[g0], f = gates_p[g0 + H], g = gates_p[g0 + 2 * H], oo = gates_p[g0 + 3 * H];
+      const float tc = tanhf(c_p[o]);
+      const float dc = (dc_next ? dc_next[o] : 0.f) + dh * oo * (1.f - tc * tc);
+      dg_p[g0] = dc * g * i * (1.f - i);
+      dg_p[g0 + H] = dc * c_pp[o] * f * (1.f - f);
+      dg_p[g0 + 2 * H] = dc * i * (1.f - g * g);
+      dg_p[g0 + 3 * H] = dh * tc * oo * (1.f - oo);
+      dc_prev[o] = dc * f;
+    }
+  }
+}
+
+// dg_t: dgates of step t [B][4H]; gates_p / c_pp / c_p: activated gates, c_{t-2}... of step t-1 (c_pp = cell state entering
+// step t-1, c_p = cell state it produced); dh_ext: external dL/dh_{t-1} (may be NULL); dc_next: dL/dc_{t-1} from step t.
+extern "C" int lctvqa_lstm_step_bwd_fused(const float* dg_t, const float* w_hh, const float* dh_ext, const float* dc_next,
+                                          const float* gates_p, const float* c_pp, const float* c_p, float* dg_p, float* dc_prev,
+                                          int B, int H, void* stream) {
+  LCT_REQUIRE(lctvqa_lstm_step_fused_supported(B, H), "lstm_step_bwd_fused: need H %% 32 == 0 (got H=%d)", H);
+  LCT_REQUIRE(((uintptr_t)dg_t & 15) == 0, "lstm_step_bwd_fused: dgates must be 16-B aligned");
+  hipLaunchKernelGGL(lstm_step_bwd_fused_kernel, dim3(cdiv(B, 32) * (H / 32)), dim3(256), 0, (hipStream_t)stream, dg_t, w_hh, dh_ext,
+                     dc_next, gates_p, c_pp, c_p, dg_p, dc_prev, B, H);
+  return lct_check_launch("lstm_step_bwd_fused");
 }

@@ -252,12 +252,18 @@ class LSTMFn(torch.autograd.Function):
         dh_rec = _chk(dhT) if dhT is not None else None
         dc = _chk(dcT) if dcT is not None else None
         dgates = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
+        fused = bool(lib.query('lstm_step_fused_supported', B, H))
         for t in range(T - 1, -1, -1):
             dc_prev = torch.empty((B, H), dtype=torch.float32, device=dev)
-            lib('lstm_cell_bwd', dh_rec, dout[t] if dout is not None else None, dc, gates[t],
-                c_all[t], c_all[t + 1], dgates[t], dc_prev, B, H)
+            if fused and t < T - 1:
+                # dh_rec = dgates[t+1] . W_hh and the cell backward of step t in one launch
+                lib('lstm_step_bwd_fused', dgates[t + 1], w_hh, dout[t] if dout is not None else None, dc, gates[t],
+                    c_all[t], c_all[t + 1], dgates[t], dc_prev, B, H)
+            else:
+                lib('lstm_cell_bwd', dh_rec, dout[t] if dout is not None else None, dc, gates[t],
+                    c_all[t], c_all[t + 1], dgates[t], dc_prev, B, H)
             dc = dc_prev
-            if t > 0 or ctx.has_init:
+            if (not fused and t > 0) or (t == 0 and ctx.has_init):
                 dh_rec = linear_bwd_input(dgates[t], w_hh)
         dg2 = dgates.reshape(T * B, 4 * H)
         ni = ctx.needs_input_grad
@@ -358,6 +364,45 @@ class MulTanhDropFn(torch.autograd.Function):
         db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
         lib('mul_tanh_drop_bwd', dz, a, b, t, mask, float(ctx.scale), da, db, a.numel())
         return da, db, None, None
+
+
+class FusionFc1Fn(torch.autograd.Function):
+    """Fusion head, first half (reference basic_vqa/models.py:96-100) as ONE GEMM launch:
+    h1 = drop2(tanh(fc1(drop1(tanh(img * qst))))): the pointwise mul + tanh + dropout is applied to the GEMM's A
+    operand while it is staged (never written to HBM).  Backward re-materialises it once for the weight gradient."""
+
+    @staticmethod
+    def forward(ctx, img, qst, W, b, mask1, scale1, mask2, scale2):
+        img, qst, W = _chk(img), _chk(qst), _chk(W)
+        B, E = img.shape
+        A = W.shape[0]
+        h1 = torch.empty((B, A), dtype=torch.float32, device=img.device)
+        need = lib.query('gemm_workspace_bytes', B, A, E)
+        ws = _workspace(need, img.device) if need else None
+        lib('fusion_fc1', img, qst, mask1, float(scale1), W, b, mask2, float(scale2), h1, B, E, A, ws, need)
+        ctx.save_for_backward(img, qst, W, h1, mask1, mask2)
+        ctx.scales = (float(scale1), float(scale2))
+        return h1
+
+    @staticmethod
+    def backward(ctx, dy):
+        img, qst, W, h1, mask1, mask2 = ctx.saved_tensors
+        s1, s2 = ctx.scales
+        dy = _chk(dy)
+        dpre = torch.empty_like(dy)
+        lib('act_bwd', dy, h1, mask2, s2, dpre, dy.numel(), ACT_TANH)
+        t = torch.empty_like(img)
+        z = torch.empty_like(img)
+        lib('mul_tanh_drop_fwd', img, qst, mask1, s1, t, z, img.numel())
+        dW = linear_bwd_weight(dpre, z) if ctx.needs_input_grad[2] else None
+        db = colsum(dpre) if ctx.needs_input_grad[3] else None
+        da = dq = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dz = linear_bwd_input(dpre, W)
+            da = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+            dq = torch.empty_like(qst) if ctx.needs_input_grad[1] else None
+            lib('mul_tanh_drop_bwd', dz, img, qst, t, mask1, s1, da, dq, img.numel())
+        return da, dq, dW, db, None, None, None, None
 
 
 class XentFn(torch.autograd.Function):
