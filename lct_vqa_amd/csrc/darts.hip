@@ -71,35 +71,50 @@ __global__ void dwconv_bwd_input_kernel(const float* __restrict__ dy, const floa
     dx[o] = a;
   }
 }
-// partial[blk][tap*C + c] = sum over the block's output pixels of dy[p][c] * relu?(x[p shifted by tap][c])
+// partial[blk][tap*C + c] = sum over the block's output pixels of dy[p][c] * relu?(x[p shifted by tap][c]).
+// thread = (weight index wi = t % NWc, pixel lane t / NWc): all 256 threads stream pixels, lanes meet in LDS.
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 float* __restrict__ part, int B, int H, int W, int C, int K,
                                                                 int s, int p, int d, int Ho, int Wo, int relu_in, long per_blk) {
+  __shared__ float red[256];
   const int KK = K * K, NW = KK * C;
   const long P = (long)B * Ho * Wo;
   const long q0 = blockIdx.x * per_blk, q1 = min(P, q0 + per_blk);
-  for (int t = threadIdx.x; t < NW; t += blockDim.x) {
-    const int c = t % C, tap = t / C, ky = tap / K, kx = tap % K;
+  for (int w0 = 0; w0 < NW; w0 += 256) {
+    const int NWc = min(256, NW - w0);            // weights handled in this pass
+    const int PL = 256 / NWc;                     // pixel lanes
+    const int wi = threadIdx.x % NWc, pl = threadIdx.x / NWc;
     float a = 0.f;
-    for (long q = q0; q < q1; q++) {
-      int ox = q % Wo; int oy = (q / Wo) % Ho; int n = q / ((long)Wo * Ho);
-      int iy = oy * s - p + ky * d, ix = ox * s - p + kx * d;
-      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-      float v = x[(((long)n * H + iy) * W + ix) * C + c];
-      if (relu_in) v = fmaxf(v, 0.f);
-      a = fmaf(dy[q * C + c], v, a);
+    if (pl < PL) {
+      const int t = w0 + wi, c = t % C, tap = t / C, ky = tap / K, kx = tap % K;
+      for (long q = q0 + pl; q < q1; q += PL) {
+        int ox = q % Wo; int oy = (q / Wo) % Ho; int n = q / ((long)Wo * Ho);
+        int iy = oy * s - p + ky * d, ix = ox * s - p + kx * d;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        float v = x[(((long)n * H + iy) * W + ix) * C + c];
+        if (relu_in) v = fmaxf(v, 0.f);
+        a = fmaf(dy[q * C + c], v, a);
+      }
     }
-    part[(long)blockIdx.x * NW + t] = a;
+    __syncthreads();
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < NWc) {
+      float sum = 0.f;
+      for (int l = 0; l < PL; l++) sum += red[l * NWc + threadIdx.x];
+      part[(long)blockIdx.x * NW + w0 + threadIdx.x] = sum;
+    }
   }
 }
-// dw[c][ky][kx] = sum_blk part[blk][tap*C + c]
-__global__ void dwconv_bwd_weight_finish_kernel(const float* __restrict__ part, int nblk, int C, int KK, float* __restrict__ dw) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= C * KK) return;
+// dw[c][ky][kx] = sum_blk part[blk][tap*C + c]   (one wave per weight, strided over the partials)
+__global__ __launch_bounds__(64) void dwconv_bwd_weight_finish_kernel(const float* __restrict__ part, int nblk, int C, int KK,
+                                                                      float* __restrict__ dw) {
+  const int t = blockIdx.x;
   const int c = t % C, tap = t / C;
   float a = 0.f;
-  for (int b = 0; b < nblk; b++) a += part[(long)b * C * KK + t];
-  dw[c * KK + tap] = a;
+  for (int b = threadIdx.x; b < nblk; b += 64) a += part[(long)b * C * KK + t];
+  a = wave_sum(a);
+  if (threadIdx.x == 0) dw[c * KK + tap] = a;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -214,14 +229,20 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     part[((long)blockIdx.x * 2 + 1) * C + threadIdx.x] = tb;
   }
 }
-// mean/invstd (+ running stats update: momentum m, unbiased variance)
-__global__ void bn_stats_finish_kernel(const double* __restrict__ part, int nblk, int C, long P, float eps, float momentum,
-                                       float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
-                                       float* __restrict__ run_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// mean/invstd (+ running stats update: momentum m, unbiased variance); one wave per channel
+__global__ __launch_bounds__(64) void bn_stats_finish_kernel(const double* __restrict__ part, int nblk, int C, long P, float eps,
+                                                             float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                                             float* __restrict__ run_mean, float* __restrict__ run_var) {
+  const int c = blockIdx.x;
   double a = 0.0, b = 0.0;
-  for (int k = 0; k < nblk; k++) { a += part[((long)k * 2) * C + c]; b += part[((long)k * 2 + 1) * C + c]; }
+  for (int k = threadIdx.x; k < nblk; k += 64) { a += part[((long)k * 2) * C + c]; b += part[((long)k * 2 + 1) * C + c]; }
+  a = wave_sum_d(a); b = wave_sum_d(b);
+  if (threadIdx.x != 0) return;
   const double m = a / (double)P;
   double var = b / (double)P - m * m;
   if (var < 0.0) var = 0.0;
@@ -274,13 +295,13 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     part[((long)blockIdx.x * 2 + 1) * C + threadIdx.x] = tb;
   }
 }
-__global__ void bn_bwd_finish_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ sum_dy,
-                                     float* __restrict__ sum_dy_xhat) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void bn_bwd_finish_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ sum_dy,
+                                                           float* __restrict__ sum_dy_xhat) {
+  const int c = blockIdx.x;
   double a = 0.0, b = 0.0;
-  for (int k = 0; k < nblk; k++) { a += part[((long)k * 2) * C + c]; b += part[((long)k * 2 + 1) * C + c]; }
-  sum_dy[c] = (float)a; sum_dy_xhat[c] = (float)b;
+  for (int k = threadIdx.x; k < nblk; k += 64) { a += part[((long)k * 2) * C + c]; b += part[((long)k * 2 + 1) * C + c]; }
+  a = wave_sum_d(a); b = wave_sum_d(b);
+  if (threadIdx.x == 0) { sum_dy[c] = (float)a; sum_dy_xhat[c] = (float)b; }
 }
 // training: dx = g*invstd*(dy - sum_dy/P - xhat*sum_dy_xhat/P);  eval: dx = g*invstd*dy
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
@@ -409,15 +430,19 @@ __global__ __launch_bounds__(256) void mixed_combine_bwd_scalars_kernel(const fl
   __syncthreads();
   if (threadIdx.x < 9) part[(long)blockIdx.x * 9 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
 }
-// dw[k] = beta * S_k ;  dbeta = sum_k w_k S_k + S_8
-__global__ void mixed_combine_bwd_scalars_finish_kernel(const float* __restrict__ part, int nblk, int nbr,
+// dw[k] = beta * S_k ;  dbeta = sum_k w_k S_k + S_8   (one wave, strided over the partials)
+__global__ __launch_bounds__(64) void mixed_combine_bwd_scalars_finish_kernel(const float* __restrict__ part, int nblk, int nbr,
                                                         const float* __restrict__ wts, const float* __restrict__ beta,
                                                         float* __restrict__ dw, float* __restrict__ dbeta) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double S[9];
+#pragma unroll
   for (int k = 0; k < 9; k++) S[k] = 0.0;
-  for (int b = 0; b < nblk; b++)
+  for (int b = threadIdx.x; b < nblk; b += 64)
+#pragma unroll
     for (int k = 0; k < 9; k++) S[k] += part[(long)b * 9 + k];
+#pragma unroll
+  for (int k = 0; k < 9; k++) S[k] = wave_sum_d(S[k]);
+  if (threadIdx.x != 0) return;
   double db = S[8];
   for (int k = 0; k < nbr; k++) { dw[k] = (float)(beta[0] * S[k]); db += wts[k] * S[k]; }
   dbeta[0] = (float)db;
@@ -481,8 +506,7 @@ int lctvqa_dwconv_bwd_weight(const float* dy, const float* x, float* dw, float* 
                      pad, dil, Ho, Wo, relu_in, per);
   int rc = lct_check_launch("dwconv_bwd_weight");
   if (rc) return rc;
-  hipLaunchKernelGGL(dwconv_bwd_weight_finish_kernel, dim3(cdiv(C * K * K, 256)), dim3(256), 0, (hipStream_t)stream, scratch, nb, C,
-                     K * K, dw);
+  hipLaunchKernelGGL(dwconv_bwd_weight_finish_kernel, dim3(C * K * K), dim3(64), 0, (hipStream_t)stream, scratch, nb, C, K * K, dw);
   return lct_check_launch("dwconv_bwd_weight_finish");
 }
 
@@ -531,8 +555,8 @@ int lctvqa_batchnorm_fwd(const float* x, long ldx, float* y, long ldy, long P, i
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(256), 0, st, x, ldx, P, C, per, scratch);
     int rc = lct_check_launch("bn_stats_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, scratch, nb, C, P, eps, momentum, mean, invstd,
-                       run_mean, run_var);
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(C), dim3(64), 0, st, scratch, nb, C, P, eps, momentum, mean, invstd, run_mean,
+                       run_var);
   } else {
     LCT_REQUIRE(run_mean && run_var, "batchnorm eval: running statistics required");
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, run_mean, run_var, eps, C, mean, invstd);
@@ -553,7 +577,7 @@ int lctvqa_batchnorm_bwd(const float* dy, long lddy, const float* x, long ldx, c
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(256), 0, st, dy, lddy, x, ldx, mean, invstd, P, C, per, scratch);
   int rc = lct_check_launch("bn_bwd_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, scratch, nb, C, sums, sums + C);
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(C), dim3(64), 0, st, scratch, nb, C, sums, sums + C);
   rc = lct_check_launch("bn_bwd_finish");
   if (rc) return rc;
   if (dgamma) {

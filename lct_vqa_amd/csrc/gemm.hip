@@ -261,7 +261,8 @@ long lctvqa_gemm_workspace_bytes(int M, int N, int K) {
     splits = 512 / tiles;
     int maxs = K / 64;
     if (splits > maxs) splits = maxs;
-    if (splits > 32) splits = 32;
+    int cap = K >= 65536 ? 512 : 32;         // pixel-reduction GEMMs (1x1-conv weight gradients: K = B*H*W) get deep splits
+    if (splits > cap) splits = cap;
     if (splits < 1) splits = 1;
   }
   return splits > 1 ? (long)splits * M * N * (long)sizeof(float) : 0;
