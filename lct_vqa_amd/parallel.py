@@ -93,11 +93,19 @@ def init_distributed():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # rehearsal on a 1-GPU box: every rank shares device 0 and the collective goes through gloo (RCCL refuses
+    # two ranks on one device); exercises hooks / buckets / barriers, not the xGMI transport
+    backend = os.environ.get('LCTVQA_DIST_BACKEND', 'nccl')
+    if os.environ.get('LCTVQA_REHEARSE_ONE_GPU') == '1':
+        local, backend = 0, 'gloo'
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, world, local
