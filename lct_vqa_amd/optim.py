@@ -45,6 +45,38 @@ class FusedAdam(torch.optim.Optimizer):
         self.flat = dict(params=ps, p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), step=0,
                          scratch=torch.empty(1024, dtype=torch.float32, device=dev),
                          norm=torch.zeros(1, dtype=torch.float32, device=dev))
+        self._publish_state()
+
+    def _publish_state(self):
+        """Expose the arena's moments in torch.optim.Adam's per-parameter state format ('step', 'exp_avg',
+        'exp_avg_sq' as VIEWS of the flat buffers) so that state_dict() / checkpoints (reference
+        basic_vqa/experiment.py:398-417: {'ef_opt': optimizer.state_dict(), ...}) are wire-compatible."""
+        f, o = self.flat, 0
+        for p in f['params']:
+            k = p.numel()
+            self.state[p] = {'step': torch.tensor(float(f['step'])), 'exp_avg': f['m'][o:o + k].view_as(p.data),
+                             'exp_avg_sq': f['v'][o:o + k].view_as(p.data)}
+            o += k
+
+    def load_state_dict(self, state_dict):
+        """Accepts a torch.optim.Adam (or FusedAdam) state_dict; in flat mode the moments are copied into the arena."""
+        import copy
+        state_dict = copy.deepcopy(state_dict)        # never alias (and later mutate in place) the caller's tensors
+        if self.flat is None:
+            return super().load_state_dict(state_dict)
+        f = self.flat
+        super().load_state_dict(state_dict)          # fills self.state[p] with (new) tensors
+        o, step = 0, 0
+        for p in f['params']:
+            k = p.numel()
+            st = self.state.get(p, {})
+            if 'exp_avg' in st:
+                f['m'][o:o + k].copy_(st['exp_avg'].reshape(-1))
+                f['v'][o:o + k].copy_(st['exp_avg_sq'].reshape(-1))
+                step = max(step, int(float(st['step'])))
+            o += k
+        f['step'] = step
+        self._publish_state()
 
     @property
     def flat_grad(self):
@@ -73,6 +105,8 @@ class FusedAdam(torch.optim.Optimizer):
         if self.flat is not None:
             f, g = self.flat, self.param_groups[0]
             f['step'] += 1
+            for p in f['params']:
+                self.state[p]['step'] = torch.tensor(float(f['step']))
             norm = self.grad_norm() if max_grad_norm is not None else None
             lib('adam_step', f['p'], f['g'], f['m'], f['v'], f['p'].numel(), norm,
                 float(max_grad_norm or 0.0), float(g['lr']), float(g['betas'][0]), float(g['betas'][1]),
@@ -89,7 +123,7 @@ class FusedAdam(torch.optim.Optimizer):
                     st['step'] = 0
                     st['exp_avg'] = torch.zeros_like(p)
                     st['exp_avg_sq'] = torch.zeros_like(p)
-                st['step'] += 1
+                st['step'] = st['step'] + 1
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if not p.is_contiguous():
                     raise RuntimeError('FusedAdam: non-contiguous parameter')

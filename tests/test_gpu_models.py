@@ -135,3 +135,42 @@ def test_ef_small_trainable_vgg_against_reference_goldens(pkg):
             rs, ra = fx['vgg_grad_checksums'][k]
             assert abs(a - ra) <= 2e-3 * max(ra, 1e-12), (k, a, ra)
             assert abs(s - rs) <= 2e-3 * max(ra, 1e-12), (k, s, rs)
+
+
+def test_checkpoint_wire_compat_with_torch_adam(pkg, tmp_path):
+    """Reference checkpoints (experiment.py:398-417) hold {'w_model': state_dict, 'w_opt': Adam.state_dict(), ...}.
+    A torch.optim.Adam state written by the reference must resume in FusedAdam (per-tensor and flat arena), and a
+    FusedAdam checkpoint must load back into torch.optim.Adam."""
+    ops, models, _, _ = pkg
+    from lct_vqa_amd.optim import FusedAdam
+    fx = load('w_small.pt')
+    m = _build(models.VqaModel, fx).eval()
+    img, qst, lab = fx['image'].to(DEV), fx['question'].to(DEV), fx['label'].to(DEV)
+    ref_opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    for _ in range(2):
+        ref_opt.zero_grad()
+        ops.cross_entropy(m(img, qst), lab).backward()
+        ref_opt.step()
+    ck = {'w_model': m.state_dict(), 'w_opt': ref_opt.state_dict()}
+    torch.save(ck, tmp_path / 'w_model.pt')
+    ck = torch.load(tmp_path / 'w_model.pt', map_location=DEV, weights_only=False)
+    results = []
+    for flatten in (False, True):
+        m2 = _build(models.VqaModel, fx).eval()
+        m2.load_state_dict(ck['w_model'])
+        opt = FusedAdam(list(m2.parameters()), lr=1e-3, flatten=flatten)
+        opt.load_state_dict(ck['w_opt'])
+        opt.zero_grad()
+        ops.cross_entropy(m2(img, qst), lab).backward()
+        opt.step()
+        results.append(m2.fc2.weight.detach().clone())
+        sd = opt.state_dict()
+        assert len(sd['state']) >= 13 and all(set(v) >= {'step', 'exp_avg', 'exp_avg_sq'} for v in sd['state'].values())
+    # continue the torch optimizer one more step: all three must agree
+    ref_opt.zero_grad()
+    ops.cross_entropy(m(img, qst), lab).backward()
+    ref_opt.step()
+    for r in results:
+        assert rel_err(r, m.fc2.weight) < 1e-5
+    t_opt = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    t_opt.load_state_dict(sd)                      # FusedAdam(flat) -> torch.optim.Adam
