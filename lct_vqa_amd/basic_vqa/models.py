@@ -23,9 +23,15 @@ class ImgEncoder(nn.Module):
         self.model = model
         self.fc = nn.Linear(in_features, embed_size)
 
-    def forward(self, image):
+    def trunk(self, image):
+        """The frozen part only (VGG19 minus its last fc, under no_grad): [B,4096].  It does not depend on any
+        trainable parameter, so a caller may run it for batch i+1 on a second HIP stream while batch i's
+        head/backward/optimizer runs (bench.py)."""
         with torch.no_grad():
-            img_feature = self.model(image)
+            return self.model(image)
+
+    def forward(self, image, trunk_feature=None):
+        img_feature = self.trunk(image) if trunk_feature is None else trunk_feature
         img_feature = ops.linear(img_feature, self.fc.weight, self.fc.bias)
         return ops.L2NormFn.apply(img_feature)
 
@@ -84,8 +90,8 @@ class VqaModel(nn.Module):
         z = ops.FusionFc1Fn.apply(img_feature, qst_feature, self.fc1.weight, self.fc1.bias, m1, scale, m2, scale)
         return ops.linear(z, self.fc2.weight, self.fc2.bias)
 
-    def forward(self, img, qst):
-        img_feature = self.img_encoder(img)
+    def forward(self, img, qst, trunk_feature=None):
+        img_feature = self.img_encoder(img, trunk_feature)
         qst_feature = self.qst_encoder(qst)
         return self._head(img_feature, qst_feature)
 

@@ -519,7 +519,7 @@ int lctvqa_conv3x3_first_nchw(const float* x_nchw, const float* w_oihw, const fl
 }
 
 int lctvqa_maxpool2x2_nhwc(const float* x, float* y, int B, int H, int W, int C, void* stream) {
-  LCT_REQUIRE(C % 4 == 0 && !(H & 1) && !(W & 1), "maxpool2x2: need C%%4==0 and even H,W");
+  LCT_REQUIRE(C % 4 == 0 && H >= 2 && W >= 2, "maxpool2x2: need C%%4==0 and H,W >= 2 (odd sizes floor like nn.MaxPool2d)");
   long t = (long)B * (H / 2) * (W / 2) * (C / 4);
   int b = (int)((t + 255) / 256);
   if (b > 8192) b = 8192;

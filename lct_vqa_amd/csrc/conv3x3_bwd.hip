@@ -312,7 +312,7 @@ int lctvqa_conv3x3_pack_weights_dgrad(const float* w_oihw, float* w_packed, int 
 }
 
 int lctvqa_relu_pool_bwd_nhwc(const float* dout, const float* act, float* dz, int B, int H, int W, int C, int pool, void* stream) {
-  LCT_REQUIRE(C % 4 == 0 && (!pool || (!(H & 1) && !(W & 1))), "relu_pool_bwd: need C%%4==0 (and even H,W with pool)");
+  LCT_REQUIRE(C % 4 == 0, "relu_pool_bwd: need C%%4==0");   // odd H/W with pool: the caller pre-zeroes dz (uncovered last row/col)
   long t = pool ? (long)B * (H / 2) * (W / 2) * (C / 4) : (long)B * H * W * (C / 4);
   int b = (int)((t + 255) / 256);
   if (b > 16384) b = 16384;

@@ -635,7 +635,8 @@ class VggFeaturesFn(torch.autograd.Function):
             act = acts[li]
             w, b = params[2 * li], params[2 * li + 1]
             Cout, Cin = w.shape[0], w.shape[1]
-            dz = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
+            odd = pool and (H % 2 or W % 2)            # floor pooling leaves the last row/col without gradient
+            dz = (torch.zeros if odd else torch.empty)((B, H, W, Cout), dtype=torch.float32, device=dev)
             lib('relu_pool_bwd_nhwc', d, act, dz, B, H, W, Cout, pool)
             if li == 0:
                 scratch = torch.empty(lib.query('conv3x3_first_wgrad_scratch_elems', B, H, W, Cout), dtype=torch.float32, device=dev)

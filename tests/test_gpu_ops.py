@@ -253,14 +253,16 @@ def test_conv3x3_wgrad_dgrad(ops, hip_lib, B, H, W, Cin, Cout):
     assert rel_err(dx.permute(0, 3, 1, 2), gx) < 5e-5
 
 
-def test_trainable_vgg_trunk_backward(ops):
-    """vgg19 trunk with gradients (reference models_lct.py:62-63) at 32x32: every parameter gradient vs torch."""
+@pytest.mark.parametrize('size', [32, 40])
+def test_trainable_vgg_trunk_backward(ops, size):
+    """vgg19 trunk with gradients (reference models_lct.py:62-63) at 32x32 and 40x40 (odd intermediate maps: floor
+    pooling): every parameter gradient vs torch."""
     from lct_vqa_amd import vgg
     torch.manual_seed(8)
     m = vgg.vgg19()
     m.classifier = torch.nn.Sequential(*list(m.classifier.children())[:-1])
     m.eval()
-    x = torch.randn(2, 3, 32, 32)
+    x = torch.randn(2, 3, size, size)
     # torch reference of the same module structure
     h = x
     for mod in m.features:
