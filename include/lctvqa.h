@@ -178,6 +178,11 @@ int lctvqa_mixed_combine_bwd_scalars(const float* dout, long ldd, const float* c
                                      const float* beta, const float* x, int B, int Ho, int Wo, int C, int reduce, float* dw,
                                      float* dbeta, float* scratch, void* stream);
 
+/* ---- input pipeline, device side (data_loader_v2.py:53-55,82-86: ToTensor + Normalize done per sample on the host):
+ *      uint8 HWC rows of the image store -> fp32 NCHW, y = (x/255 - mean[c]) / std[c] ---------------------------- */
+int lctvqa_image_u8_nhwc_to_f32_nchw(const uint8_t* x, float* y, int B, int H, int W, float m0, float m1, float m2,
+                                     float s0, float s1, float s2, void* stream);
+
 /* ---- optimiser on a flat parameter arena: clip_grad_norm_(5) + Adam (experiment.py:226-227,
  *      model_factory.py:20-21) and the architects' vector ops (architect_lct.py:112-116) ---- */
 int lctvqa_grad_norm(const float* g, long n, float* scratch /* >=1024 floats */, float* total_norm_out, void* stream);

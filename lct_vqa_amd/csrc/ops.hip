@@ -718,3 +718,28 @@ extern "C" int lctvqa_lstm_step_bwd_fused(const float* dg_t, const float* w_hh, 
                      dc_next, gates_p, c_pp, c_p, dg_p, dc_prev, B, H);
   return lct_check_launch("lstm_step_bwd_fused");
 }
+
+// ------------------------------------------------------------------------------------------
+// Input pipeline, device side (reference basic_vqa/data_loader_v2.py:53-55,82-86: PIL fromarray -> ToTensor ->
+// Normalize(mean,std) per sample on the host): the uint8 HWC image store rows are copied to HBM as they are
+// (3 B/pixel over PCIe instead of 12) and converted here:  y[n][c][h][w] = (x[n][h][w][c]/255 - mean[c]) / std[c]
+// ------------------------------------------------------------------------------------------
+__global__ void image_u8_to_f32_nchw_kernel(const uint8_t* __restrict__ x, float* __restrict__ y, int B, int H, int W, float m0,
+                                            float m1, float m2, float s0, float s1, float s2) {
+  const long HW = (long)H * W, total = (long)B * HW;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const long n = o / HW, p = o % HW;
+    const uint8_t* px = x + o * 3;
+    float* dst = y + n * 3 * HW + p;
+    dst[0] = ((float)px[0] * (1.f / 255.f) - m0) / s0;
+    dst[HW] = ((float)px[1] * (1.f / 255.f) - m1) / s1;
+    dst[2 * HW] = ((float)px[2] * (1.f / 255.f) - m2) / s2;
+  }
+}
+extern "C" int lctvqa_image_u8_nhwc_to_f32_nchw(const uint8_t* x, float* y, int B, int H, int W, float m0, float m1, float m2,
+                                                float s0, float s1, float s2, void* stream) {
+  LCT_REQUIRE(B > 0 && H > 0 && W > 0 && s0 != 0.f && s1 != 0.f && s2 != 0.f, "image_u8_to_f32: bad args");
+  hipLaunchKernelGGL(image_u8_to_f32_nchw_kernel, dim3(ew_blocks((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W,
+                     m0, m1, m2, s0, s1, s2);
+  return lct_check_launch("image_u8_to_f32_nchw");
+}
