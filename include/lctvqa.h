@@ -110,6 +110,12 @@ int lctvqa_lstm_step_bwd_fused(const float* dg_t, const float* w_hh, const float
                                int B, int H, void* stream);
 int lctvqa_lstm_cell_bwd(const float* dh_rec, const float* dh_ext, const float* dc_next, const float* gates,
                          const float* c_prev, const float* c_cur, float* dgates, float* dc_prev, int B, int H, void* stream);
+/* GRU cell (nn.GRU, gates r,z,n): the "LSTM/GRU" question-encoder variant of BASELINE.json (not in the reference;
+ * oracle = torch.nn.GRU).  xp/hp: [B][3H] projections incl. their biases; saved [B][4H] = r,z,n,hp_n */
+int lctvqa_gru_cell_fwd(const float* xp, const float* hp, const float* h_prev, float* saved, float* h_out, int B, int H,
+                        void* stream);
+int lctvqa_gru_cell_bwd(const float* dh_rec, const float* dh_ext, const float* saved, const float* h_prev, float* dxp,
+                        float* dhp, float* dh_carry, int B, int H, void* stream);
 /* tanh(cat(h,c)) of models.py:62-65 (num_layers = 1) and its backward */
 int lctvqa_cat_tanh_fwd(const float* h, const float* c, float* out, int B, int H, void* stream);
 int lctvqa_cat_tanh_bwd(const float* dy, const float* y, float* dh, float* dc, int B, int H, void* stream);

@@ -743,3 +743,55 @@ extern "C" int lctvqa_image_u8_nhwc_to_f32_nchw(const uint8_t* x, float* y, int 
                      m0, m1, m2, s0, s1, s2);
   return lct_check_launch("image_u8_to_f32_nchw");
 }
+
+// ------------------------------------------------------------------------------------------
+// GRU cell (nn.GRU gate order r,z,n) -- the "LSTM/GRU question encoder" variant named by BASELINE.json
+// (not present in the reference; oracle = torch.nn.GRU):
+//   r = s(xp_r + hp_r)  z = s(xp_z + hp_z)  n = tanh(xp_n + r * hp_n)  h' = (1-z)*n + z*h
+// xp = x.W_ih^T + b_ih, hp = h.W_hh^T + b_hh, each [B][3H].  saved[b][4H] = r, z, n, hp_n for the backward.
+// ------------------------------------------------------------------------------------------
+__global__ void gru_cell_fwd_kernel(const float* __restrict__ xp, const float* __restrict__ hp, const float* __restrict__ h_prev,
+                                    float* __restrict__ saved, float* __restrict__ h_out, int B, int H) {
+  long total = (long)B * H;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    int u = o % H; long b = o / H;
+    long g0 = b * 3 * H + u, s0 = b * 4 * H + u;
+    float r = sigmoidf_(xp[g0] + hp[g0]);
+    float z = sigmoidf_(xp[g0 + H] + hp[g0 + H]);
+    float hn = hp[g0 + 2 * H];
+    float n = tanhf(xp[g0 + 2 * H] + r * hn);
+    saved[s0] = r; saved[s0 + H] = z; saved[s0 + 2 * H] = n; saved[s0 + 3 * H] = hn;
+    h_out[o] = (1.f - z) * n + z * h_prev[o];
+  }
+}
+// dh = dh_rec + dh_ext;  writes dxp [B][3H], dhp [B][3H] and dh_carry = dh * z (the direct path to h_prev)
+__global__ void gru_cell_bwd_kernel(const float* __restrict__ dh_rec, const float* __restrict__ dh_ext,
+                                    const float* __restrict__ saved, const float* __restrict__ h_prev, float* __restrict__ dxp,
+                                    float* __restrict__ dhp, float* __restrict__ dh_carry, int B, int H) {
+  long total = (long)B * H;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    int u = o % H; long b = o / H;
+    long g0 = b * 3 * H + u, s0 = b * 4 * H + u;
+    float r = saved[s0], z = saved[s0 + H], n = saved[s0 + 2 * H], hn = saved[s0 + 3 * H];
+    float dh = (dh_rec ? dh_rec[o] : 0.f) + (dh_ext ? dh_ext[o] : 0.f);
+    float dn = dh * (1.f - z) * (1.f - n * n);
+    float dz = dh * (h_prev[o] - n) * z * (1.f - z);
+    float dr = dn * hn * r * (1.f - r);
+    dxp[g0] = dr; dxp[g0 + H] = dz; dxp[g0 + 2 * H] = dn;
+    dhp[g0] = dr; dhp[g0 + H] = dz; dhp[g0 + 2 * H] = dn * r;
+    dh_carry[o] = dh * z;
+  }
+}
+extern "C" int lctvqa_gru_cell_fwd(const float* xp, const float* hp, const float* h_prev, float* saved, float* h_out, int B, int H,
+                                   void* stream) {
+  LCT_REQUIRE(B > 0 && H > 0, "gru_cell_fwd: bad shape");
+  hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3(ew_blocks((long)B * H)), dim3(256), 0, (hipStream_t)stream, xp, hp, h_prev, saved, h_out, B, H);
+  return lct_check_launch("gru_cell_fwd");
+}
+extern "C" int lctvqa_gru_cell_bwd(const float* dh_rec, const float* dh_ext, const float* saved, const float* h_prev, float* dxp,
+                                   float* dhp, float* dh_carry, int B, int H, void* stream) {
+  LCT_REQUIRE(B > 0 && H > 0, "gru_cell_bwd: bad shape");
+  hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(ew_blocks((long)B * H)), dim3(256), 0, (hipStream_t)stream, dh_rec, dh_ext, saved, h_prev,
+                     dxp, dhp, dh_carry, B, H);
+  return lct_check_launch("gru_cell_bwd");
+}

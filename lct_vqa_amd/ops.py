@@ -280,6 +280,62 @@ def lstm(x, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None):
     return LSTMFn.apply(x, w_ih, w_hh, b_ih, b_hh, h0, c0)
 
 
+class GRUFn(torch.autograd.Function):
+    """Single-layer nn.GRU over [T,B,I] (gate order r,z,n): the GRU question-encoder variant named by BASELINE.json
+    (the reference itself only has nn.LSTM).  Returns (out [T,B,H], h_T [B,H])."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h0):
+        ctx.set_materialize_grads(False)
+        x, w_ih, w_hh = _chk(x), _chk(w_ih), _chk(w_hh)
+        T, B, I = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        xp = linear_fwd(x.reshape(T * B, I), w_ih, b_ih).reshape(T, B, 3 * H)
+        saved = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
+        h_all = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
+        if h0 is None:
+            h_all[0].zero_()
+        else:
+            h_all[0].copy_(h0.reshape(B, H))
+        hp = torch.empty((B, 3 * H), dtype=torch.float32, device=dev)
+        for t in range(T):
+            linear_fwd(h_all[t], w_hh, b_hh, out=hp)
+            lib('gru_cell_fwd', xp[t], hp, h_all[t], saved[t], h_all[t + 1], B, H)
+        ctx.save_for_backward(x, w_ih, w_hh, saved, h_all)
+        ctx.has_init = h0 is not None
+        return h_all[1:], h_all[T].clone()
+
+    @staticmethod
+    def backward(ctx, dout, dhT):
+        x, w_ih, w_hh, saved, h_all = ctx.saved_tensors
+        T, B, I = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        dout = _chk(dout) if dout is not None else None
+        dh = _chk(dhT) if dhT is not None else None
+        dxp = torch.empty((T, B, 3 * H), dtype=torch.float32, device=dev)
+        dhp = torch.empty((T, B, 3 * H), dtype=torch.float32, device=dev)
+        for t in range(T - 1, -1, -1):
+            carry = torch.empty((B, H), dtype=torch.float32, device=dev)
+            lib('gru_cell_bwd', dh, dout[t] if dout is not None else None, saved[t], h_all[t], dxp[t], dhp[t], carry, B, H)
+            if t > 0 or ctx.has_init:
+                dh = gemm(dhp[t], 3 * H, 1, w_hh, 1, H, B, H, 3 * H, addend=carry)     # dhp . W_hh + dh*z
+        ni = ctx.needs_input_grad
+        dxp2, dhp2 = dxp.reshape(T * B, 3 * H), dhp.reshape(T * B, 3 * H)
+        dx = linear_bwd_input(dxp2, w_ih).reshape(T, B, I) if ni[0] else None
+        dw_ih = linear_bwd_weight(dxp2, x.reshape(T * B, I)) if ni[1] else None
+        dw_hh = linear_bwd_weight(dhp2, h_all[:T].reshape(T * B, H)) if ni[2] else None
+        db_ih = colsum(dxp2) if ni[3] else None
+        db_hh = colsum(dhp2) if ni[4] else None
+        dh0 = dh if (ctx.has_init and ni[5]) else None
+        return dx, dw_ih, dw_hh, db_ih, db_hh, dh0
+
+
+def gru(x, w_ih, w_hh, b_ih, b_hh, h0=None):
+    return GRUFn.apply(x, w_ih, w_hh, b_ih, b_hh, h0)
+
+
 class CatTanhFn(torch.autograd.Function):
     """tanh(reshape(transpose(cat(h,c,2)))) for num_layers = 1 (models.py:62-65)."""
 

@@ -174,3 +174,37 @@ def test_checkpoint_wire_compat_with_torch_adam(pkg, tmp_path):
         assert rel_err(r, m.fc2.weight) < 1e-5
     t_opt = torch.optim.Adam(m2.parameters(), lr=1e-3)
     t_opt.load_state_dict(sd)                      # FusedAdam(flat) -> torch.optim.Adam
+
+
+def test_gru_variant_model_vs_torch(pkg):
+    """VGG19 + GRU variant (BASELINE.json configs[2] recurrent half; not in the reference): logits and gradients vs
+    the same arithmetic in plain torch (nn.GRU) on CPU, frozen trunk output shared."""
+    ops, models, _, _ = pkg
+    from lct_vqa_amd.basic_vqa import models_ext
+    torch.manual_seed(5)
+    m = models_ext.VqaModelGRU(32, 50, 40, 16, 1, 32)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    md = m.to(DEV).eval()
+    img = torch.randn(3, 3, 32, 32)
+    qst = torch.randint(50, (3, 9))
+    lab = torch.randint(40, (3,))
+    lg = md(img.to(DEV), qst.to(DEV))
+    loss = ops.cross_entropy(lg, lab.to(DEV))
+    names = [n for n, _ in md.named_parameters() if not n.startswith('img_encoder.model.')]
+    grads = torch.autograd.grad(loss, [dict(md.named_parameters())[n] for n in names])
+    # torch restatement on CPU
+    from oracle import vqa_oracle as O
+    P = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    img_f = O.img_encoder(img, P, None, True)
+    gru = torch.nn.GRU(16, 32, 1)
+    v = torch.tanh(P['qst_encoder.word2vec.weight'][qst]).transpose(0, 1)
+    _, h = torch._VF.gru(v, torch.zeros(1, 3, 32), [P['qst_encoder.gru.weight_ih_l0'], P['qst_encoder.gru.weight_hh_l0'],
+                                                     P['qst_encoder.gru.bias_ih_l0'], P['qst_encoder.gru.bias_hh_l0']],
+                         True, 1, 0.0, False, False, False)
+    qf = torch.nn.functional.linear(torch.tanh(h[0]), P['qst_encoder.fc.weight'], P['qst_encoder.fc.bias'])
+    ref = O.fusion_head(img_f, qf, P, None)
+    rloss = O.cross_entropy(ref, lab)
+    rg = torch.autograd.grad(rloss, [P[n] for n in names])
+    assert rel_err(lg, ref) < 1e-3 and torch.equal(lg.argmax(1).cpu(), ref.argmax(1))
+    for n, a, r in zip(names, grads, rg):
+        assert rel_err(a, r) < 1e-3, n

@@ -281,3 +281,25 @@ def test_trainable_vgg_trunk_backward(ops, size):
     got = torch.autograd.grad((out * wgt.to(DEV)).sum(), list(md.parameters()))
     for (k, _), a, r in zip(md.named_parameters(), got, ref):
         assert rel_err(a, r) < 2e-3, k
+
+
+def test_gru_fwd_bwd_vs_torch(ops):
+    """GRU question-encoder variant (BASELINE.json 'LSTM/GRU'; not in the reference): oracle = torch.nn.GRU."""
+    torch.manual_seed(9)
+    B, T, We, H = 5, 6, 12, 16
+    gru = torch.nn.GRU(We, H, 1)
+    x = torch.randn(T, B, We)
+    h0 = torch.randn(B, H) * 0.3
+    for use_init in (False, True):
+        xr = x.clone().requires_grad_()
+        out, h = gru(xr, h0.view(1, B, H) if use_init else None)
+        loss = (out * 0.3).sum() + (h * h).sum()
+        ref = torch.autograd.grad(loss, [xr] + list(gru.parameters()))
+        pd = [p.detach().to(DEV).requires_grad_() for p in gru.parameters()]
+        xd = x.to(DEV).requires_grad_()
+        h0d = h0.to(DEV) if use_init else None
+        od, hd = ops.gru(xd, pd[0], pd[1], pd[2], pd[3], h0d)
+        assert rel_err(od, out) < 2e-5 and rel_err(hd, h[0]) < 2e-5
+        got = torch.autograd.grad((od * 0.3).sum() + (hd * hd).sum(), [xd] + pd)
+        for a, r in zip(got, ref):
+            assert rel_err(a, r) < 1e-4
