@@ -45,6 +45,14 @@ int lctvqa_conv3x3_pack_weights(const float* w_oihw, float* w_packed, int Cout, 
  * y: [B,H,W,Cout] or [B,H/2,W/2,Cout].  pool_tmp ([B,H,W,Cout]) is only used by the fallback. */
 int lctvqa_conv3x3_nhwc(const float* x, const float* w_oihw, const float* w_packed, const float* bias, float* y,
                         float* pool_tmp, int B, int H, int W, int Cin, int Cout, int relu, int pool, void* stream);
+/* Winograd F(2x2,3x3) variant of the same operator (fp32, 2.25x fewer MFMA FLOPs; differs from the direct kernel by
+ * ordinary fp32 rounding).  u_packed: lctvqa_conv3x3_wino_packed_elems floats from lctvqa_conv3x3_wino_pack_weights
+ * (flip_transpose=1 packs the weights of the dgrad convolution). */
+long lctvqa_conv3x3_wino_packed_elems(int Cout, int Cin);
+int lctvqa_conv3x3_wino_supported(int B, int H, int W, int Cin, int Cout, int pool);
+int lctvqa_conv3x3_wino_pack_weights(const float* w_oihw, float* u_packed, int Cout, int Cin, int flip_transpose, void* stream);
+int lctvqa_conv3x3_wino_nhwc(const float* x, const float* u_packed, const float* bias, float* y, int B, int H, int W, int Cin,
+                             int Cout, int relu, int pool, void* stream);
 /* first layer: NCHW image [B,3,H,W] (the layout the reference's loaders produce,
  * data_loader_v2.py:82-86) -> NHWC [B,H,W,Cout], conv3x3 + bias + ReLU */
 int lctvqa_conv3x3_first_nchw(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc, int B,

@@ -5,6 +5,7 @@ the hot path runs in the HIP library.  There is NO eager/CPU fallback: tensors m
 ROCm device and the library must be built, otherwise these functions raise.
 """
 import contextlib
+import os
 import threading
 
 import torch
@@ -567,10 +568,44 @@ def conv_timer_stop():
 
 
 # ----------------------------------------------------------------------------- VGG19 trunk
+_conv_algo = os.environ.get('LCTVQA_CONV_ALGO', 'winograd')
+
+
+def set_conv_algo(name):
+    """'winograd' (F(2x2,3x3) fp32 MFMA kernel where the shape allows, default) or 'direct' (implicit-GEMM kernel)."""
+    global _conv_algo
+    if name not in ('winograd', 'direct'):
+        raise ValueError(name)
+    _conv_algo = name
+
+
+def get_conv_algo():
+    return _conv_algo
+
+
+def _timed(name, flops, fn):
+    if _conv_timer is None:
+        fn()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    _conv_timer.append((name, e0, e1, flops))
+
+
 def _conv_block(cur, w, b, B, H, W, pool, name_timer=True):
     """conv3x3 + bias + ReLU (+ fused 2x2 max pool) on an NHWC activation -> NHWC output."""
     dev = cur.device
     Cout, Cin = w.shape[0], w.shape[1]
+    if _conv_algo == 'winograd' and lib.query('conv3x3_wino_supported', B, H, W, Cin, Cout, pool):
+        up = torch.empty(Cout * Cin * 16, dtype=torch.float32, device=dev)
+        lib('conv3x3_wino_pack_weights', w, up, Cout, Cin, 0)
+        Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
+        _timed(f'wino{H}x{W}_{Cin}->{Cout}{"+pool" if pool else ""}', 2.0 * B * H * W * Cout * Cin * 9,
+               lambda: lib('conv3x3_wino_nhwc', cur, up, b, out, B, H, W, Cin, Cout, 1, pool))
+        return out
     mfma = lib.query('conv3x3_uses_mfma', B, H, W, Cin, Cout, pool)
     wp = tmp = None
     if mfma:
@@ -714,7 +749,11 @@ class VggFeaturesFn(torch.autograd.Function):
             grads[2 * li] = dw
             # dgrad: conv3x3(dz) with W'[ci][co] = flip(W[co][ci])
             dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
-            if lib.query('conv3x3_uses_mfma', B, H, W, Cout, Cin, 0):
+            if _conv_algo == 'winograd' and lib.query('conv3x3_wino_supported', B, H, W, Cout, Cin, 0):
+                up = torch.empty(Cout * Cin * 16, dtype=torch.float32, device=dev)
+                lib('conv3x3_wino_pack_weights', w, up, Cin, Cout, 1)         # dgrad conv: Cout' = Cin, Cin' = Cout
+                lib('conv3x3_wino_nhwc', dz, up, None, dx, B, H, W, Cout, Cin, 0, 0)
+            elif lib.query('conv3x3_uses_mfma', B, H, W, Cout, Cin, 0):
                 wp = torch.empty(Cout * Cin * 9, dtype=torch.float32, device=dev)
                 lib('conv3x3_pack_weights_dgrad', w, wp, Cout, Cin)
                 lib('conv3x3_nhwc', dz, w, wp, None, dx, None, B, H, W, Cout, Cin, 0, 0)

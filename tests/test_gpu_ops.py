@@ -17,6 +17,46 @@ def ops(hip_lib):
     return _ops
 
 
+def _wino_case(hip_lib, B, H, W, Cin, Cout, pool, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = torch.relu(F.conv2d(x, w, b, padding=1))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    up = torch.empty(Cout * Cin * 16, device=DEV)
+    hip_lib('conv3x3_wino_pack_weights', w.to(DEV), up, Cout, Cin, 0)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.full((B, Ho, Wo, Cout), float('nan'), device=DEV)
+    hip_lib('conv3x3_wino_nhwc', xd, up, b.to(DEV), y, B, H, W, Cin, Cout, 1, pool)
+    torch.cuda.synchronize()
+    got = y.permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got).all()
+    return rel_err(got, ref)
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,pool', [
+    (2, 32, 32, 64, 64, 0), (2, 32, 32, 64, 64, 1),       # 64-tile patch (8,32), 2x2 waves (conv1_2)
+    (3, 16, 16, 64, 128, 0), (3, 16, 16, 128, 128, 1),    # (8,16), ragged stacked rows
+    (2, 56, 56, 128, 256, 0), (1, 56, 56, 256, 256, 1),   # (16,8)
+    (3, 28, 28, 256, 512, 0), (2, 28, 28, 512, 512, 1),   # (32,4): patch spans images
+    (5, 14, 14, 512, 512, 0), (3, 14, 14, 512, 512, 1),   # (8,14): 28 of 32 tile slots, image gaps
+    (1, 64, 48, 16, 64, 0), (2, 24, 8, 32, 128, 1),
+])
+def test_conv3x3_winograd(hip_lib, B, H, W, Cin, Cout, pool):
+    assert hip_lib.query('conv3x3_wino_supported', B, H, W, Cin, Cout, pool) == 1
+    assert _wino_case(hip_lib, B, H, W, Cin, Cout, pool) < 2e-5
+
+
+def test_conv3x3_winograd_full_res_layers(hip_lib):
+    for (H, Cin, Cout, pool) in [(224, 64, 64, 1), (112, 64, 128, 0)]:
+        assert _wino_case(hip_lib, 1, H, H, Cin, Cout, pool) < 2e-5
+    for (H, Cin, Cout, pool) in [(224, 64, 64, 1), (112, 128, 128, 1), (56, 256, 256, 0), (28, 512, 512, 0), (14, 512, 512, 1)]:
+        assert hip_lib.query('conv3x3_wino_supported', 256, H, H, Cin, Cout, pool) == 1
+
+
 def _conv_case(ops, hip_lib, B, H, W, Cin, Cout, pool, seed=0):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, Cin, H, W, generator=g)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--only', default='')
     ap.add_argument('--bwd', action='store_true', help='also time wgrad and dgrad')
+    ap.add_argument('--wino', action='store_true', help='also time the Winograd F(2x2,3x3) kernel')
     args = ap.parse_args()
     lib.load()
     dev = torch.device('cuda')
@@ -42,6 +43,7 @@ def main():
     print(f'first 3->64 @224: {ms:.3f} ms  ({y.numel() * 4 / ms / 1e6:.0f} GB/s written)')
     del x, y
     seen = {}
+    wino_ms = {}
     for (H, Cin, Cout, pool) in LAYERS:
         if only and H not in only:
             continue
@@ -60,6 +62,18 @@ def main():
                 lib('conv3x3_nhwc', xin, wt, wp, bs, out, None, B, H, H, Cin, Cout, 1, pool)
             e1.record(); torch.cuda.synchronize()
             seen[key] = e0.elapsed_time(e1) / args.iters
+            if args.wino and lib.query('conv3x3_wino_supported', B, H, H, Cin, Cout, pool):
+                up = torch.empty(Cout * Cin * 16, device=dev)
+                lib('conv3x3_wino_pack_weights', wt, up, Cout, Cin, 0)
+                for it in range(args.iters + 1):
+                    if it == 1:
+                        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+                    lib('conv3x3_wino_nhwc', xin, up, bs, out, B, H, H, Cin, Cout, 1, pool)
+                e1.record(); torch.cuda.synchronize()
+                t = e0.elapsed_time(e1) / args.iters
+                wino_ms[key] = t
+                print(f'   wino  {H}x{H} {Cin}->{Cout}: {t:7.3f} ms  {2.0 * B * H * H * Cout * Cin * 9 / t / 1e9:6.1f} algorithmic TFLOP/s '
+                      f'({2.0 * B * H * H * Cout * Cin * 4 / t / 1e9:6.1f} executed)')
             if args.bwd:
                 dz = torch.randn(B, H, H, Cout, device=dev)
                 dw = torch.empty_like(wt)
@@ -83,6 +97,9 @@ def main():
         fl = 2.0 * B * H * H * Cout * Cin * 9
         tot_ms += ms; tot_fl += fl
         print(f'conv {H:3d}x{H:<3d} {Cin:3d}->{Cout:3d}{"+pool" if pool else "     "}: {ms:7.3f} ms  {fl / ms / 1e9:6.1f} TFLOP/s')
+    if wino_ms:
+        tw = sum(wino_ms.get((H, Cin, Cout, pool), seen[(H, Cin, Cout, pool)]) for (H, Cin, Cout, pool) in LAYERS if not only or H in only)
+        print(f'TOTAL winograd: {tw:.3f} ms  {tot_fl / tw / 1e9:.1f} algorithmic TFLOP/s')
     print(f'TOTAL mfma conv: {tot_ms:.3f} ms  {tot_fl / tot_ms / 1e9:.1f} TFLOP/s  ({tot_fl / tot_ms / 1e9 / 157.3 * 100:.1f}% of 157.3)')
 
 
