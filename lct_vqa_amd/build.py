@@ -16,7 +16,7 @@ OUT_DIR = os.path.join(HERE, '_C')
 LIB = os.path.join(OUT_DIR, 'liblctvqa_hip.so')
 SOURCES = ['api.hip', 'conv3x3.hip', 'conv3x3_bwd.hip', 'conv3x3_wino.hip', 'darts.hip', 'gemm.hip', 'ops.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', 
-         '-Wno-unused-result', '-Wno-unused-value', '-I' + CSRC]
+         '-Wno-unused-result', '-Wno-unused-value', '-Wno-inline-asm', '-I' + CSRC]
 
 
 def _hipcc():

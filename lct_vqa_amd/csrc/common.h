@@ -30,6 +30,15 @@ __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Same copy, but opaque to the compiler's waitcnt insertion.  With the builtin the compiler must assume that any later
+// LDS read may alias the in-flight DMA and drains vmcnt to 0 in front of it; kernels that keep unrelated global loads
+// in flight across LDS reads use this form and order the DMA themselves (s_waitcnt vmcnt(N) + barrier).
+__device__ __forceinline__ void glds16_opaque(const float* g, float* lds_wave_base) {
+  const unsigned l = __builtin_amdgcn_readfirstlane(
+      (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -576,7 +576,8 @@ def set_conv_algo(name):
     global _conv_algo
     if name not in ('winograd', 'direct'):
         raise ValueError(name)
-    _conv_algo = name
+    prev, _conv_algo = _conv_algo, name
+    return prev
 
 
 def get_conv_algo():

@@ -293,16 +293,56 @@ def test_conv3x3_wgrad_dgrad(ops, hip_lib, B, H, W, Cin, Cout):
     assert rel_err(dx.permute(0, 3, 1, 2), gx) < 5e-5
 
 
-@pytest.mark.parametrize('size', [32, 40])
-def test_trainable_vgg_trunk_backward(ops, size):
-    """vgg19 trunk with gradients (reference models_lct.py:62-63) at 32x32 and 40x40 (odd intermediate maps: floor
-    pooling): every parameter gradient vs torch."""
+_TRUNK_CACHE = {}
+
+
+def _well_conditioned_trunk(size, margin=1e-5):
+    """A vgg19 trunk + input whose ReLU gates and max-pool winners in the small deep maps (<= 5x5, where one element
+    is a visible share of every weight gradient) are decided by more than `margin` (relative to the layer's max):
+    a pre-activation within fp32 rounding of zero flips a gate between two correct fp32 implementations and
+    re-routes that element's whole gradient, which says nothing about the kernels under test."""
     from lct_vqa_amd import vgg
+    if size in _TRUNK_CACHE:
+        return _TRUNK_CACHE[size]
     torch.manual_seed(8)
     m = vgg.vgg19()
     m.classifier = torch.nn.Sequential(*list(m.classifier.children())[:-1])
     m.eval()
-    x = torch.randn(2, 3, size, size)
+    for seed in range(1000):
+        x = torch.randn(2, 3, size, size, generator=torch.Generator().manual_seed(seed))
+        ok, h = True, x
+        with torch.no_grad():
+            for mod in m.features:
+                if isinstance(mod, torch.nn.Conv2d):
+                    h = mod(h)
+                    if h.shape[-1] <= 5 and h.abs().min() <= margin * h.abs().max():
+                        ok = False
+                elif isinstance(mod, torch.nn.ReLU):
+                    h = torch.relu(h)
+                else:
+                    if h.shape[-1] <= 5:
+                        Hc = h.shape[-1] // 2 * 2
+                        win = h[..., :Hc, :Hc].unfold(2, 2, 2).unfold(3, 2, 2).reshape(*h.shape[:2], -1, 4)
+                        top = win.topk(2, dim=-1).values
+                        live = top[..., 0] > 0                      # an all-zero window routes no gradient either way
+                        if live.any() and (top[..., 0] - top[..., 1])[live].min() <= margin * h.abs().max():
+                            ok = False
+                    h = mod(h)
+                if not ok:
+                    break
+        if ok:
+            _TRUNK_CACHE[size] = (m, x)
+            return m, x
+    raise RuntimeError('no well-conditioned input found')
+
+
+@pytest.mark.parametrize('algo', ['winograd', 'direct'])
+@pytest.mark.parametrize('size', [32, 40])
+def test_trainable_vgg_trunk_backward(ops, size, algo):
+    """vgg19 trunk with gradients (reference models_lct.py:62-63) at 32x32 and 40x40 (odd intermediate maps: floor
+    pooling): every parameter gradient vs torch, with both convolution algorithms."""
+    from lct_vqa_amd import vgg
+    m, x = _well_conditioned_trunk(size)
     # torch reference of the same module structure
     h = x
     for mod in m.features:
@@ -316,9 +356,13 @@ def test_trainable_vgg_trunk_backward(ops, size):
     md.classifier = torch.nn.Sequential(*list(md.classifier.children())[:-1])
     md.load_state_dict(m.state_dict())
     md = md.to(DEV).eval()
-    out = md(x.to(DEV))
-    assert rel_err(out, h) < 1e-4
-    got = torch.autograd.grad((out * wgt.to(DEV)).sum(), list(md.parameters()))
+    prev = ops.set_conv_algo(algo)
+    try:
+        out = md(x.to(DEV))
+        assert rel_err(out, h) < 1e-4
+        got = torch.autograd.grad((out * wgt.to(DEV)).sum(), list(md.parameters()))
+    finally:
+        ops.set_conv_algo(prev)
     for (k, _), a, r in zip(md.named_parameters(), got, ref):
         assert rel_err(a, r) < 2e-3, k
 
