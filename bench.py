@@ -42,6 +42,8 @@ def parse():
     ap.add_argument('--workload', default='w', choices=['w', 'lct'],
                     help="'w' = BASELINE configs[1] (default, the headline metric); 'lct' = stage-1 + stage-2 step of "
                          "experiment.py:216-268 (EF fixed encoder + generate + W soft loss), reported under its own metric name")
+    ap.add_argument('--conv-algo', default=None, choices=['winograd', 'direct'],
+                    help='trunk convolution algorithm (default: LCTVQA_CONV_ALGO or winograd, fp32 either way)')
     return ap.parse_args()
 
 
@@ -102,6 +104,8 @@ def main():
     from lct_vqa_amd.basic_vqa import models, config
     from lct_vqa_amd.optim import FusedAdam
     lib.load()                                      # fail loudly if the HIP library is missing
+    if args.conv_algo:
+        ops.set_conv_algo(args.conv_algo)
     rank, world, local = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
@@ -230,19 +234,32 @@ def main():
         return
     ms = dt / args.steps * 1e3
     value = world * B * args.steps / dt
-    # ---- roofline of the dominant kernel (conv3x3_mfma_kernel, every instantiation) ----
+    # ---- roofline of the dominant kernel family (the 15 MFMA conv launches of the VGG19 trunk per step) ----
+    # achieved = ALGORITHMIC FLOPs (direct-convolution count 2*B*H*W*Cout*Cin*9) / live HIP-event
+    # time of those launches.  With the Winograd kernels the MFMA pipe executes 2.25x fewer FLOPs than that count, so
+    # `frac` can exceed 1; `mfma_executed_*` is what the pipe really ran (its utilisation against the dense fp32 peak).
+    algo = ops.get_conv_algo()
     tot_flops = sum(r['flops'] for r in conv)
+    tot_exec = sum(r['flops'] / (2.25 if r['name'].startswith('wino') else 1.0) for r in conv)
     tot_ms = sum(r['ms'] for r in conv)
     nlaunch = max(1, len(conv))
     achieved = tot_flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-    roofline = {'bound': 'mfma', 'kernel': 'conv3x3_mfma_kernel (15 VGG19 layers/step)', 'achieved': round(achieved, 2),
+    executed = tot_exec / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    nwino = sum(1 for r in conv if r['name'].startswith('wino'))
+    roofline = {'bound': 'mfma',
+                'kernel': ('conv3x3_wino2_kernel / conv3x3_wino3_kernel (Winograd F(2x2,3x3) fp32 MFMA, %d of %d launches) + '
+                           'conv3x3_mfma_kernel (direct)' % (nwino, nlaunch)) if nwino else
+                          'conv3x3_mfma_kernel (direct implicit GEMM, 15 VGG19 layers/step)',
+                'algorithm': algo, 'achieved': round(achieved, 2),
                 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                'mfma_executed_tflops': round(executed, 2), 'mfma_executed_frac': round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
                 'traffic': None, 'launches': nlaunch, 'avg_launch_ms': round(tot_ms / nlaunch, 4),
                 'flops_per_launch': tot_flops / nlaunch, 'conv_ms_per_step': round(tot_ms / args.steps, 3)}
     try:      # HBM bytes per launch of the same kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
-        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_conv_gemm.json')))['conv3x3_mfma_family']
+        pfile = 'r01_pmc_conv_wino.json' if nwino else 'r01_pmc_conv_gemm.json'
+        pm = json.load(open(os.path.join(ROOT, 'profiles', pfile)))['conv3x3_family']
         roofline['traffic'] = pm['hbm_bytes_per_launch']
-        roofline['traffic_source'] = 'profiles/r01_pmc_conv_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per launch)'
+        roofline['traffic_source'] = f'profiles/{pfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per launch)'
     except Exception:
         pass
     if args.layer_report:

@@ -27,6 +27,17 @@
 
 __device__ __attribute__((aligned(64))) float g_zero_page_w[64];
 
+#ifndef WINO_XCD_MAP
+#define WINO_XCD_MAP 1
+#endif
+static inline int wino_grid(int mtiles, int ntiles) {
+#if WINO_XCD_MAP
+  return ((mtiles + 7) / 8) * 8 * ntiles;
+#else
+  return mtiles * ntiles;
+#endif
+}
+
 // U[cout/32][Cin/16][16 xi*4+nu][4 chunks][32 cout][4 ch] = G g G^T.   flip_t: weights of the dgrad convolution
 // (g'[ci][co][ky][kx] = g[co][ci][2-ky][2-kx]; Cout/Cin then name the dgrad conv's own output/input channels).
 __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int flip_t) {
@@ -97,7 +108,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino2_kernel(const float* __re
   const int wn = wave;
   const int j = lane & 31, h = lane >> 5;
   const int NT = Cout / 128;
+#if WINO_XCD_MAP
+  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), each XCD with its own L2: the NT workgroups that
+  // read the same input patch are given consecutive slots of ONE XCD so that all but the first hit its L2.
+  const int n_tile = (blockIdx.x >> 3) % NT, m_tile = ((blockIdx.x >> 3) / NT) * 8 + (blockIdx.x & 7);
+  if (m_tile >= ((Btot * H + TH - 1) / TH) * (W / TW)) return;
+#else
   const int n_tile = blockIdx.x % NT, m_tile = blockIdx.x / NT;
+#endif
   const int CT = W / TW;
   const int ct = m_tile % CT, rt = m_tile / CT;
   const int R0 = rt * TH, x0 = ct * TW;
@@ -381,7 +399,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino3_kernel(const float* __re
   const int nh = wave & 1, xh = wave >> 1;
   const int j = lane & 31, h = lane >> 5;
   const int NT = Cout / 64;
+#if WINO_XCD_MAP
+  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), each XCD with its own L2: the NT workgroups that
+  // read the same input patch are given consecutive slots of ONE XCD so that all but the first hit its L2.
+  const int n_tile = (blockIdx.x >> 3) % NT, m_tile = ((blockIdx.x >> 3) / NT) * 8 + (blockIdx.x & 7);
+  if (m_tile >= ((Btot * H + TH - 1) / TH) * (W / TW)) return;
+#else
   const int n_tile = blockIdx.x % NT, m_tile = blockIdx.x / NT;
+#endif
   const int CT = W / TW;
   const int ct = m_tile % CT, rt = m_tile / CT;
   const int R0 = rt * TH, x0 = ct * TW;
@@ -604,7 +629,7 @@ static int launch_wino2(const float* x, const float* up, const float* bias, floa
   constexpr int VBUF = 16 * 4 * 32 * 4;
   size_t lds = (size_t)(2 * RAWSZ + 2 * VBUF) * sizeof(float);
   long Rtot = (long)B * H;
-  dim3 grid(cdiv(Rtot, TH) * (W / TW) * (Cout / 128));
+  dim3 grid(wino_grid(cdiv(Rtot, TH) * (W / TW), Cout / 128));
   if (pool) {
     auto k = conv3x3_wino2_kernel<TH, TW, true>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -626,7 +651,7 @@ static int launch_wino3(const float* x, const float* up, const float* bias, floa
   constexpr int VBUF = 16 * 4 * 32 * 4;
   size_t lds = (size_t)(RAWSZ + VBUF) * sizeof(float);
   long Rtot = (long)B * H;
-  dim3 grid(cdiv(Rtot, TH) * (W / TW) * (Cout / 64));
+  dim3 grid(wino_grid(cdiv(Rtot, TH) * (W / TW), Cout / 64));
   if (pool) {
     auto k = conv3x3_wino3_kernel<TH, TW, true>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

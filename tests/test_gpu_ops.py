@@ -367,6 +367,45 @@ def test_trainable_vgg_trunk_backward(ops, size, algo):
         assert rel_err(a, r) < 2e-3, k
 
 
+def _torch_trunk(m, x):
+    """Plain torch forward of a lct_vqa_amd.vgg.VGG module's layers (the module's own forward is HIP-only)."""
+    h = x
+    for mod in m.features:
+        h = mod(h) if not isinstance(mod, torch.nn.ReLU) else torch.relu(h)
+    h = torch.flatten(m.avgpool(h), 1)
+    for mod in m.classifier:
+        h = mod(h) if not isinstance(mod, torch.nn.ReLU) else torch.relu(h)
+    return h
+
+
+def test_frozen_trunk_packed_weight_cache_follows_weight_updates(ops):
+    """The frozen trunk packs its conv weights once (ops._packed_weights); an in-place update or a load_state_dict of
+    the frozen parameters must be seen by the next forward."""
+    from lct_vqa_amd import vgg
+    torch.manual_seed(3)
+    m = vgg.vgg19()
+    m.classifier = torch.nn.Sequential(*list(m.classifier.children())[:-1])
+    for p in m.parameters():
+        p.requires_grad = False
+    m.eval()
+    md = vgg.vgg19()
+    md.classifier = torch.nn.Sequential(*list(md.classifier.children())[:-1])
+    md.load_state_dict(m.state_dict())
+    for p in md.parameters():
+        p.requires_grad = False
+    md = md.to(DEV).eval()
+    x = torch.randn(2, 3, 64, 64)
+    with torch.no_grad():
+        assert rel_err(md(x.to(DEV)), _torch_trunk(m, x)) < 1e-4
+        assert rel_err(md(x.to(DEV)), _torch_trunk(m, x)) < 1e-4       # second call: served from the cache
+        m.features[7].weight.mul_(1.5)
+        md.features[7].weight.mul_(1.5)                                # in-place update bumps the version counter
+        assert rel_err(md(x.to(DEV)), _torch_trunk(m, x)) < 1e-4
+        m.features[12].weight.normal_(0, 0.05)
+        md.load_state_dict(m.state_dict())
+        assert rel_err(md(x.to(DEV)), _torch_trunk(m, x)) < 1e-4
+
+
 def test_gru_fwd_bwd_vs_torch(ops):
     """GRU question-encoder variant (BASELINE.json 'LSTM/GRU'; not in the reference): oracle = torch.nn.GRU."""
     torch.manual_seed(9)

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Merge rocprofv3 --pmc passes (each with --kernel-trace, csv) into the per-kernel JSON kept under profiles/.
+
+    python tools/pmc_profile.py out.json dirFETCH dirWRITE dirMFMA [note]
+
+dirFETCH: pass with FETCH_SIZE; dirWRITE: WRITE_SIZE; dirMFMA: SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE.
+FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled (gfx950 tallies the 128-B requests of 16-B/lane streams at
+64 B: MI355X_MICROARCH.md, HBM section).  The `conv3x3_family` entry aggregates the MFMA conv kernels (direct and
+Winograd) per launch: bench.py reads its hbm_bytes_per_launch as roofline.traffic."""
+import collections, csv, glob, json, sys
+
+
+def load(d):
+    cc = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
+    kt = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)
+    dur = {}
+    for f in kt:
+        for r in csv.DictReader(open(f)):
+            dur[r['Dispatch_Id']] = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-9
+    vals = collections.defaultdict(lambda: collections.defaultdict(dict))
+    for f in cc:
+        for r in csv.DictReader(open(f)):
+            vals[r['Kernel_Name']][r['Counter_Name']][r['Dispatch_Id']] = float(r['Counter_Value'])
+    return vals, dur
+
+
+def short(k):
+    return k.split('(')[0]
+
+
+def main():
+    out, df, dw, dm = sys.argv[1:5]
+    note = sys.argv[5] if len(sys.argv) > 5 else ''
+    vf, _ = load(df)
+    vw, _ = load(dw)
+    vm, dur = load(dm)
+    res = {}
+    fam = dict(launches=0, rd=0.0, wr=0.0, busy=0.0, cyc=0.0)
+    for k in sorted(set(vf) | set(vw) | set(vm)):
+        f = vf.get(k, {}).get('FETCH_SIZE', {})
+        w = vw.get(k, {}).get('WRITE_SIZE', {})
+        b = vm.get(k, {}).get('SQ_VALU_MFMA_BUSY_CYCLES', {})
+        g = vm.get(k, {}).get('GRBM_GUI_ACTIVE', {})
+        n = max(len(f), len(w), len(b), 1)
+        rd = 2 * 1024 * sum(f.values()) / max(1, len(f))
+        wr = 1024 * sum(w.values()) / max(1, len(w))
+        cyc = sum(g.values()) / 8
+        t = sum(dur.get(i, 0.0) for i in g)
+        e = {'launches': n, 'hbm_read_GB_per_launch': round(rd / 1e9, 4), 'hbm_write_GB_per_launch': round(wr / 1e9, 4),
+             'mfma_busy_frac': round(sum(b.values()) / (4 * 256 * cyc), 4) if cyc else None,
+             'clock_GHz': round(cyc / t * 1e-9, 3) if t else None, 'avg_ms_in_pmc_pass': round(t / max(1, len(g)) * 1e3, 4)}
+        res[short(k)] = e
+        if 'conv3x3_mfma_kernel' in k or 'conv3x3_wino' in k:
+            fam['launches'] += n
+            fam['rd'] += rd * n; fam['wr'] += wr * n
+            fam['busy'] += sum(b.values()); fam['cyc'] += cyc
+    L = max(1, fam['launches'])
+    doc = {'note': note or 'rocprofv3 --pmc passes; FETCH_SIZE/WRITE_SIZE in KB, FETCH_SIZE doubled (gfx950 correction)',
+           'kernels': res,
+           'conv3x3_family': {'launches': L, 'hbm_read_GB_per_launch': round(fam['rd'] / L / 1e9, 4),
+                              'hbm_write_GB_per_launch': round(fam['wr'] / L / 1e9, 4),
+                              'hbm_bytes_per_launch': int((fam['rd'] + fam['wr']) / L),
+                              'mfma_busy_frac': round(fam['busy'] / (4 * 256 * fam['cyc']), 4) if fam['cyc'] else None}}
+    json.dump(doc, open(out, 'w'), indent=1)
+    print(json.dumps(doc['conv3x3_family']))
+
+
+if __name__ == '__main__':
+    main()
