@@ -149,6 +149,11 @@ int lctvqa_softmax_rows(const float* x, float* y, int M, int N, float inv_temp, 
 int lctvqa_softmax_rows_bwd(const float* dy, const float* y, float* dx, int M, int N, float inv_temp, void* stream);
 /* torch.argmax(x, 1) (first maximal index) -> int64  (models_lct.py:161, experiment.py:218) */
 int lctvqa_argmax_rows(const float* x, long ld, int M, int N, long* out, void* stream);
+/* validation counters (basic_vqa/experiment.py:314-324 + misc.py:42-45 num_correct): row argmax of the answer logits x[M,N]
+ * against K multiple-choice answers choices[K][M] (int64).  counts2[0] += #hits with "<unk>" accepted, counts2[1] +=
+ * #hits with a prediction == unk_idx replaced by -9999.  counts2 accumulates (zero it per epoch); pred_out may be null. */
+int lctvqa_eval_multi_choice(const float* x, long ld, int M, int N, const long* choices, int K, long unk_idx, long* pred_out,
+                             long* counts2, void* stream);
 /* nn.Dropout keep mask from a counter-based generator: mask[i] = U(seed, offset+i) >= p */
 int lctvqa_dropout_mask(uint8_t* mask, long n, unsigned long long seed, unsigned long long offset, float p, void* stream);
 

@@ -298,6 +298,47 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
   }
 }
 
+// Validation counters of one batch (reference basic_vqa/experiment.py:314-324, misc.py:42-45): for every sample the
+// row argmax of the answer logits is compared with its K multiple-choice answers.
+//   counts[0] += #samples whose prediction is one of its choices                       ("<unk> accepted", Exp1)
+//   counts[1] += the same with a prediction equal to unk_idx replaced by -9999          ("<unk> rejected", Exp2)
+// choices: [K][M] int64 (the reference's list of K LongTensors stacked).  pred_out (optional): the argmax per row.
+__global__ __launch_bounds__(256) void eval_multi_choice_kernel(const float* __restrict__ x, long ld, int N,
+                                                                const long* __restrict__ choices, int K, int M, long unk_idx,
+                                                                long* __restrict__ pred_out, long* __restrict__ counts) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const long row = blockIdx.x;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int e = threadIdx.x; e < N; e += blockDim.x) {
+    float v = x[row * ld + e];
+    if (v > best || (v == best && e < idx)) { best = v; idx = e; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++)
+      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    if (pred_out) pred_out[row] = idx;
+    const long p1 = idx, p2 = (idx == unk_idx) ? -9999 : (long)idx;
+    int hit1 = 0, hit2 = 0;
+    for (int k = 0; k < K; k++) {
+      const long c = choices[(long)k * M + row];
+      hit1 |= (c == p1);
+      hit2 |= (c == p2);
+    }
+    if (hit1) atomicAdd((unsigned long long*)&counts[0], 1ULL);
+    if (hit2) atomicAdd((unsigned long long*)&counts[1], 1ULL);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // dropout keep-mask from a counter-based generator (seed, offset): mask[i] = U(i) >= p.
 // (PyTorch's CPU Bernoulli stream cannot be reproduced on the GPU; parity tests inject masks.)
@@ -477,6 +518,14 @@ int lctvqa_softmax_rows_bwd(const float* dy, const float* y, float* dx, int M, i
 int lctvqa_argmax_rows(const float* x, long ld, int M, int N, long* out, void* stream) {
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ld, N, out);
   return lct_check_launch("argmax_rows");
+}
+int lctvqa_eval_multi_choice(const float* x, long ld, int M, int N, const long* choices, int K, long unk_idx, long* pred_out,
+                             long* counts2, void* stream) {
+  LCT_REQUIRE(M >= 0 && N > 0 && K >= 0, "eval_multi_choice: bad sizes");
+  if (M == 0) return 0;
+  hipLaunchKernelGGL(eval_multi_choice_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ld, N, choices, K, M, unk_idx, pred_out,
+                     counts2);
+  return lct_check_launch("eval_multi_choice");
 }
 int lctvqa_dropout_mask(uint8_t* mask, long n, unsigned long long seed, unsigned long long offset, float p, void* stream) {
   LCT_REQUIRE(p >= 0.f && p < 1.f, "dropout_mask: bad p");

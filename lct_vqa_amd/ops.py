@@ -548,6 +548,24 @@ def argmax_rows(x):
     return out
 
 
+def eval_multi_choice(logits, choices, unk_idx, counts=None):
+    """Row argmax of `logits` [B,A] against the multiple-choice answers `choices` [K,B] (int64, device).
+    Returns (pred [B] int64, counts [2] int64 device tensor): counts[0] += hits with '<unk>' accepted,
+    counts[1] += hits with '<unk>' rejected (reference experiment.py:314-324).  No host synchronisation."""
+    x = _chk(logits.detach())
+    if choices.dtype != torch.int64 or not choices.is_cuda:
+        raise RuntimeError('eval_multi_choice: choices must be an int64 device tensor [K,B]')
+    choices = choices.contiguous()
+    K, B = choices.shape
+    if B != x.shape[0]:
+        raise RuntimeError(f'eval_multi_choice: {B} choice columns for {x.shape[0]} rows')
+    if counts is None:
+        counts = torch.zeros(2, dtype=torch.int64, device=x.device)
+    pred = torch.empty(B, dtype=torch.int64, device=x.device)
+    lib('eval_multi_choice', x, x.stride(0), B, x.shape[1], choices, K, int(unk_idx), pred, counts)
+    return pred, counts
+
+
 # ----------------------------------------------------------------------------- per-launch timing (bench.py roofline)
 _conv_timer = None
 

@@ -23,33 +23,33 @@ def _bn(x, P, key, train, new_stats, affine=False):
     return y
 
 
-def _relu_conv_bn(x, P, key, train, ns):
-    """operations.py:22-33 (kernel 1, affine False)."""
-    return _bn(F.conv2d(torch.relu(x), P[key + '.op.1.weight']), P, key + '.op.2', train, ns)
+def _relu_conv_bn(x, P, key, train, ns, affine=False):
+    """operations.py:22-33 (kernel 1; affine False in the search network)."""
+    return _bn(F.conv2d(torch.relu(x), P[key + '.op.1.weight']), P, key + '.op.2', train, ns, affine)
 
 
-def _dil_conv(x, P, key, k, stride, pad, train, ns):
+def _dil_conv(x, P, key, k, stride, pad, train, ns, affine=False):
     """operations.py:35-47."""
     C = x.shape[1]
     y = F.conv2d(torch.relu(x), P[key + '.op.1.weight'], None, stride, pad, 2, C)
     y = F.conv2d(y, P[key + '.op.2.weight'])
-    return _bn(y, P, key + '.op.3', train, ns)
+    return _bn(y, P, key + '.op.3', train, ns, affine)
 
 
-def _sep_conv(x, P, key, k, stride, pad, train, ns):
+def _sep_conv(x, P, key, k, stride, pad, train, ns, affine=False):
     """operations.py:50-67."""
     C = x.shape[1]
     y = F.conv2d(torch.relu(x), P[key + '.op.1.weight'], None, stride, pad, 1, C)
-    y = _bn(F.conv2d(y, P[key + '.op.2.weight']), P, key + '.op.3', train, ns)
+    y = _bn(F.conv2d(y, P[key + '.op.2.weight']), P, key + '.op.3', train, ns, affine)
     y = F.conv2d(torch.relu(y), P[key + '.op.5.weight'], None, 1, pad, 1, C)
-    return _bn(F.conv2d(y, P[key + '.op.6.weight']), P, key + '.op.7', train, ns)
+    return _bn(F.conv2d(y, P[key + '.op.6.weight']), P, key + '.op.7', train, ns, affine)
 
 
-def _fact_reduce(x, P, key, train, ns):
+def _fact_reduce(x, P, key, train, ns, affine=False):
     """operations.py:90-104."""
     x = torch.relu(x)
     out = torch.cat([F.conv2d(x, P[key + '.conv_1.weight'], None, 2), F.conv2d(x[:, :, 1:, 1:], P[key + '.conv_2.weight'], None, 2)], 1)
-    return _bn(out, P, key + '.bn', train, ns)
+    return _bn(out, P, key + '.bn', train, ns, affine)
 
 
 def _mixed_op(x, w, P, key, stride, train, ns):
@@ -117,5 +117,54 @@ def network_forward(image, P, arch, train=False, new_stats=None, layers=4, steps
             offset += len(states)
             states.append(acc)
         s0, s1 = s1, torch.cat(states[-multiplier:], 1)
+        reduction_prev = reduction
+    return F.adaptive_avg_pool2d(s1, 7).flatten(1)
+
+
+# ----------------------------------------------------------------------------- derived (discrete) network
+def _derived_op(name, x, P, key, stride, train, ns):
+    """One primitive of operations.py:4-14 at full width with affine BatchNorm (OPS[name](C, stride, True))."""
+    if name == 'max_pool_3x3':
+        return F.max_pool2d(x, 3, stride, 1)
+    if name == 'avg_pool_3x3':
+        return F.avg_pool2d(x, 3, stride, 1, count_include_pad=False)
+    if name == 'skip_connect':
+        return x if stride == 1 else _fact_reduce(x, P, key, train, ns, True)
+    if name == 'sep_conv_3x3':
+        return _sep_conv(x, P, key, 3, stride, 1, train, ns, True)
+    if name == 'sep_conv_5x5':
+        return _sep_conv(x, P, key, 5, stride, 2, train, ns, True)
+    if name == 'dil_conv_3x3':
+        return _dil_conv(x, P, key, 3, stride, 2, train, ns, True)
+    if name == 'dil_conv_5x5':
+        return _dil_conv(x, P, key, 5, stride, 4, train, ns, True)
+    raise ValueError(name)
+
+
+def derived_forward(image, P, genotype, train=False, new_stats=None, layers=4, prefix=''):
+    """PARITY UNPINNED: the reference decodes a genotype (model_search.py:205-250) but has no derived network to compare
+    with.  Restates the DARTS-family construction lct_vqa_amd/basic_vqa/pcdarts/model.py documents: node = sum of its two
+    selected op(state[index]); stride 2 on edges from the two cell inputs of a reduction cell; output = concat."""
+    N, _, H, W = image.shape
+    x = image.expand(N, 3, H, W)
+    s = _bn(F.conv2d(x, P[prefix + 'stem.0.weight'], None, 1, 1), P, prefix + 'stem.1', train, new_stats, affine=True)
+    s0 = s1 = s
+    reduction_prev = False
+    for ci in range(layers):
+        reduction = ci in [layers // 3, 2 * layers // 3]
+        key = f'{prefix}cells.{ci}'
+        gene, concat = (genotype.reduce, genotype.reduce_concat) if reduction else (genotype.normal, genotype.normal_concat)
+        p0 = _fact_reduce(s0, P, key + '.preprocess0', train, new_stats, True) if reduction_prev else \
+            _relu_conv_bn(s0, P, key + '.preprocess0', train, new_stats, True)
+        p1 = _relu_conv_bn(s1, P, key + '.preprocess1', train, new_stats, True)
+        states = [p0, p1]
+        for i in range(len(gene) // 2):
+            hs = []
+            for e in (2 * i, 2 * i + 1):
+                name, idx = gene[e]
+                stride = 2 if reduction and idx < 2 else 1
+                hs.append(_derived_op(name, states[idx], P, f'{key}._ops.{e}', stride, train, new_stats))
+            states.append(hs[0] + hs[1])
+        s0, s1 = s1, torch.cat([states[i] for i in concat], 1)
         reduction_prev = reduction
     return F.adaptive_avg_pool2d(s1, 7).flatten(1)

@@ -287,3 +287,26 @@ def w_train_step(image, question, label, P, opt_state, masks=None, lr=1e-3, clip
         opt_state[k] = (m, v)
         newP[k] = p
     return loss.detach(), logits.detach(), newP, dict(zip(names, grads))
+
+
+# ----------------------------------------------------------------------------- validation counters
+def num_correct(pred, multi_choice):
+    """reference basic_vqa/misc.py:42-45: a prediction counts when it equals any of the sample's choices."""
+    res = torch.stack([(ans == pred) for ans in multi_choice])
+    return res.any(dim=0).sum().item()
+
+
+def num_correct_qst(qst_pred, qst):
+    """reference basic_vqa/misc.py:47-58: questions with 0 / <=3 / <=5 mismatching tokens."""
+    tok = qst_pred.argmax(dim=2)[:, :-1]
+    err_cnt = (~(qst[:, 1:] == tok)).sum(dim=1)
+    return (err_cnt == 0).sum().item(), (err_cnt <= 3).sum().item(), (err_cnt <= 5).sum().item()
+
+
+def val_counters(output, label, multi_choice, ans_unk_idx):
+    """reference basic_vqa/experiment.py:314-324: (CE loss, corr with '<unk>' accepted, corr with '<unk>' -> -9999)."""
+    _, pred1 = torch.max(output, 1)
+    _, pred2 = torch.max(output, 1)
+    loss = torch.nn.functional.cross_entropy(output, label)
+    pred2[pred2 == ans_unk_idx] = -9999
+    return loss.item(), num_correct(pred1, multi_choice), num_correct(pred2, multi_choice)

@@ -155,3 +155,63 @@ def test_network_against_reference_goldens(D):
     sd = net.state_dict()
     for k, v in fx['running_after'].items():
         assert rel_err(sd[k], v) < 1e-4, k
+
+
+def test_derived_network_from_searched_genotype_vs_oracle(D):
+    """SURVEY f-4: decode the searched architecture (the golden fixture's alphas/betas -> the reference's genotype string)
+    and run the DERIVED network (one op per edge, two edges per node) on the HIP primitives: forward in eval and train
+    mode, every parameter gradient and the BatchNorm running statistics against the oracle restatement.  A second,
+    hand-written genotype covers every primitive (both pools, skip/FactorizedReduce, sep 3/5, dil 3/5) at stride 1 and 2."""
+    from oracle import darts_oracle as O
+    from lct_vqa_amd.basic_vqa import config
+    config.DEVICE = torch.device(DEV)
+    from lct_vqa_amd.basic_vqa.pcdarts.model_search import Network
+    from lct_vqa_amd.basic_vqa.pcdarts.model import NetworkDerived
+    from lct_vqa_amd.basic_vqa.pcdarts.genotypes import Genotype
+    fx = load('darts_net.pt')
+    torch.manual_seed(fx['seed'])
+    search = Network(fx['C'], 512, fx['layers']).to(DEV)
+    for a, r in zip(search.arch_parameters(), fx['arch']):
+        a.data.copy_(r)
+    searched = search.genotype()
+    assert str(searched) == fx['genotype']
+    every = Genotype(
+        normal=[('sep_conv_3x3', 0), ('max_pool_3x3', 1), ('skip_connect', 0), ('dil_conv_5x5', 2),
+                ('avg_pool_3x3', 1), ('sep_conv_5x5', 3), ('dil_conv_3x3', 2), ('skip_connect', 4)],
+        normal_concat=range(2, 6),
+        reduce=[('max_pool_3x3', 0), ('skip_connect', 1), ('sep_conv_5x5', 0), ('avg_pool_3x3', 2),
+                ('dil_conv_3x3', 1), ('dil_conv_5x5', 0), ('sep_conv_3x3', 3), ('avg_pool_3x3', 1)],
+        reduce_concat=range(2, 6))
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(3, 3, 32, 32, generator=g)
+    for geno in (searched, every):
+        torch.manual_seed(21)
+        net = NetworkDerived(fx['C'], 512, fx['layers'], geno)
+        for n, b in net.named_buffers():                       # non-trivial running statistics for the eval pass
+            if n.endswith('running_mean'):
+                b.normal_(0, 0.1, generator=g)
+            elif n.endswith('running_var'):
+                b.uniform_(0.5, 1.5, generator=g)
+        P = {k: v.clone() for k, v in net.state_dict().items()}
+        net = net.to(DEV)
+        net.eval()
+        with torch.no_grad():
+            ev = net(img.to(DEV))
+        ref_ev = O.derived_forward(img, P, geno, train=False, layers=fx['layers'])
+        assert ev.shape == ref_ev.shape == (3, net.output_ch * 49)
+        assert rel_err(ev, ref_ev) < 1e-4
+        net.train()
+        tr = net(img.to(DEV))
+        Pg = {k: (v.clone().requires_grad_() if v.is_floating_point() and 'running' not in k else v.clone()) for k, v in P.items()}
+        ns = {}
+        ref_tr = O.derived_forward(img, Pg, geno, train=True, new_stats=ns, layers=fx['layers'])
+        assert rel_err(tr, ref_tr) < 1e-4
+        wgt = torch.randn(ref_tr.shape, generator=g)
+        names = [n for n, _ in net.named_parameters()]
+        ref_g = torch.autograd.grad((ref_tr * wgt).sum(), [Pg[n] for n in names])
+        got_g = torch.autograd.grad((tr * wgt.to(DEV)).sum(), [p for _, p in net.named_parameters()])
+        for n, a, r in zip(names, got_g, ref_g):
+            assert rel_err(a, r) < 2e-3, n
+        sd = net.state_dict()
+        for k, v in ns.items():
+            assert rel_err(sd[k], v) < 1e-4, k

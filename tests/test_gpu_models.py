@@ -208,3 +208,40 @@ def test_gru_variant_model_vs_torch(pkg):
     assert rel_err(lg, ref) < 1e-3 and torch.equal(lg.argmax(1).cpu(), ref.argmax(1))
     for n, a, r in zip(names, grads, rg):
         assert rel_err(a, r) < 1e-3, n
+
+
+def test_eval_path_counters_vs_oracle(pkg):
+    """Validation counters (SURVEY f-2; reference experiment.py:314-324, misc.py:42-58): fused argmax + '<unk>' masking +
+    multiple-choice match on the device vs the oracle's restatement; includes ties (first index wins, like torch.max),
+    predictions equal to '<unk>', and an epoch of several ragged batches."""
+    from oracle import vqa_oracle as O
+    from lct_vqa_amd.basic_vqa import misc
+    g = torch.Generator().manual_seed(11)
+    A, K, unk = 37, 10, 1
+    ev = misc.Evaluator(unk, torch.device(DEV))
+    tot = [0.0, 0, 0]
+    nb = 0
+    for B in (1, 7, 64, 5):
+        out = torch.randn(B, A, generator=g)
+        out[0, 3] = out[0, 9] = out[0].max() + 1.0                      # tie: index 3 must win
+        if B > 2:
+            out[2, unk] = out[2].max() + 2.0                            # predicts '<unk>'
+        label = torch.randint(0, A, (B,), generator=g)
+        mc = [torch.randint(0, A, (B,), generator=g) for _ in range(K)]
+        mc[4][0] = 3
+        if B > 2:
+            mc[1][2] = unk                                              # '<unk>' is among the choices: Exp1 hit, Exp2 miss
+        l, c1, c2 = O.val_counters(out.clone(), label, mc, unk)
+        tot[0] += l; tot[1] += c1; tot[2] += c2; nb += 1
+        pred = ev.update(out.to(DEV), label.to(DEV), mc)
+        assert torch.equal(pred.cpu(), out.argmax(1))
+        assert misc.num_correct(pred, mc) == O.num_correct(out.argmax(1), mc)
+    r = ev.result()
+    assert (r['corr_exp1'], r['corr_exp2']) == (tot[1], tot[2])
+    assert r['corr_exp1'] > r['corr_exp2']
+    assert abs(r['loss'] - tot[0] / nb) < 1e-5
+    # question accuracy buckets
+    qp = torch.randn(6, 9, 21, generator=g)
+    q = torch.randint(0, 21, (6, 9), generator=g)
+    q[0, 1:] = qp[0].argmax(1)[:-1]                                     # one fully correct question
+    assert misc.num_correct_qst(qp.to(DEV), q.to(DEV)) == O.num_correct_qst(qp, q)
