@@ -23,15 +23,19 @@ class ImgEncoder(nn.Module):
         self.model = model
         self.fc = nn.Linear(in_features, embed_size)
 
-    def trunk(self, image):
+    def trunk(self, image, conv_feature=None):
         """The frozen part only (VGG19 minus its last fc, under no_grad): [B,4096].  It does not depend on any
         trainable parameter, so a caller may run it for batch i+1 on a second HIP stream while batch i's
-        head/backward/optimizer runs (bench.py, DESIGN.md section 5.1)."""
+        head/backward/optimizer runs (bench.py, DESIGN.md section 3.7)."""
         with torch.no_grad():
-            return self.model(image)
+            return self.model(image, conv_feature)
 
-    def forward(self, image, trunk_feature=None):
-        img_feature = self.trunk(image) if trunk_feature is None else trunk_feature
+    def conv_features(self, image):
+        """vgg19.features + avgpool of the frozen trunk (no dropout in it): shareable between forwards of one batch."""
+        return self.model.conv_features(image)
+
+    def forward(self, image, trunk_feature=None, conv_feature=None):
+        img_feature = self.trunk(image, conv_feature) if trunk_feature is None else trunk_feature
         img_feature = ops.linear(img_feature, self.fc.weight, self.fc.bias)
         return ops.L2NormFn.apply(img_feature)
 
@@ -90,8 +94,8 @@ class VqaModel(nn.Module):
         z = ops.FusionFc1Fn.apply(img_feature, qst_feature, self.fc1.weight, self.fc1.bias, m1, scale, m2, scale)
         return ops.linear(z, self.fc2.weight, self.fc2.bias)
 
-    def forward(self, img, qst, trunk_feature=None):
-        img_feature = self.img_encoder(img, trunk_feature)
+    def forward(self, img, qst, trunk_feature=None, conv_feature=None):
+        img_feature = self.img_encoder(img, trunk_feature, conv_feature)
         qst_feature = self.qst_encoder(qst)
         return self._head(img_feature, qst_feature)
 
@@ -112,8 +116,12 @@ class VqaModel(nn.Module):
         return ops.cross_entropy(ans_out, labels)
 
     def _soft_loss(self, images, questions, labels, pseudo_qst, pseudo_labels):
-        ans_out_1 = self(images, questions)
+        """reference models.py:118-125.  Both forwards see the same images through the same frozen trunk: its
+        convolutional part (deterministic, 98 % of a forward) is evaluated once; the classifier with its two live
+        dropouts and everything after it run per forward, in the reference's order (so do the mask draws)."""
+        conv = self.img_encoder.conv_features(images)
+        ans_out_1 = self(images, questions, conv_feature=conv)
         loss_1 = ops.cross_entropy(ans_out_1, labels)
-        ans_out_2 = self(images, pseudo_qst)
+        ans_out_2 = self(images, pseudo_qst, conv_feature=conv)
         loss_2 = softXEnt(ans_out_2, pseudo_labels)
         return loss_1 + _config.active().W_LAMBDA * loss_2

@@ -723,10 +723,12 @@ def vgg_features_forward(image, convs, fuse_pool=True, keep=None):
     return flat, (H, W, Cl)
 
 
-def vgg_trunk_forward(image, convs, fcs, train):
+def vgg_trunk_forward(image, convs, fcs, train, conv_feature=None):
     """torchvision vgg19 (reference basic_vqa/models.py:23-28,36), forward only (frozen trunk).
-    fcs: list of (weight, bias, act, drop_p) for the classifier.  Returns [B, fcs[-1] out features]."""
-    x, _ = vgg_features_forward(image, convs, fuse_pool=True, keep=None)
+    fcs: list of (weight, bias, act, drop_p) for the classifier.  Returns [B, fcs[-1] out features].
+    conv_feature: the flattened features+avgpool output [B, 25088] of an earlier call on the same image and weights
+    (deterministic: the dropouts live in the classifier, which is always re-run)."""
+    x = conv_feature if conv_feature is not None else vgg_features_forward(image, convs, fuse_pool=True, keep=None)[0]
     B, dev = x.shape[0], x.device
     for (w, b, act, drop_p) in fcs:
         m = dropout_mask((B, w.shape[0]), dev, drop_p) if (train and drop_p > 0) else None

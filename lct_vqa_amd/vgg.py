@@ -64,12 +64,21 @@ class VGG(nn.Module):
             fcs.append((lin.weight, lin.bias, act, p))
         return convs, fcs
 
-    def forward(self, x):
+    def conv_features(self, x):
+        """features + avgpool + flatten of a trunk that needs no gradient: [B, 512*7*7].  Deterministic (no dropout), so
+        a caller that evaluates the same frozen trunk on the same batch twice may pass it back as `conv_feature`."""
+        convs, _ = self._plan()
+        with torch.no_grad():
+            return ops.vgg_features_forward(x, convs, fuse_pool=True, keep=None)[0]
+
+    def forward(self, x, conv_feature=None):
         convs, fcs = self._plan()
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not needs_grad:
             with torch.no_grad():
-                return ops.vgg_trunk_forward(x, convs, fcs, True)
+                return ops.vgg_trunk_forward(x, convs, fcs, True, conv_feature)
+        if conv_feature is not None:
+            raise RuntimeError('conv_feature can only be re-used with a trunk that needs no gradient')
         # trainable trunk (reference models_lct.py:62-63): autograd through the HIP backward kernels
         plan = ['M' if isinstance(c, str) else 'C' for c in convs]
         params = [t for c in convs if not isinstance(c, str) for t in c]
