@@ -53,6 +53,14 @@ int lctvqa_conv3x3_wino_supported(int B, int H, int W, int Cin, int Cout, int po
 int lctvqa_conv3x3_wino_pack_weights(const float* w_oihw, float* u_packed, int Cout, int Cin, int flip_transpose, void* stream);
 int lctvqa_conv3x3_wino_nhwc(const float* x, const float* u_packed, const float* bias, float* y, int B, int H, int W, int Cin,
                              int Cout, int relu, int pool, void* stream);
+/* Winograd F(4x4,3x3) variant (fp32, 4x fewer MFMA FLOPs than direct; H, W multiples of 4; differs from the direct kernel by
+ * fp32 rounding of the larger transforms, ~4e-6 of the layer's largest output).  Same calling convention as the F(2x2,3x3)
+ * entry points above; u_packed holds lctvqa_conv3x3_wino4_packed_elems floats. */
+long lctvqa_conv3x3_wino4_packed_elems(int Cout, int Cin);
+int lctvqa_conv3x3_wino4_supported(int B, int H, int W, int Cin, int Cout, int pool);
+int lctvqa_conv3x3_wino4_pack_weights(const float* w_oihw, float* u_packed, int Cout, int Cin, int flip_transpose, void* stream);
+int lctvqa_conv3x3_wino4_nhwc(const float* x, const float* u_packed, const float* bias, float* y, int B, int H, int W, int Cin,
+                              int Cout, int relu, int pool, void* stream);
 /* first layer: NCHW image [B,3,H,W] (the layout the reference's loaders produce,
  * data_loader_v2.py:82-86) -> NHWC [B,H,W,Cout], conv3x3 + bias + ReLU */
 int lctvqa_conv3x3_first_nchw(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc, int B,

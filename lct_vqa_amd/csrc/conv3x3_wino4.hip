@@ -1,0 +1,447 @@
+// Winograd F(4x4,3x3) convolution for the VGG19 trunk on gfx950, fp32 in / fp32 accumulate, NHWC.
+//
+// Same operator as conv3x3.hip / conv3x3_wino.hip (nn.Conv2d(Cin,Cout,3,padding=1) + bias + ReLU [+ MaxPool2d(2,2)],
+// reference basic_vqa/models.py:36 via torchvision vgg19.features) with the larger minimal-filtering tile
+//     Y(4x4) = A^T [ sum_cin (G g G^T)(6x6) (.) (B^T d B)(6x6) ] A          (Lavin & Gray 2016, F(4x4,3x3))
+// = 36 multiplies per 4x4 output tile and (cin,cout) pair instead of 144: 4x fewer MFMA FLOPs than the direct
+// algorithm (F(2x2,3x3): 2.25x).  All arithmetic is fp32; the transforms use the small integers / fractions of the
+// published matrices, which costs about one decimal digit: measured 3-4e-6 max error relative to the layer's largest
+// output on the trunk's shapes (direct fp32: 2-3e-7; tools/sim_f43.py), far inside the 1e-3 logit gate.
+//
+// Structure (one workgroup = 8 waves, two per SIMD, 256 registers each):
+//  * a workgroup owns 32 tiles (TY x TX tiles of 4x4 output pixels) x 64 output channels.  Wave (xg, cg) accumulates 9 of
+//    the 36 transformed-domain GEMMs (xi*6+nu = 9 xg .. 9 xg + 8) for 32 tiles x 32 channels = 144 accumulator
+//    registers; the second wave of a SIMD fills the first one's issue gaps;
+//  * K loop in 8-channel chunks: raw halo patch HBM->LDS by LDS-DMA (planar per channel quad, stacked rows with one
+//    shared zero row per image boundary); input transform B^T d B by waves 0..5: thread = (tile, channel quad), wave =
+//    output column nu, so every wave runs straight-line code for its column; V[36][2 quads][32 tiles][4] double
+//    buffered, the transform of chunk c+1 cut into slices pinned between the MFMAs of chunk c; weights U = G g G^T
+//    straight from L2 into one register slot per (xi,nu), refilled a whole phase ahead (counted vmcnt, bare barrier);
+//  * epilogue: the 36 accumulators of a (tile, channel) live in 4 waves: they are exchanged through LDS in 4 rounds
+//    (8 (channel group, register) units = 73.7 KB per round), each wave output-transforms A^T M A one unit per round,
+//    adds bias, ReLU, optional 2x2 max-pool in registers, NHWC stores 128 B contiguous per half wave.
+#include "common.h"
+
+__device__ __attribute__((aligned(64))) float g_zero_page_w4[64];
+
+// U[cout/32][Cin/8][36 xi*6+nu][2 quads][32 cout][4 ch] = G g G^T.   flip_t: weights of the dgrad convolution
+// (g'[ci][co][ky][kx] = g[co][ci][2-ky][2-kx]; Cout/Cin then name the dgrad conv's own output/input channels).
+__global__ void wino4_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int flip_t) {
+  const long total = (long)Cout * Cin * 36;
+  const int NCH = Cin / 8;
+  const float Gm[6][3] = {{0.25f, 0.f, 0.f},
+                          {-1.f / 6, -1.f / 6, -1.f / 6},
+                          {-1.f / 6, 1.f / 6, -1.f / 6},
+                          {1.f / 24, 1.f / 12, 1.f / 6},
+                          {1.f / 24, -1.f / 12, 1.f / 6},
+                          {0.f, 0.f, 1.f}};
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const int e = o & 3, j = (o >> 2) & 31, h = (o >> 7) & 1;
+    const long rest = o >> 8;
+    const int xn = rest % 36;
+    const long rest2 = rest / 36;
+    const int chunk = rest2 % NCH, grp = rest2 / NCH;
+    const int co = grp * 32 + j, ci = chunk * 8 + h * 4 + e;
+    const int xi = xn / 6, nu = xn % 6;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      float t = 0.f;                                           // (g G^T)[a][nu]
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        const float gv = flip_t ? w[((long)ci * Cout + co) * 9 + (2 - a) * 3 + (2 - b)] : w[((long)co * Cin + ci) * 9 + a * 3 + b];
+        t += gv * Gm[nu][b];
+      }
+      acc += Gm[xi][a] * t;
+    }
+    u[o] = acc;
+  }
+}
+
+template <int TY, int TX, int GMAX, bool POOL>
+__global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __restrict__ x, const float* __restrict__ up,
+                                                               const float* __restrict__ bias, float* __restrict__ y, int Btot,
+                                                               int H, int W, int Cin, int Cout, int relu, int G) {
+  constexpr int NTILE = TY * TX;
+  static_assert(NTILE <= 32, "patch holds too many tiles");
+  constexpr int TH = 4 * TY, TW = 4 * TX, RS = TW + 2;
+  constexpr int HRMAX = TH + 2 + GMAX;
+  constexpr int PMAX = HRMAX * RS;
+  constexpr int AROUNDS = (PMAX + 63) / 64;
+  constexpr int PLANE = AROUNDS * 64 * 4;                       // floats per channel-quad plane of the raw patch
+  constexpr int RAWSZ = 2 * PLANE;                              // 8 channels
+  constexpr int VSZ = 36 * 256;                                 // floats per V buffer: [36][2 quads][32 tiles][4]
+  constexpr int NPC = (2 * AROUNDS + 7) / 8;                    // LDS-DMA pieces per wave and chunk
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* V = smem;                    // [2][VSZ]   (re-used as the exchange buffer of the epilogue)
+  float* raw = smem + 2 * VSZ;        // [2][RAWSZ]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = wave & 1, xg = wave >> 1;
+  const int j = lane & 31, h = lane >> 5;
+  const int NT = Cout / 64;
+  // workgroups are dealt to the 8 XCDs round-robin: the NT workgroups reading one input patch share an XCD (its L2)
+  const int n_tile = (blockIdx.x >> 3) % NT, m_tile = ((blockIdx.x >> 3) / NT) * 8 + (blockIdx.x & 7);
+  const int CT = W / TW;
+  if (m_tile >= ((Btot * H + TH - 1) / TH) * CT) return;
+  const int ct = m_tile % CT, rt = m_tile / CT;
+  const int R0 = rt * TH, x0 = ct * TW;
+  const int Rtot = Btot * H;
+  const int n0img = R0 / H, y0 = R0 % H;
+  const int NCH = Cin / 8;
+  const int PLIVE = (TH + 2 + G) * RS;
+
+  // ---- raw patch staging: piece pc = quad * AROUNDS + round, this wave takes pc = wave, wave + 8, ...
+  int aoff[NPC], pdst[NPC];
+#pragma unroll
+  for (int k = 0; k < NPC; k++) {
+    const int pc = wave + 8 * k;
+    const int q = pc / AROUNDS, r = pc % AROUNDS;
+    const int p = r * 64 + lane;
+    const int hr = p / RS, hx = p % RS;
+    const int xx = x0 - 1 + hx;
+    int yv = y0 - 1 + hr;
+    int n = n0img;
+    while (yv > H) { yv -= (H + 1); n++; }
+    const bool ok = (p < PLIVE) && (yv >= 0) && (yv < H) && (n < Btot) && (xx >= 0) && (xx < W);
+    aoff[k] = ok ? (((n * H + yv) * W + xx) * Cin + q * 4) : -1;
+    pdst[k] = (pc < 2 * AROUNDS && r * 64 < PLIVE) ? (q * PLANE + r * 256) : -1;      // wave-uniform
+  }
+  auto stage_raw = [&](int chunk, float* dst) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NPC; k++) {
+      if (pdst[k] >= 0) {
+        const float* src = (aoff[k] >= 0) ? (x + (long)aoff[k] + chunk * 8) : g_zero_page_w4;
+        glds16_opaque(src, dst + pdst[k]);
+      }
+    }
+  };
+
+  // ---- input transform: thread = (tile tt, channel quad tc), wave = output column nu (waves 6, 7: none)
+  const int tt = lane & 31, tc = lane >> 5;
+  int tbase = tc * PLANE;
+  if (tt < NTILE) {
+    const int ty = tt / TX, tx = tt % TX;
+    const int g = (y0 + 4 * ty) / H;                            // image boundaries (= shared zero rows) above this tile
+    tbase = tc * PLANE + ((4 * ty + g) * RS + 4 * tx) * 4;
+  }
+  const int vwoff = tc * 128 + tt * 4;                          // + (xi*6+nu)*256
+  f32x4 Tc[6];                                                  // (d B)[y][nu], y = 0..5
+  // row yy of the 6x6 patch: the pixels column NU of d B needs, combined with that column of B (= row of B^T).  Load and
+  // combine sit in one slice: the LDS latency in between is covered by the SIMD's other wave.
+  auto trow = [&](const float* rw, int yy, int nu) __attribute__((always_inline)) {
+    const float* p0 = rw + tbase + yy * RS * 4;
+    f32x4 r;
+    if (nu == 0 || nu == 5) {                                                   // 4 d0 - 5 d2 + d4  |  4 d1 - 5 d3 + d5
+      const float* p = p0 + (nu == 0 ? 0 : 4);
+      const f32x4 l0 = *(const f32x4*)(p), l1 = *(const f32x4*)(p + 8), l2 = *(const f32x4*)(p + 16);
+      r = 4.f * l0 - 5.f * l1 + l2;
+    } else {
+      const f32x4 l0 = *(const f32x4*)(p0 + 4), l1 = *(const f32x4*)(p0 + 8), l2 = *(const f32x4*)(p0 + 12), l3 = *(const f32x4*)(p0 + 16);
+      if (nu == 1) r = (l3 - 4.f * l1) + (l2 - 4.f * l0);                       // (d4 - 4 d2) + (d3 - 4 d1)
+      else if (nu == 2) r = (l3 - 4.f * l1) - (l2 - 4.f * l0);
+      else if (nu == 3) r = (l3 - l1) + 2.f * (l2 - l0);                        // (d4 - d2) + 2 (d3 - d1)
+      else r = (l3 - l1) - 2.f * (l2 - l0);
+    }
+    asm volatile("" : "+v"(r));                                 // keep the slice where it is written
+    Tc[yy] = r;
+  };
+  // column pass of column nu, slice s = 0..3: xi = 0 | 1,2 | 3,4 | 5
+  auto tcol = [&](float* Vd, int nu, int s) __attribute__((always_inline)) {
+    float* v = Vd + nu * 256 + vwoff;
+    if (s == 0) {
+      *(f32x4*)(v) = 4.f * Tc[0] - 5.f * Tc[2] + Tc[4];
+    } else if (s == 1) {
+      const f32x4 a = Tc[4] - 4.f * Tc[2], b = Tc[3] - 4.f * Tc[1];
+      *(f32x4*)(v + 1 * 6 * 256) = a + b;
+      *(f32x4*)(v + 2 * 6 * 256) = a - b;
+    } else if (s == 2) {
+      const f32x4 c = Tc[4] - Tc[2], e = 2.f * (Tc[3] - Tc[1]);
+      *(f32x4*)(v + 3 * 6 * 256) = c + e;
+      *(f32x4*)(v + 4 * 6 * 256) = c - e;
+    } else {
+      *(f32x4*)(v + 5 * 6 * 256) = 4.f * Tc[1] - 5.f * Tc[3] + Tc[5];
+    }
+  };
+  auto transform_all = [&](const float* rw, float* Vd, int nu) __attribute__((always_inline)) {
+    if (nu > 5) return;
+#pragma unroll
+    for (int yy = 0; yy < 6; yy++) {
+      trow(rw, yy, nu);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) tcol(Vd, nu, s);
+  };
+  // transform work of the main loop cut into slices pinned between the MFMAs of step q (slot i = 0, 1)
+  auto tslice = [&](const float* rwn, float* Vn, int q, int i, int nu) __attribute__((always_inline)) {
+    if (nu > 5) return;
+    // steps 0..5, slot 1: row q; steps 7, 8: the four column slices
+    if (i == 1 && q < 6) trow(rwn, q, nu);
+    if (q >= 7) tcol(Vn, nu, (q - 7) * 2 + i);
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int q = 0; q < 9; q++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
+
+  // packed weights: [32-channel group][chunk][36][2 quads][32 ch][4]; this wave: group 2 n_tile + cg, planes 9 xg ..
+  const long UCH = 36 * 256;                                    // floats per (group, chunk)
+  const float* ub = up + (long)(n_tile * 2 + cg) * NCH * UCH + (xg * 9) * 256 + (h * 32 + j) * 4;
+  const float* va = V + (xg * 9) * 256 + h * 128 + j * 4;
+
+  // weights: ring of three (xi,nu) slots; the slot of step q is refilled right behind its MFMAs with the weights of step
+  // q+3 (this chunk's for q < 6, the next chunk's q-6 otherwise).  A slot per step (a whole phase of lead, as in the
+  // F(2x2,3x3) kernels) would need 24 more registers than the 256 of a wave at two waves per SIMD.
+  f32x4 Bw[3];
+  f32x4 Aa, Ab;
+#ifndef W4_X_NOT
+#define W4_X_NOT 0
+#endif
+#ifndef W4_X_NOB
+#define W4_X_NOB 0
+#endif
+#ifndef W4_X_NORAW
+#define W4_X_NORAW 0
+#endif
+#ifndef W4_X_NOEPI
+#define W4_X_NOEPI 0
+#endif
+#define W4_SB() __builtin_amdgcn_sched_barrier(0)
+#define W4_MF(Q, ACUR, E) acc[Q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ACUR[E], Bw[(Q) % 3][E], acc[Q], 0, 0, 0)
+  // one (xi,nu): 4 MFMAs (8 channels); the other work is pinned between them in source order
+#define W4_STEP(Q, ACUR, ANEXT, NXT, NU)                                                               \
+  {                                                                                                   \
+    W4_MF(Q, ACUR, 0);                                                                                \
+    if ((Q) + 1 < 9) ANEXT = *(const f32x4*)(vc + ((Q) + 1) * 256);                                    \
+    W4_SB();                                                                                          \
+    W4_MF(Q, ACUR, 1);                                                                                \
+    if (NXT && !W4_X_NOT) tslice(rwn, Vn, Q, 0, NU);                                                  \
+    W4_SB();                                                                                          \
+    W4_MF(Q, ACUR, 2);                                                                                \
+    if (NXT && !W4_X_NOT) tslice(rwn, Vn, Q, 1, NU);                                                  \
+    W4_SB();                                                                                          \
+    W4_MF(Q, ACUR, 3);                                                                                \
+    if (W4_X_NOB) {                                                                                   \
+    } else if ((Q) < 6) {                                                                             \
+      Bw[(Q) % 3] = *(const f32x4*)(uc + ((Q) + 3) * 256);                                             \
+    } else if (NXT) {                                                                                 \
+      Bw[(Q) % 3] = *(const f32x4*)(uc + UCH + ((Q) - 6) * 256);                                       \
+    }                                                                                                 \
+    W4_SB();                                                                                          \
+  }
+#define W4_PHASE(NXT, NU)                                                                             \
+  {                                                                                                   \
+    const float* vc = va + (chunk & 1) * VSZ;                                                         \
+    float* Vn = V + ((chunk + 1) & 1) * VSZ;                                                          \
+    const float* rwn = raw + ((chunk + 1) & 1) * RAWSZ;                                               \
+    const float* uc = ub + (long)chunk * UCH;                                                         \
+    Aa = *(const f32x4*)(vc);                                                                         \
+    W4_STEP(0, Aa, Ab, NXT, NU) W4_STEP(1, Ab, Aa, NXT, NU) W4_STEP(2, Aa, Ab, NXT, NU)                \
+    W4_STEP(3, Ab, Aa, NXT, NU) W4_STEP(4, Aa, Ab, NXT, NU) W4_STEP(5, Ab, Aa, NXT, NU)                \
+    W4_STEP(6, Aa, Ab, NXT, NU) W4_STEP(7, Ab, Aa, NXT, NU) W4_STEP(8, Aa, Ab, NXT, NU)                \
+  }
+  // End of a phase: the raw patch of chunk+2 (LDS-DMA issued at the start of the phase) must have landed; the 9 weight
+  // loads of the next chunk, issued after it, stay in flight.  Bare barrier (not __syncthreads(), whose fence would
+  // drain them); lgkmcnt(0) retires the transform's LDS stores.
+#define W4_MAIN(NU)                                                                                   \
+  {                                                                                                   \
+    int chunk = 0;                                                                                    \
+    for (; chunk < NCH - 1; chunk++) {                                                                \
+      W4_PHASE(true, NU)                                                                              \
+      asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");                        \
+      if (chunk + 3 < NCH && !W4_X_NORAW) stage_raw(chunk + 3, raw + ((chunk + 1) & 1) * RAWSZ);      \
+    }                                                                                                 \
+    W4_PHASE(false, NU)                                                                               \
+  }
+
+  stage_raw(0, raw);
+  if (NCH > 1) stage_raw(1, raw + RAWSZ);
+#pragma unroll
+  for (int q = 0; q < 3; q++) Bw[q] = *(const f32x4*)(ub + q * 256);
+  // builtin (not asm): the compiler's waitcnt bookkeeping then sees the prologue loads retired and derives the counted
+  // waits of the loop from the loop's own issue order.  0x0F70 = vmcnt(0), expcnt/lgkmcnt untouched.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  transform_all(raw, V, wave);
+  __syncthreads();
+  if (NCH > 2) stage_raw(2, raw);
+
+  switch (wave) {
+    case 0: W4_MAIN(0) break;
+    case 1: W4_MAIN(1) break;
+    case 2: W4_MAIN(2) break;
+    case 3: W4_MAIN(3) break;
+    case 4: W4_MAIN(4) break;
+    case 5: W4_MAIN(5) break;
+    default: W4_MAIN(6) break;
+  }
+#undef W4_MAIN
+#undef W4_PHASE
+#undef W4_STEP
+#undef W4_MF
+#undef W4_SB
+
+  // ---- epilogue: exchange the 36 accumulators of each (tile, channel) through LDS, 4 rounds of 8 (channel group,
+  // register) units; wave w output-transforms unit w of a round
+  float* xch = V;                                               // [8 units][36][64 lanes] floats = 73.7 KB = both V buffers
+  const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+  for (int rnd = 0; rnd < (W4_X_NOEPI ? (relu == 12345 ? 4 : 0) : 4); rnd++) {
+    __syncthreads();                                            // V (first round) / the previous round's reads are done
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+      float* d = xch + ((cg * 4) * 36 + xg * 9 + q) * 64 + lane;
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) d[rr * 36 * 64] = acc[q][4 * rnd + rr];
+    }
+    __syncthreads();
+    {
+      const int unit = wave, c = unit >> 2, rr = unit & 3;
+      const int r = 4 * rnd + rr;
+      const float* s = xch + (unit * 36) * 64 + lane;
+      // R[xi][jj] = sum_nu M[xi][nu] A[nu][jj]  (6 x 4), then Y[i][jj] = sum_xi A^T[i][xi] R[xi][jj]
+      float Rm[6][4];
+#pragma unroll
+      for (int xi = 0; xi < 6; xi++) {
+        const float m0 = s[(xi * 6 + 0) * 64], m1 = s[(xi * 6 + 1) * 64], m2 = s[(xi * 6 + 2) * 64], m3 = s[(xi * 6 + 3) * 64],
+                    m4 = s[(xi * 6 + 4) * 64], m5 = s[(xi * 6 + 5) * 64];
+        const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+        Rm[xi][0] = m0 + s1 + s2;
+        Rm[xi][1] = d1 + 2.f * d2;
+        Rm[xi][2] = s1 + 4.f * s2;
+        Rm[xi][3] = d1 + 8.f * d2 + m5;
+      }
+      const int co = (n_tile * 2 + c) * 32 + j;
+      const float bv = bias ? bias[co] : 0.f;
+      float Y[4][4];
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) {
+        const float s1 = Rm[1][jj] + Rm[2][jj], d1 = Rm[1][jj] - Rm[2][jj], s2 = Rm[3][jj] + Rm[4][jj], d2 = Rm[3][jj] - Rm[4][jj];
+        Y[0][jj] = Rm[0][jj] + s1 + s2 + bv;
+        Y[1][jj] = d1 + 2.f * d2 + bv;
+        Y[2][jj] = s1 + 4.f * s2 + bv;
+        Y[3][jj] = d1 + 8.f * d2 + Rm[5][jj] + bv;
+      }
+      if (relu) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 4; b++) Y[a][b] = fmaxf(Y[a][b], 0.f);
+      }
+      const int tile = (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (tile < NTILE) {
+        const int ty = tile / TX, tx = tile % TX;
+        const int R = R0 + 4 * ty;
+        if (R < Rtot) {
+          if (POOL) {
+            const int n = R / H, yy = R % H;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+              for (int b = 0; b < 2; b++) {
+                const float v = fmaxf(fmaxf(Y[2 * a][2 * b], Y[2 * a][2 * b + 1]), fmaxf(Y[2 * a + 1][2 * b], Y[2 * a + 1][2 * b + 1]));
+                const long opix = ((long)n * Ho + (yy >> 1) + a) * Wo + ((x0 >> 1) + 2 * tx + b);
+                y[opix * Cout + co] = v;
+              }
+          } else {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+              for (int b = 0; b < 4; b++) y[((long)(R + a) * W + x0 + 4 * tx + b) * Cout + co] = Y[a][b];
+          }
+        }
+      }
+    }
+  }
+}
+
+static int w4_max_boundaries(int H, int TH, long Rtot) {
+  int best = 0;
+  long lim = Rtot < (long)H * TH * 2 ? Rtot : (long)H * TH * 2;
+  for (long R0 = 0; R0 < lim; R0 += TH) {
+    long last = R0 + TH - 1 < Rtot - 1 ? R0 + TH - 1 : Rtot - 1;
+    int g = (int)(last / H - R0 / H);
+    if (g > best) best = g;
+  }
+  return best;
+}
+
+// patch (TY x TX tiles of 4x4 pixels): 1 = (4,8) 16x32 px, 2 = (8,4) 32x16, 3 = (16,2) 64x8, 4 = (32,1) 128x4
+static int w4_select(int W) {
+  if (W % 32 == 0) return 1;
+  if (W % 16 == 0) return 2;
+  if (W % 8 == 0) return 3;
+  if (W % 4 == 0) return 4;
+  return 0;
+}
+static int w4_th(int sel) { return sel == 1 ? 16 : sel == 2 ? 32 : sel == 3 ? 64 : 128; }
+static int w4_gmax(int sel) { return sel == 4 ? 5 : 2; }
+
+template <int TY, int TX, int GMAX>
+static int launch_wino4(const float* x, const float* up, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
+                        int relu, int pool, int G, hipStream_t st) {
+  constexpr int RS = 4 * TX + 2;
+  constexpr int AROUNDS = ((4 * TY + 2 + GMAX) * RS + 63) / 64;
+  constexpr int RAWSZ = 2 * AROUNDS * 64 * 4;
+  constexpr int VSZ = 36 * 256;
+  size_t lds = (size_t)(2 * VSZ + 2 * RAWSZ) * sizeof(float);
+  long Rtot = (long)B * H;
+  const int mtiles = cdiv(Rtot, 4 * TY) * (W / (4 * TX));
+  dim3 grid(((mtiles + 7) / 8) * 8 * (Cout / 64));
+  if (pool) {
+    auto k = conv3x3_wino4_kernel<TY, TX, GMAX, true>;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(512), lds, st, x, up, bias, y, B, H, W, Cin, Cout, relu, G);
+  } else {
+    auto k = conv3x3_wino4_kernel<TY, TX, GMAX, false>;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(512), lds, st, x, up, bias, y, B, H, W, Cin, Cout, relu, G);
+  }
+  return lct_check_launch("conv3x3_wino4");
+}
+
+extern "C" {
+
+long lctvqa_conv3x3_wino4_packed_elems(int Cout, int Cin) { return (long)Cout * Cin * 36; }
+
+int lctvqa_conv3x3_wino4_supported(int B, int H, int W, int Cin, int Cout, int pool) {
+  if (Cin % 8 || Cin < 16 || Cout % 64 || (H & 3) || (W & 3)) return 0;
+  const int sel = w4_select(W);
+  if (!sel) return 0;
+  if (w4_max_boundaries(H, w4_th(sel), (long)B * H) > w4_gmax(sel)) return 0;
+  if ((long)B * H * W * Cin >= (1L << 31)) return 0;
+  return 1;
+}
+
+int lctvqa_conv3x3_wino4_pack_weights(const float* w_oihw, float* u_packed, int Cout, int Cin, int flip_transpose, void* stream) {
+  LCT_REQUIRE(Cin % 8 == 0 && Cout % 32 == 0, "wino4_pack_weights: need Cin%%8==0, Cout%%32==0 (got %d,%d)", Cin, Cout);
+  long total = (long)Cout * Cin * 36;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(wino4_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, u_packed, Cout, Cin, flip_transpose);
+  return lct_check_launch("wino4_pack");
+}
+
+int lctvqa_conv3x3_wino4_nhwc(const float* x, const float* u_packed, const float* bias, float* y, int B, int H, int W, int Cin,
+                              int Cout, int relu, int pool, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  LCT_REQUIRE(lctvqa_conv3x3_wino4_supported(B, H, W, Cin, Cout, pool), "conv3x3_wino4: unsupported shape B=%d H=%d W=%d Cin=%d Cout=%d",
+              B, H, W, Cin, Cout);
+  const int sel = w4_select(W);
+  const int G = w4_max_boundaries(H, w4_th(sel), (long)B * H);
+  switch (sel) {
+    case 1: return launch_wino4<4, 8, 2>(x, u_packed, bias, y, B, H, W, Cin, Cout, relu, pool, G, st);
+    case 2: return launch_wino4<8, 4, 2>(x, u_packed, bias, y, B, H, W, Cin, Cout, relu, pool, G, st);
+    case 3: return launch_wino4<16, 2, 2>(x, u_packed, bias, y, B, H, W, Cin, Cout, relu, pool, G, st);
+    case 4: return launch_wino4<32, 1, 5>(x, u_packed, bias, y, B, H, W, Cin, Cout, relu, pool, G, st);
+    default: break;
+  }
+  lct_set_error("conv3x3_wino4: no tiling");
+  return LCT_EUNSUPPORTED;
+}
+
+}  // extern "C"

@@ -19,12 +19,14 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--only', default='')
+    ap.add_argument('--f43', action='store_true', help='time the F(4x4,3x3) entry points (lctvqa_conv3x3_wino4_*)')
     args = ap.parse_args()
     only = [int(v) for v in args.only.split(',')] if args.only else None
     dev = torch.device('cuda')
     dlls = [ctypes.CDLL(os.path.abspath(p)) for p in args.libs]
+    sfx = 'wino4' if args.f43 else 'wino'
     for d in dlls:
-        d.lctvqa_conv3x3_wino_packed_elems.restype = ctypes.c_long
+        getattr(d, f'lctvqa_conv3x3_{sfx}_packed_elems').restype = ctypes.c_long
     B = args.batch
     P = ctypes.c_void_p
     st = lambda: P(torch.cuda.current_stream().cuda_stream)
@@ -32,21 +34,23 @@ def main():
     for (H, Cin, Cout, pool) in LAYERS:
         if only and H not in only:
             continue
+        if not getattr(dlls[0], f'lctvqa_conv3x3_{sfx}_supported')(B, H, H, Cin, Cout, pool):
+            continue
         xin = torch.randn(B, H, H, Cin, device=dev)
         wt = torch.randn(Cout, Cin, 3, 3, device=dev) * (2.0 / (9 * Cin)) ** 0.5
         bs = torch.zeros(Cout, device=dev)
-        up = torch.empty(dlls[0].lctvqa_conv3x3_wino_packed_elems(Cout, Cin), device=dev)
+        up = torch.empty(getattr(dlls[0], f'lctvqa_conv3x3_{sfx}_packed_elems')(Cout, Cin), device=dev)
         Ho = H // 2 if pool else H
         out = torch.empty(B, Ho, Ho, Cout, device=dev)
         fl = 2.0 * B * H * H * Cout * Cin * 9
         times = [[] for _ in dlls]
         for rnd in range(args.rounds + 1):
             for i, d in enumerate(dlls):
-                assert d.lctvqa_conv3x3_wino_pack_weights(P(wt.data_ptr()), P(up.data_ptr()), Cout, Cin, 0, st()) == 0
+                assert getattr(d, f'lctvqa_conv3x3_{sfx}_pack_weights')(P(wt.data_ptr()), P(up.data_ptr()), Cout, Cin, 0, st()) == 0
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):
-                    rc = d.lctvqa_conv3x3_wino_nhwc(P(xin.data_ptr()), P(up.data_ptr()), P(bs.data_ptr()), P(out.data_ptr()),
+                    rc = getattr(d, f'lctvqa_conv3x3_{sfx}_nhwc')(P(xin.data_ptr()), P(up.data_ptr()), P(bs.data_ptr()), P(out.data_ptr()),
                                                     B, H, H, Cin, Cout, 1, pool, st())
                     assert rc == 0
                 e1.record(); torch.cuda.synchronize()
