@@ -42,8 +42,8 @@ def parse():
     ap.add_argument('--workload', default='w', choices=['w', 'lct'],
                     help="'w' = BASELINE configs[1] (default, the headline metric); 'lct' = stage-1 + stage-2 step of "
                          "experiment.py:216-268 (EF fixed encoder + generate + W soft loss), reported under its own metric name")
-    ap.add_argument('--conv-algo', default=None, choices=['winograd', 'direct'],
-                    help='trunk convolution algorithm (default: LCTVQA_CONV_ALGO or winograd, fp32 either way)')
+    ap.add_argument('--conv-algo', default=None, choices=['winograd', 'winograd2', 'direct'],
+                    help='trunk convolution algorithm (default: LCTVQA_CONV_ALGO or winograd = F(4x4,3x3) / F(2x2,3x3) / direct by shape; all fp32)')
     return ap.parse_args()
 
 
@@ -237,18 +237,20 @@ def main():
     # ---- roofline of the dominant kernel family (the 15 MFMA conv launches of the VGG19 trunk per step) ----
     # achieved = ALGORITHMIC FLOPs (direct-convolution count 2*B*H*W*Cout*Cin*9) / live HIP-event
     # time of those launches.  With the Winograd kernels the MFMA pipe executes 2.25x fewer FLOPs than that count, so
-    # `frac` can exceed 1; `mfma_executed_*` is what the pipe really ran (its utilisation against the dense fp32 peak).
+    # `frac` can exceed 1; `mfma_executed_*` is what the pipe really ran (its utilisation against the dense fp32 peak):
+    # F(4x4,3x3) executes 1/4 of the direct count, F(2x2,3x3) 1/2.25.
     algo = ops.get_conv_algo()
     tot_flops = sum(r['flops'] for r in conv)
-    tot_exec = sum(r['flops'] / (2.25 if r['name'].startswith('wino') else 1.0) for r in conv)
+    tot_exec = sum(r['flops'] / (4.0 if r['name'].startswith('wino4') else 2.25 if r['name'].startswith('wino') else 1.0) for r in conv)
     tot_ms = sum(r['ms'] for r in conv)
     nlaunch = max(1, len(conv))
     achieved = tot_flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     executed = tot_exec / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     nwino = sum(1 for r in conv if r['name'].startswith('wino'))
+    nw4 = sum(1 for r in conv if r['name'].startswith('wino4'))
     roofline = {'bound': 'mfma',
-                'kernel': ('conv3x3_wino2_kernel / conv3x3_wino3_kernel (Winograd F(2x2,3x3) fp32 MFMA, %d of %d launches) + '
-                           'conv3x3_mfma_kernel (direct)' % (nwino, nlaunch)) if nwino else
+                'kernel': ('conv3x3_wino4_kernel (Winograd F(4x4,3x3), %d launches) + conv3x3_wino2/3_kernel (F(2x2,3x3), %d) + '
+                           'conv3x3_mfma_kernel (direct, %d): fp32 MFMA' % (nw4, nwino - nw4, nlaunch - nwino)) if nwino else
                           'conv3x3_mfma_kernel (direct implicit GEMM, 15 VGG19 layers/step)',
                 'algorithm': algo, 'achieved': round(achieved, 2),
                 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),

@@ -586,16 +586,32 @@ def conv_timer_stop():
 
 
 # ----------------------------------------------------------------------------- VGG19 trunk
-_conv_algo = os.environ.get('LCTVQA_CONV_ALGO', 'winograd')
+_conv_algo = os.environ.get('LCTVQA_CONV_ALGO', 'winograd')   # see set_conv_algo
+
+
+_CONV_ALGOS = ('winograd', 'winograd2', 'direct')
 
 
 def set_conv_algo(name):
-    """'winograd' (F(2x2,3x3) fp32 MFMA kernel where the shape allows, default) or 'direct' (implicit-GEMM kernel)."""
+    """Trunk convolution algorithm, all fp32 on the MFMA pipe:
+    'winograd'  (default) F(4x4,3x3) where the shape allows (H, W multiples of 4), else F(2x2,3x3), else direct;
+    'winograd2' F(2x2,3x3) where the shape allows, else direct;
+    'direct'    the implicit-GEMM kernel only.
+    Returns the previous setting."""
     global _conv_algo
-    if name not in ('winograd', 'direct'):
+    if name not in _CONV_ALGOS:
         raise ValueError(name)
     prev, _conv_algo = _conv_algo, name
     return prev
+
+
+def _wino_variant(B, H, W, Cin, Cout, pool):
+    """'wino4' | 'wino' | None: the Winograd kernel the current algorithm setting selects for this shape."""
+    if _conv_algo == 'winograd' and lib.query('conv3x3_wino4_supported', B, H, W, Cin, Cout, pool):
+        return 'wino4'
+    if _conv_algo in ('winograd', 'winograd2') and lib.query('conv3x3_wino_supported', B, H, W, Cin, Cout, pool):
+        return 'wino'
+    return None
 
 
 def get_conv_algo():
@@ -647,12 +663,14 @@ def _conv_block(cur, w, b, B, H, W, pool, name_timer=True):
     """conv3x3 + bias + ReLU (+ fused 2x2 max pool) on an NHWC activation -> NHWC output."""
     dev = cur.device
     Cout, Cin = w.shape[0], w.shape[1]
-    if _conv_algo == 'winograd' and lib.query('conv3x3_wino_supported', B, H, W, Cin, Cout, pool):
-        up = _packed_weights(w, 'wino', Cout * Cin * 16, lambda dst: lib('conv3x3_wino_pack_weights', w, dst, Cout, Cin, 0))
+    wv = _wino_variant(B, H, W, Cin, Cout, pool)
+    if wv is not None:
+        up = _packed_weights(w, wv, Cout * Cin * (36 if wv == 'wino4' else 16),
+                             lambda dst: lib(f'conv3x3_{wv}_pack_weights', w, dst, Cout, Cin, 0))
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
-        _timed(f'wino{H}x{W}_{Cin}->{Cout}{"+pool" if pool else ""}', 2.0 * B * H * W * Cout * Cin * 9,
-               lambda: lib('conv3x3_wino_nhwc', cur, up, b, out, B, H, W, Cin, Cout, 1, pool))
+        _timed(f'{wv}_{H}x{W}_{Cin}->{Cout}{"+pool" if pool else ""}', 2.0 * B * H * W * Cout * Cin * 9,
+               lambda: lib(f'conv3x3_{wv}_nhwc', cur, up, b, out, B, H, W, Cin, Cout, 1, pool))
         return out
     mfma = lib.query('conv3x3_uses_mfma', B, H, W, Cin, Cout, pool)
     wp = tmp = None
@@ -798,10 +816,11 @@ class VggFeaturesFn(torch.autograd.Function):
             grads[2 * li] = dw
             # dgrad: conv3x3(dz) with W'[ci][co] = flip(W[co][ci])
             dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
-            if _conv_algo == 'winograd' and lib.query('conv3x3_wino_supported', B, H, W, Cout, Cin, 0):
-                up = torch.empty(Cout * Cin * 16, dtype=torch.float32, device=dev)
-                lib('conv3x3_wino_pack_weights', w, up, Cin, Cout, 1)         # dgrad conv: Cout' = Cin, Cin' = Cout
-                lib('conv3x3_wino_nhwc', dz, up, None, dx, B, H, W, Cout, Cin, 0, 0)
+            wv = _wino_variant(B, H, W, Cout, Cin, 0)
+            if wv is not None:
+                up = torch.empty(Cout * Cin * (36 if wv == 'wino4' else 16), dtype=torch.float32, device=dev)
+                lib(f'conv3x3_{wv}_pack_weights', w, up, Cin, Cout, 1)        # dgrad conv: Cout' = Cin, Cin' = Cout
+                lib(f'conv3x3_{wv}_nhwc', dz, up, None, dx, B, H, W, Cout, Cin, 0, 0)
             elif lib.query('conv3x3_uses_mfma', B, H, W, Cout, Cin, 0):
                 wp = torch.empty(Cout * Cin * 9, dtype=torch.float32, device=dev)
                 lib('conv3x3_pack_weights_dgrad', w, wp, Cout, Cin)

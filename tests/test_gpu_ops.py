@@ -17,20 +17,29 @@ def ops(hip_lib):
     return _ops
 
 
-def _wino_case(hip_lib, B, H, W, Cin, Cout, pool, seed=0):
+def _wino_case(hip_lib, B, H, W, Cin, Cout, pool, seed=0, variant='wino', relu=1, flip=0):
+    """Winograd kernel (variant 'wino' = F(2x2,3x3), 'wino4' = F(4x4,3x3)) vs an fp64 torch convolution; flip=1 packs the
+    weights of the dgrad convolution from a forward parameter [Cin][Cout][3][3]."""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    if flip:
+        wf = torch.randn(Cin, Cout, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+        w = wf.flip(2, 3).transpose(0, 1).contiguous()
+    else:
+        wf = w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
     b = torch.randn(Cout, generator=g) * 0.1
-    ref = torch.relu(F.conv2d(x, w, b, padding=1))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if relu:
+        ref = torch.relu(ref)
     if pool:
         ref = F.max_pool2d(ref, 2, 2)
+    ref = ref.float()
     xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
-    up = torch.empty(Cout * Cin * 16, device=DEV)
-    hip_lib('conv3x3_wino_pack_weights', w.to(DEV), up, Cout, Cin, 0)
+    up = torch.empty(hip_lib.query(f'conv3x3_{variant}_packed_elems', Cout, Cin), device=DEV)
+    hip_lib(f'conv3x3_{variant}_pack_weights', wf.to(DEV), up, Cout, Cin, flip)
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     y = torch.full((B, Ho, Wo, Cout), float('nan'), device=DEV)
-    hip_lib('conv3x3_wino_nhwc', xd, up, b.to(DEV), y, B, H, W, Cin, Cout, 1, pool)
+    hip_lib(f'conv3x3_{variant}_nhwc', xd, up, b.to(DEV), y, B, H, W, Cin, Cout, relu, pool)
     torch.cuda.synchronize()
     got = y.permute(0, 3, 1, 2).cpu()
     assert torch.isfinite(got).all()
@@ -48,6 +57,30 @@ def _wino_case(hip_lib, B, H, W, Cin, Cout, pool, seed=0):
 def test_conv3x3_winograd(hip_lib, B, H, W, Cin, Cout, pool):
     assert hip_lib.query('conv3x3_wino_supported', B, H, W, Cin, Cout, pool) == 1
     assert _wino_case(hip_lib, B, H, W, Cin, Cout, pool) < 2e-5
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,pool', [
+    (2, 32, 32, 64, 64, 0), (2, 32, 32, 64, 64, 1),       # patch (4,8) tiles = 16x32 px
+    (3, 16, 16, 64, 128, 0), (3, 16, 16, 128, 128, 1),    # (8,4) = 32x16 px, ragged stacked rows, patch spans images
+    (2, 56, 56, 128, 256, 0), (1, 56, 56, 256, 256, 1),   # (16,2) = 64x8 px
+    (3, 28, 28, 256, 512, 0), (2, 28, 28, 512, 512, 1),   # (32,1) = 128x4 px: up to 5 image boundaries in a patch
+    (5, 20, 20, 64, 64, 1), (1, 64, 48, 16, 64, 0), (2, 24, 8, 32, 128, 1), (6, 4, 4, 128, 64, 0),
+])
+def test_conv3x3_winograd_f4x4(hip_lib, B, H, W, Cin, Cout, pool):
+    """F(4x4,3x3): fp32 with the published transform constants; error budget 3e-5 of the layer's largest output on signed
+    random data (measured <= 2e-5; F(2x2,3x3) and the direct kernel: <= 2e-6), the north-star gate is 1e-3 on logits."""
+    assert hip_lib.query('conv3x3_wino4_supported', B, H, W, Cin, Cout, pool) == 1
+    assert _wino_case(hip_lib, B, H, W, Cin, Cout, pool, variant='wino4') < 3e-5
+    assert _wino_case(hip_lib, B, H, W, Cin, Cout, 0, seed=1, variant='wino4', relu=0, flip=1) < 3e-5      # dgrad form
+
+
+def test_conv3x3_winograd_f4x4_full_res_and_limits(hip_lib):
+    for (H, Cin, Cout, pool) in [(224, 64, 64, 1), (112, 64, 128, 0)]:
+        assert _wino_case(hip_lib, 1, H, H, Cin, Cout, pool, variant='wino4') < 3e-5
+    for (H, Cin, Cout, pool) in [(224, 64, 64, 1), (112, 128, 128, 1), (56, 256, 256, 0), (28, 512, 512, 0)]:
+        assert hip_lib.query('conv3x3_wino4_supported', 256, H, H, Cin, Cout, pool) == 1
+    assert hip_lib.query('conv3x3_wino4_supported', 256, 14, 14, 512, 512, 0) == 0      # 14 is not a multiple of 4: F(2x2,3x3)
+    assert hip_lib.query('conv3x3_wino4_supported', 4, 28, 28, 512, 32, 0) == 0
 
 
 def test_conv3x3_winograd_full_res_layers(hip_lib):
@@ -336,7 +369,7 @@ def _well_conditioned_trunk(size, margin=1e-5):
     raise RuntimeError('no well-conditioned input found')
 
 
-@pytest.mark.parametrize('algo', ['winograd', 'direct'])
+@pytest.mark.parametrize('algo', ['winograd', 'winograd2', 'direct'])
 @pytest.mark.parametrize('size', [32, 40])
 def test_trainable_vgg_trunk_backward(ops, size, algo):
     """vgg19 trunk with gradients (reference models_lct.py:62-63) at 32x32 and 40x40 (odd intermediate maps: floor
