@@ -143,6 +143,7 @@ def main():
         torch.manual_seed(11)
         ef = models_lct.VqaModel(pretrained=True, **DIMS).to(dev).train()
         ef.qst_encoder.max_length = 14
+        ef.img_encoder.model.cache_packed_weights = True        # pretrained=True: frozen trunk (models_lct.py:62-63 under no_grad)
         ef_opt = FusedAdam(ef.trainable_parameters(), lr=config.LEARNING_RATE, flatten=True)
         ef_red = parallel.FlatGradReducer(ef_opt.flat['params'], ef_opt.flat_grad, scale_fn=parallel.hip_scale) if world > 1 else None
         w_step = step
@@ -170,6 +171,9 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # The W model's VGG19 is frozen by construction (models.py:35-36; no optimizer or architect of this step holds its
+    # parameters): keep its kernel-layout weights between steps instead of re-packing 15 layers per step.
+    model.img_encoder.model.cache_packed_weights = True
     pipelined = (args.workload == 'w') and not args.no_pipeline
     if pipelined:
         # Two-stream software pipeline.  The VGG19 trunk is frozen (models.py:35-36) so trunk(batch i+1) is independent

@@ -629,17 +629,19 @@ def _timed(name, flops, fn):
     _conv_timer.append((name, e0, e1, flops))
 
 
-# Packed (kernel-layout) copies of the conv weights of FROZEN parameters, re-made only when the parameter changes: the
-# reference's W model freezes the trunk (basic_vqa/models.py:35-36), so its 15 layers are packed once, not once per
-# step.  Only tensors with requires_grad=False are cached (nothing updates them behind autograd's back: the flat-arena
-# optimizer and the architects' axpy kernels only ever touch trainable parameters); load_state_dict / copy_ bump
-# `_version`, a device move changes the storage.  One copy per (parameter, stream) so that two streams never share
-# a buffer that one of them may be re-packing.
+# Packed (kernel-layout) copies of the conv weights.  By default they are re-made on every call: parameters change behind
+# autograd's back (the flat-arena optimizer's kernel, the architects' `p.data.add_` perturbations,
+# architect_lct.py:142-155,194-207), so nothing derived from a parameter may outlive a call.  A trunk that is frozen BY
+# CONSTRUCTION (the W model's VGG19, reference basic_vqa/models.py:35-36: run under no_grad, held by no optimizer) can
+# opt in to a cache (`vgg.VGG.cache_packed_weights = True`, set by bench.py): one packed copy per (parameter, stream),
+# re-made when the tensor's version counter moves (load_state_dict / copy_ / any in-place op on the parameter itself)
+# or the storage changes (device move).  In-place writes through `.data` do not move the counter: do not opt in for
+# parameters that receive them.
 _pack_cache = {}
 
 
-def _packed_weights(w, kind, numel, pack):
-    if w.requires_grad:
+def _packed_weights(w, kind, numel, pack, cache=False):
+    if not cache:
         dst = torch.empty(numel, dtype=torch.float32, device=w.device)
         pack(dst)
         return dst
@@ -659,14 +661,14 @@ def clear_pack_cache():
     _pack_cache.clear()
 
 
-def _conv_block(cur, w, b, B, H, W, pool, name_timer=True):
+def _conv_block(cur, w, b, B, H, W, pool, cache=False):
     """conv3x3 + bias + ReLU (+ fused 2x2 max pool) on an NHWC activation -> NHWC output."""
     dev = cur.device
     Cout, Cin = w.shape[0], w.shape[1]
     wv = _wino_variant(B, H, W, Cin, Cout, pool)
     if wv is not None:
         up = _packed_weights(w, wv, Cout * Cin * (36 if wv == 'wino4' else 16),
-                             lambda dst: lib(f'conv3x3_{wv}_pack_weights', w, dst, Cout, Cin, 0))
+                             lambda dst: lib(f'conv3x3_{wv}_pack_weights', w, dst, Cout, Cin, 0), cache)
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
         _timed(f'{wv}_{H}x{W}_{Cin}->{Cout}{"+pool" if pool else ""}', 2.0 * B * H * W * Cout * Cin * 9,
@@ -675,7 +677,7 @@ def _conv_block(cur, w, b, B, H, W, pool, name_timer=True):
     mfma = lib.query('conv3x3_uses_mfma', B, H, W, Cin, Cout, pool)
     wp = tmp = None
     if mfma:
-        wp = _packed_weights(w, 'direct', Cout * Cin * 9, lambda dst: lib('conv3x3_pack_weights', w, dst, Cout, Cin))
+        wp = _packed_weights(w, 'direct', Cout * Cin * 9, lambda dst: lib('conv3x3_pack_weights', w, dst, Cout, Cin), cache)
     elif pool:
         tmp = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
@@ -698,7 +700,7 @@ def _pool(cur, B, H, W):
     return out
 
 
-def vgg_features_forward(image, convs, fuse_pool=True, keep=None):
+def vgg_features_forward(image, convs, fuse_pool=True, keep=None, cache=False):
     """vgg19.features + avgpool + flatten.  image NCHW [B,3,H,W]; convs: list of (weight OIHW, bias) with 'M'
     marking MaxPool2d(2,2).  When ``keep`` (a list) is given it receives, per conv layer,
     (activation after ReLU [un-pooled], H, W, pooled_after) for the backward pass; pools are then NOT
@@ -726,7 +728,7 @@ def vgg_features_forward(image, convs, fuse_pool=True, keep=None):
             fused = 0
         else:
             fused = 1 if (fuse and pool_next and H % 2 == 0 and W % 2 == 0) else 0
-            out = _conv_block(cur, w, b, B, H, W, fused)
+            out = _conv_block(cur, w, b, B, H, W, fused, cache)
         if keep is not None:
             keep.append((out, H, W, 1 if pool_next else 0))
         cur = out
@@ -741,12 +743,12 @@ def vgg_features_forward(image, convs, fuse_pool=True, keep=None):
     return flat, (H, W, Cl)
 
 
-def vgg_trunk_forward(image, convs, fcs, train, conv_feature=None):
+def vgg_trunk_forward(image, convs, fcs, train, conv_feature=None, cache=False):
     """torchvision vgg19 (reference basic_vqa/models.py:23-28,36), forward only (frozen trunk).
     fcs: list of (weight, bias, act, drop_p) for the classifier.  Returns [B, fcs[-1] out features].
     conv_feature: the flattened features+avgpool output [B, 25088] of an earlier call on the same image and weights
     (deterministic: the dropouts live in the classifier, which is always re-run)."""
-    x = conv_feature if conv_feature is not None else vgg_features_forward(image, convs, fuse_pool=True, keep=None)[0]
+    x = conv_feature if conv_feature is not None else vgg_features_forward(image, convs, fuse_pool=True, keep=None, cache=cache)[0]
     B, dev = x.shape[0], x.device
     for (w, b, act, drop_p) in fcs:
         m = dropout_mask((B, w.shape[0]), dev, drop_p) if (train and drop_p > 0) else None

@@ -18,6 +18,10 @@ CFG_E = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M',
 
 
 class VGG(nn.Module):
+    # opt-in: keep the kernel-layout copies of the conv weights between calls of the no-grad path (ops._packed_weights);
+    # only for a trunk whose parameters nobody updates in place behind the version counter
+    cache_packed_weights = False
+
     def __init__(self, num_classes=1000):
         super().__init__()
         layers, cin = [], 3
@@ -69,14 +73,14 @@ class VGG(nn.Module):
         a caller that evaluates the same frozen trunk on the same batch twice may pass it back as `conv_feature`."""
         convs, _ = self._plan()
         with torch.no_grad():
-            return ops.vgg_features_forward(x, convs, fuse_pool=True, keep=None)[0]
+            return ops.vgg_features_forward(x, convs, fuse_pool=True, keep=None, cache=self.cache_packed_weights)[0]
 
     def forward(self, x, conv_feature=None):
         convs, fcs = self._plan()
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not needs_grad:
             with torch.no_grad():
-                return ops.vgg_trunk_forward(x, convs, fcs, True, conv_feature)
+                return ops.vgg_trunk_forward(x, convs, fcs, True, conv_feature, cache=self.cache_packed_weights)
         if conv_feature is not None:
             raise RuntimeError('conv_feature can only be re-used with a trunk that needs no gradient')
         # trainable trunk (reference models_lct.py:62-63): autograd through the HIP backward kernels

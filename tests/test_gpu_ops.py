@@ -412,8 +412,8 @@ def _torch_trunk(m, x):
 
 
 def test_frozen_trunk_packed_weight_cache_follows_weight_updates(ops):
-    """The frozen trunk packs its conv weights once (ops._packed_weights); an in-place update or a load_state_dict of
-    the frozen parameters must be seen by the next forward."""
+    """A trunk that opted in (VGG.cache_packed_weights) packs its conv weights once (ops._packed_weights); an in-place
+    update or a load_state_dict of the parameters must still be seen by the next forward."""
     from lct_vqa_amd import vgg
     torch.manual_seed(3)
     m = vgg.vgg19()
@@ -427,10 +427,15 @@ def test_frozen_trunk_packed_weight_cache_follows_weight_updates(ops):
     for p in md.parameters():
         p.requires_grad = False
     md = md.to(DEV).eval()
+    md.cache_packed_weights = True                                     # opt-in (bench.py does this for the frozen W trunk)
     x = torch.randn(2, 3, 64, 64)
+    ops.clear_pack_cache()
     with torch.no_grad():
         assert rel_err(md(x.to(DEV)), _torch_trunk(m, x)) < 1e-4
+        n_cached = len(ops._pack_cache)
+        assert n_cached >= 10
         assert rel_err(md(x.to(DEV)), _torch_trunk(m, x)) < 1e-4       # second call: served from the cache
+        assert len(ops._pack_cache) == n_cached
         m.features[7].weight.mul_(1.5)
         md.features[7].weight.mul_(1.5)                                # in-place update bumps the version counter
         assert rel_err(md(x.to(DEV)), _torch_trunk(m, x)) < 1e-4
