@@ -259,6 +259,9 @@ def main():
                 'algorithm': algo, 'achieved': round(achieved, 2),
                 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                 'mfma_executed_tflops': round(executed, 2), 'mfma_executed_frac': round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
+                'note': ('achieved counts the ALGORITHMIC (direct-convolution) FLOPs per launch; the fp32 Winograd kernels execute 4x '
+                         '(F(4x4,3x3)) / 2.25x (F(2x2,3x3)) fewer on the MFMA pipe, so frac can exceed 1; mfma_executed_frac is the '
+                         "pipe's real utilisation against the same peak") if nwino else None,
                 'traffic': None, 'launches': nlaunch, 'avg_launch_ms': round(tot_ms / nlaunch, 4),
                 'flops_per_launch': tot_flops / nlaunch, 'conv_ms_per_step': round(tot_ms / args.steps, 3)}
     try:      # HBM bytes per launch of the same kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)

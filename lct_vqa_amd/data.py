@@ -79,7 +79,7 @@ class DeviceBatcher:
         for k in order:
             i = int(idx[k])
             iid = int(self.img_id[i])
-            h['img'][k].copy_(torch.from_numpy(np.asarray(self.images[self.id_to_row[iid]])))
+            h['img'][k].numpy()[...] = self.images[self.id_to_row[iid]]      # straight into the pinned buffer (read-only memmaps too)
             h['qst'][k].copy_(torch.from_numpy(np.asarray(self.enc_qst[i]).astype(np.int64)))
             ans = np.asarray(self.enc_ans[i])
             valid = ans.nonzero()[0]
