@@ -252,12 +252,25 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
     int chunk = 0;                                                                                    \
     for (; chunk < NCH - 1; chunk++) {                                                                \
       W4_PHASE(true, NU)                                                                              \
+      W4_DIAG_T0                                                                                      \
       asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");                        \
+      W4_DIAG_T1                                                                                      \
       if (chunk + 3 < NCH && !W4_X_NORAW) stage_raw(chunk + 3, raw + ((chunk + 1) & 1) * RAWSZ);      \
     }                                                                                                 \
     W4_PHASE(false, NU)                                                                               \
   }
 
+  // -DW4_DIAG: per-wave s_memtime stamps (ticks parked at the end-of-phase wait + barrier, K-loop ticks, epilogue ticks)
+  // written to y instead of the result; read by tools/diag_wino4.py
+#ifdef W4_DIAG
+  long dg_wait = 0, dg_t = 0;
+  const long dg_start = __builtin_amdgcn_s_memtime();
+#define W4_DIAG_T0 dg_t = __builtin_amdgcn_s_memtime();
+#define W4_DIAG_T1 dg_wait += __builtin_amdgcn_s_memtime() - dg_t;
+#else
+#define W4_DIAG_T0
+#define W4_DIAG_T1
+#endif
   stage_raw(0, raw);
   if (NCH > 1) stage_raw(1, raw + RAWSZ);
 #pragma unroll
@@ -285,6 +298,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
 #undef W4_MF
 #undef W4_SB
 
+#ifdef W4_DIAG
+  const long dg_loop_end = __builtin_amdgcn_s_memtime();
+#endif
   // ---- epilogue: exchange the 36 accumulators of each (tile, channel) through LDS, 4 rounds of 8 (channel group,
   // register) units; wave w output-transforms unit w of a round
   float* xch = V;                                               // [8 units][36][64 lanes] floats = 73.7 KB = both V buffers
@@ -333,7 +349,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
           for (int b = 0; b < 4; b++) Y[a][b] = fmaxf(Y[a][b], 0.f);
       }
       const int tile = (r & 3) + 8 * (r >> 2) + 4 * h;
+#ifdef W4_DIAG
+      if (tile < NTILE && relu == 12345) {                      // diagnostic build: the stamps go to y instead
+#else
       if (tile < NTILE) {
+#endif
         const int ty = tile / TX, tx = tile % TX;
         const int R = R0 + 4 * ty;
         if (R < Rtot) {
@@ -357,6 +377,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
       }
     }
   }
+#ifdef W4_DIAG
+  __syncthreads();
+  if (lane == 0) {
+    const long dg_end = __builtin_amdgcn_s_memtime();
+    float* dg = y + ((long)blockIdx.x * 8 + wave) * 4;
+    dg[0] = (float)dg_wait; dg[1] = (float)(dg_loop_end - dg_start); dg[2] = (float)(dg_end - dg_loop_end); dg[3] = (float)wave;
+  }
+#endif
 }
 
 static int w4_max_boundaries(int H, int TH, long Rtot) {
