@@ -1,0 +1,72 @@
+"""Full-size (BASELINE configs[1]: B=256, 224x224, T=14, A=3129, QV=17858) properties of the W model on the GPU, where the
+oracle is too slow to run: determinism, agreement of the three trunk convolution algorithms, independence of a sample's
+logits from the batch it is computed in (the trunk tiles stacked image rows, so a patch of the small maps spans several
+images), and a full train step that moves every trainable parameter and nothing else."""
+import pytest
+import torch
+
+from _util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+DIMS = dict(embed_size=1024, qst_vocab_size=17858, ans_vocab_size=3129, word_embed_size=300, num_layers=1, hidden_size=512)
+
+
+@pytest.fixture(scope='module')
+def full(hip_lib):
+    from lct_vqa_amd import ops
+    from lct_vqa_amd.basic_vqa import models, config
+    config.DEVICE = torch.device(DEV)
+    torch.manual_seed(5)
+    m = models.VqaModel(**DIMS).to(DEV)
+    g = torch.Generator().manual_seed(6)
+    img = torch.randn(256, 3, 224, 224, generator=g).to(DEV)
+    qst = torch.randint(0, DIMS['qst_vocab_size'], (256, 14), generator=g).to(DEV)
+    lab = torch.randint(0, DIMS['ans_vocab_size'], (256,), generator=g).to(DEV)
+    return ops, m, img, qst, lab
+
+
+def test_full_size_forward_properties(full):
+    ops, m, img, qst, _ = full
+    m.eval()
+    out = {}
+    with torch.no_grad():
+        for algo in ('winograd', 'winograd2', 'direct'):
+            prev = ops.set_conv_algo(algo)
+            try:
+                a = m(img, qst)
+                b = m(img, qst)
+            finally:
+                ops.set_conv_algo(prev)
+            assert torch.isfinite(a).all() and a.shape == (256, 3129)
+            assert torch.equal(a, b), f'{algo}: not deterministic'
+            out[algo] = a
+        for algo in ('winograd', 'winograd2'):
+            assert rel_err(out[algo], out['direct']) < 1e-4, algo
+            assert torch.equal(out[algo].argmax(1), out['direct'].argmax(1)), algo
+        # a sample's logits do not depend on its neighbours in the batch (different position in the stacked rows,
+        # different patches and tile slots): samples 3..6 alone vs inside the batch of 256
+        sub = m(img[3:7].contiguous(), qst[3:7].contiguous())
+        assert rel_err(sub, out['winograd'][3:7]) < 1e-5
+        assert torch.equal(sub.argmax(1), out['winograd'][3:7].argmax(1))
+
+
+def test_full_size_train_step_touches_exactly_the_trainable_parameters(full):
+    from lct_vqa_amd.optim import FusedAdam
+    ops, m, img, qst, lab = full
+    m.train()
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    opt = FusedAdam(m.trainable_parameters(), lr=1e-3, flatten=True)
+    opt.zero_grad()
+    loss = ops.cross_entropy(m(img, qst), lab)
+    loss.backward()
+    opt.step(max_grad_norm=5.0)
+    assert torch.isfinite(loss) and 6.0 < float(loss) < 10.0          # ~ln(3129) = 8.05 at random init
+    trainable = {id(p) for p in m.trainable_parameters()}
+    for n, p in m.named_parameters():
+        moved = not torch.equal(p.detach(), before[n])
+        if id(p) in trainable:
+            assert moved and torch.isfinite(p).all(), n
+            assert (p.detach() - before[n]).abs().max() <= 1.0001e-3 + 1e-9, n    # |Adam step| <= lr on the first step
+        else:
+            assert not moved, n                                      # the frozen trunk (models.py:35-36)
