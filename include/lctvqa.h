@@ -178,6 +178,12 @@ int lctvqa_dwconv_bwd_input(const float* dy, const float* w, const float* x, flo
 long lctvqa_dwconv_bwd_weight_scratch_elems(int B, int H, int W, int C, int K, int stride, int pad, int dil);
 int lctvqa_dwconv_bwd_weight(const float* dy, const float* x, float* dw, float* scratch, int B, int H, int W, int C, int K,
                              int stride, int pad, int dil, int relu_in, void* stream);
+/* 1x1-conv weight gradient for small channel counts (Cout*Cin <= 4096): dw[Cout][Cin] = sum_p dy[p][Cout] x relu?(x[p][Cin]),
+ * P = B*H*W pixels (operations.py:28,42,57,61 backward; replaces a P-deep 128x128 GEMM tile that is >98 % padding) */
+long lctvqa_pwconv_wgrad_small_scratch_elems(long P, int Cout, int Cin);
+int lctvqa_pwconv_wgrad_small_supported(long P, int Cout, int Cin);
+int lctvqa_pwconv_wgrad_small(const float* dy, const float* x, float* dw, float* scratch, long P, int Cout, int Cin, int relu_in,
+                              void* stream);
 /* 3x3 pooling pad 1: kind 0 = MaxPool2d, 1 = AvgPool2d(count_include_pad=False) */
 int lctvqa_pool3x3_fwd(const float* x, float* y, int B, int H, int W, int C, int stride, int kind, void* stream);
 int lctvqa_pool3x3_bwd(const float* dy, const float* x, float* dx, int B, int H, int W, int C, int stride, int kind, void* stream);

@@ -117,6 +117,126 @@ __global__ __launch_bounds__(64) void dwconv_bwd_weight_finish_kernel(const floa
   if (threadIdx.x == 0) dw[c * KK + tap] = a;
 }
 
+// Same reduction for C % 4 == 0 (every channel count of the search and derived networks): thread = (output pixel,
+// channel quad), one float4 of dy and K*K float4 of x per pixel (neighbours hit L1), K*K float4 accumulators in
+// registers; lanes that own the same channel quad meet by shuffles, waves by LDS.  16-B coalesced loads instead of the
+// scalar 4-B gathers of the generic kernel.   part[blk][tap*C + c] as above.
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                    float* __restrict__ part, int B, int H, int W, int C, int s, int p,
+                                                                    int d, int Ho, int Wo, int relu_in) {
+  constexpr int KK = K * K;
+  __shared__ f32x4 red[4][KK][4];                               // [wave][tap][channel quad (<= 4 per pass)]
+  const int CQ = C >> 2;
+  const long items = (long)B * Ho * Wo * CQ;
+  const f32x4* dy4 = (const f32x4*)dy;
+  const f32x4* x4 = (const f32x4*)x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the grid stride is a multiple of CQ (CQ is a power of two <= 64, blockDim = 256), so a thread keeps its channel quad
+  const int cq = threadIdx.x % CQ;
+  f32x4 acc[KK];
+#pragma unroll
+  for (int t = 0; t < KK; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < items; i += (long)gridDim.x * blockDim.x) {
+    const long q = i / CQ;
+    const int ox = q % Wo, oy = (q / Wo) % Ho, n = q / ((long)Wo * Ho);
+    const f32x4 g = dy4[i];
+#pragma unroll
+    for (int ky = 0; ky < K; ky++) {
+      const int iy = oy * s - p + ky * d;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < K; kx++) {
+        const int ix = ox * s - p + kx * d;
+        if (ix < 0 || ix >= W) continue;
+        f32x4 v = x4[(((long)n * H + iy) * W + ix) * CQ + cq];
+        if (relu_in) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        acc[ky * K + kx] += g * v;
+      }
+    }
+  }
+  // lanes with equal (lane % CQ) hold partial sums of the same channel quad
+#pragma unroll
+  for (int t = 0; t < KK; t++) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      float v = acc[t][e];
+      for (int o = 32; o >= CQ; o >>= 1) v += __shfl_xor(v, o, 64);
+      acc[t][e] = v;
+    }
+  }
+  // CQ <= 4 per pass through the LDS buffer (CQ = 1, 2, 4 in one pass; 8, 16 in several)
+  for (int c0 = 0; c0 < CQ; c0 += 4) {
+    __syncthreads();
+    if (lane >= c0 && lane < c0 + 4 && lane < CQ) {
+#pragma unroll
+      for (int t = 0; t < KK; t++) red[wave][t][lane - c0] = acc[t];
+    }
+    __syncthreads();
+    const int nq = min(4, CQ - c0);
+    for (int o = threadIdx.x; o < KK * nq; o += blockDim.x) {
+      const int t = o / nq, qd = o % nq;
+      const f32x4 sum = red[0][t][qd] + red[1][t][qd] + red[2][t][qd] + red[3][t][qd];
+      float* dst = part + (long)blockIdx.x * KK * C + t * C + (c0 + qd) * 4;
+      dst[0] = sum[0]; dst[1] = sum[1]; dst[2] = sum[2]; dst[3] = sum[3];
+    }
+  }
+}
+
+// 1x1-convolution weight gradient for small channel counts (Cout * Cin <= 4096; the DARTS cells: 4..64 channels):
+//   dw[co][ci] = sum_p dy[p][co] * relu?(x[p][ci]),  P = B*H*W pixels (10^5..10^6): a 16x16 "GEMM" with K = P, for which a
+// 128x128 MFMA tile is >98 % padding.  A block stages 256 pixels of dy and x in LDS (coalesced), thread = (output o,
+// pixel lane): the outputs are spread over all 256 threads, lanes meet in LDS; part[blk][o], finished by the same
+// column-sum kernel as the depthwise gradient.
+__global__ __launch_bounds__(256) void pwconv_wgrad_small_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 float* __restrict__ part, long P, int Cout, int Cin, int relu_in,
+                                                                 long per_blk) {
+  constexpr int TP = 256;
+  extern __shared__ float sm[];
+  float* sdy = sm;                       // [TP][Cout]
+  float* sx = sm + TP * Cout;            // [TP][Cin]
+  __shared__ float red[256];
+  const int NO = Cout * Cin;
+  const long q0 = blockIdx.x * per_blk, q1 = min(P, q0 + per_blk);
+  const int NOc = min(256, NO);                                 // outputs per pass
+  const int PL = 256 / NOc;                                     // pixel lanes
+  for (int o0 = 0; o0 < NO; o0 += 256) {
+    const int oi = threadIdx.x % NOc, pl = threadIdx.x / NOc;
+    const int o = o0 + oi;
+    const bool live = pl < PL && o < NO;
+    const int co = live ? o / Cin : 0, ci = live ? o % Cin : 0;
+    float a = 0.f;
+    for (long qb = q0; qb < q1; qb += TP) {
+      const int np = (int)min((long)TP, q1 - qb);
+      __syncthreads();
+      for (int t = threadIdx.x; t < np * Cout; t += 256) sdy[t] = dy[qb * Cout + t];
+      for (int t = threadIdx.x; t < np * Cin; t += 256) {
+        float v = x[qb * Cin + t];
+        sx[t] = relu_in ? fmaxf(v, 0.f) : v;
+      }
+      __syncthreads();
+      if (live)
+        for (int pp = pl; pp < np; pp += PL) a = fmaf(sdy[pp * Cout + co], sx[pp * Cin + ci], a);
+    }
+    __syncthreads();
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < NOc && o0 + threadIdx.x < NO) {
+      float sum = 0.f;
+      for (int l = 0; l < PL; l++) sum += red[l * NOc + threadIdx.x];
+      part[(long)blockIdx.x * NO + o0 + threadIdx.x] = sum;
+    }
+  }
+}
+// out[t] = sum_blk part[blk][t]   (one wave per output)
+__global__ __launch_bounds__(64) void colsum_partials_kernel(const float* __restrict__ part, int nblk, int NO, float* __restrict__ out) {
+  const int t = blockIdx.x;
+  float a = 0.f;
+  for (int b = threadIdx.x; b < nblk; b += 64) a += part[(long)b * NO + t];
+  a = wave_sum(a);
+  if (threadIdx.x == 0) out[t] = a;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // 3x3 pooling, padding 1, stride s (operations.py:6-7): kind 0 = max, 1 = avg (count_include_pad=False)
 // ---------------------------------------------------------------------------------------------------------
@@ -502,12 +622,47 @@ int lctvqa_dwconv_bwd_weight(const float* dy, const float* x, float* dw, float* 
   int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
   long per;
   int nb = red_blocks((long)B * Ho * Wo, &per);
-  hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, x, scratch, B, H, W, C, K, stride,
-                     pad, dil, Ho, Wo, relu_in, per);
+  const bool vec = (C % 4 == 0) && C <= 256 && ((C / 4) & (C / 4 - 1)) == 0 && (K == 3 || K == 5 || K == 7) &&
+                   (((uintptr_t)dy | (uintptr_t)x) & 15) == 0;
+  if (vec) {            // same nb blocks and the same part[blk][tap*C + c] layout, grid-stride over (pixel, channel quad) items
+    if (K == 3)
+      hipLaunchKernelGGL(dwconv_bwd_weight_vec_kernel<3>, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, x, scratch, B, H, W, C, stride,
+                         pad, dil, Ho, Wo, relu_in);
+    else if (K == 5)
+      hipLaunchKernelGGL(dwconv_bwd_weight_vec_kernel<5>, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, x, scratch, B, H, W, C, stride,
+                         pad, dil, Ho, Wo, relu_in);
+    else
+      hipLaunchKernelGGL(dwconv_bwd_weight_vec_kernel<7>, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, x, scratch, B, H, W, C, stride,
+                         pad, dil, Ho, Wo, relu_in);
+  } else {
+    hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, x, scratch, B, H, W, C, K, stride,
+                       pad, dil, Ho, Wo, relu_in, per);
+  }
   int rc = lct_check_launch("dwconv_bwd_weight");
   if (rc) return rc;
   hipLaunchKernelGGL(dwconv_bwd_weight_finish_kernel, dim3(C * K * K), dim3(64), 0, (hipStream_t)stream, scratch, nb, C, K * K, dw);
   return lct_check_launch("dwconv_bwd_weight_finish");
+}
+
+long lctvqa_pwconv_wgrad_small_scratch_elems(long P, int Cout, int Cin) {
+  long per;
+  int nb = red_blocks(P, &per);
+  return (long)nb * Cout * Cin;
+}
+int lctvqa_pwconv_wgrad_small_supported(long P, int Cout, int Cin) {
+  return P >= 1 && Cout >= 1 && Cin >= 1 && (long)Cout * Cin <= 4096 && (Cout + Cin) * 256 * 4 <= 60 * 1024;
+}
+int lctvqa_pwconv_wgrad_small(const float* dy, const float* x, float* dw, float* scratch, long P, int Cout, int Cin, int relu_in,
+                              void* stream) {
+  LCT_REQUIRE(lctvqa_pwconv_wgrad_small_supported(P, Cout, Cin), "pwconv_wgrad_small: unsupported P=%ld Cout=%d Cin=%d", P, Cout, Cin);
+  long per;
+  int nb = red_blocks(P, &per);
+  size_t lds = (size_t)(Cout + Cin) * 256 * sizeof(float);
+  hipLaunchKernelGGL(pwconv_wgrad_small_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, dy, x, scratch, P, Cout, Cin, relu_in, per);
+  int rc = lct_check_launch("pwconv_wgrad_small");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(Cout * Cin), dim3(64), 0, (hipStream_t)stream, scratch, nb, Cout * Cin, dw);
+  return lct_check_launch("pwconv_wgrad_small_finish");
 }
 
 int lctvqa_pool3x3_fwd(const float* x, float* y, int B, int H, int W, int C, int stride, int kind, void* stream) {

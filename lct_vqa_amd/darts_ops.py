@@ -105,7 +105,12 @@ class PwConvFn(torch.autograd.Function):
                 dx = out
             dx = dx.reshape(B, H, W, Cin)
         if ctx.needs_input_grad[1]:
-            dw = _gemm_ex(dy, 1, Cout, x, 1, Cin, Cout, Cin, P, 2 if ctx.relu_in else 0).reshape(w.shape)
+            if lib.query('pwconv_wgrad_small_supported', P, Cout, Cin):
+                dw = torch.empty_like(w)
+                scratch = torch.empty(lib.query('pwconv_wgrad_small_scratch_elems', P, Cout, Cin), dtype=torch.float32, device=x.device)
+                lib('pwconv_wgrad_small', dy, x, dw, scratch, P, Cout, Cin, int(ctx.relu_in))
+            else:
+                dw = _gemm_ex(dy, 1, Cout, x, 1, Cin, Cout, Cin, P, 2 if ctx.relu_in else 0).reshape(w.shape)
         return dx, dw, None
 
 
