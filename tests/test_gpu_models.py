@@ -245,3 +245,21 @@ def test_eval_path_counters_vs_oracle(pkg):
     q = torch.randint(0, 21, (6, 9), generator=g)
     q[0, 1:] = qp[0].argmax(1)[:-1]                                     # one fully correct question
     assert misc.num_correct_qst(qp.to(DEV), q.to(DEV)) == O.num_correct_qst(qp, q)
+
+
+def test_ragged_and_empty_batches(pkg):
+    """Batch sizes that are not multiples of any tile (1, 3, 5: the last, short batch of an epoch) give the same per-sample
+    logits as a larger batch; an EMPTY batch is refused loudly by the C ABI (shape check) instead of launching empty grids."""
+    ops, models, _, _ = pkg
+    torch.manual_seed(2)
+    m = models.VqaModel(embed_size=64, qst_vocab_size=50, ans_vocab_size=20, word_embed_size=16, num_layers=1,
+                        hidden_size=32).to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(5, 3, 64, 64, generator=g).to(DEV)
+    qst = torch.randint(0, 50, (5, 7), generator=g).to(DEV)
+    with torch.no_grad():
+        full = m(img, qst)
+        for B in (1, 3):
+            assert rel_err(m(img[:B].contiguous(), qst[:B].contiguous()), full[:B]) < 1e-5
+        with pytest.raises(RuntimeError):
+            m(img[:0].contiguous(), qst[:0].contiguous())
