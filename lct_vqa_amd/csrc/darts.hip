@@ -514,33 +514,44 @@ __global__ void mixed_combine_bwd_x_kernel(const float* __restrict__ dout, long 
 __global__ __launch_bounds__(256) void mixed_combine_bwd_scalars_kernel(const float* __restrict__ dout, long ldd, BranchPtrs br,
                                                                         int nbr, const float* __restrict__ x, int B, int Ho, int Wo,
                                                                         int C, int reduce, long per_blk, float* __restrict__ part) {
+  // thread = (pixel q, channel i of the first quarter): the four shuffled output channels 4i..4i+3 are one float4 of dout
+  // (g = 0: the weighted branch sum of channel i; g = 1..3: bypass channels g*Cq + i), so every lane does the same work
+  // and the branch / bypass reads are contiguous over i.
   __shared__ float red[9][4];
   const int Cq = C / 4;
   const long P = (long)B * Ho * Wo;
   const long q0 = blockIdx.x * per_blk, q1 = min(P, q0 + per_blk);
+  const bool vec = ((ldd & 3) == 0) && (((uintptr_t)dout & 15) == 0);
   float acc[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) acc[k] = 0.f;
-  for (long o = q0 * C + threadIdx.x; o < q1 * C; o += blockDim.x) {
-    int oc = o % C; long q = o / C;
-    int g = oc & 3, i = oc >> 2;
-    const float d = dout[q * ldd + oc];
-    if (g == 0) {
-#pragma unroll
-      for (int k = 0; k < 8; k++)
-        if (k < nbr) acc[k] = fmaf(d, br.p[k][q * Cq + i], acc[k]);
+  for (long o = q0 * Cq + threadIdx.x; o < q1 * Cq; o += blockDim.x) {
+    const int i = o % Cq; const long q = o / Cq;
+    float d0, d1, d2, d3;
+    if (vec) {
+      const f32x4 dv = *(const f32x4*)(dout + q * ldd + 4 * i);
+      d0 = dv[0]; d1 = dv[1]; d2 = dv[2]; d3 = dv[3];
     } else {
-      const int c = g * Cq + i;
-      float v;
-      if (!reduce) v = x[q * C + c];
-      else {
-        int ox = q % Wo; int oy = (q / Wo) % Ho; int n = q / ((long)Wo * Ho);
-        const int H = Ho * 2, W = Wo * 2;
-        const float* b0 = x + (((long)n * H + 2 * oy) * W + 2 * ox) * C + c;
-        v = fmaxf(fmaxf(b0[0], b0[C]), fmaxf(b0[(long)W * C], b0[(long)W * C + C]));
-      }
-      acc[8] = fmaf(d, v, acc[8]);
+      const float* dp = dout + q * ldd + 4 * i;
+      d0 = dp[0]; d1 = dp[1]; d2 = dp[2]; d3 = dp[3];
     }
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (k < nbr) acc[k] = fmaf(d0, br.p[k][o], acc[k]);
+    float v1, v2, v3;
+    if (!reduce) {
+      const float* xp = x + q * C + i;
+      v1 = xp[Cq]; v2 = xp[2 * Cq]; v3 = xp[3 * Cq];
+    } else {
+      const int ox = q % Wo, oy = (q / Wo) % Ho, n = q / ((long)Wo * Ho);
+      const int H = Ho * 2, W = Wo * 2;
+      const float* b0 = x + (((long)n * H + 2 * oy) * W + 2 * ox) * C + i;
+      const long rs = (long)W * C;
+      v1 = fmaxf(fmaxf(b0[Cq], b0[C + Cq]), fmaxf(b0[rs + Cq], b0[rs + C + Cq]));
+      v2 = fmaxf(fmaxf(b0[2 * Cq], b0[C + 2 * Cq]), fmaxf(b0[rs + 2 * Cq], b0[rs + C + 2 * Cq]));
+      v3 = fmaxf(fmaxf(b0[3 * Cq], b0[C + 3 * Cq]), fmaxf(b0[rs + 3 * Cq], b0[rs + C + 3 * Cq]));
+    }
+    acc[8] = fmaf(d1, v1, fmaf(d2, v2, fmaf(d3, v3, acc[8])));
   }
 #pragma unroll
   for (int k = 0; k < 9; k++) {
