@@ -117,6 +117,64 @@ __global__ __launch_bounds__(64) void dwconv_bwd_weight_finish_kernel(const floa
   if (threadIdx.x == 0) dw[c * KK + tap] = a;
 }
 
+// float4 forms of the two kernels above for C % 4 == 0: thread = (pixel, channel quad); the K*K weights of the four
+// channels are gathered per tap (w is [C][K][K]: stride K*K between channels, L1-resident).
+__global__ void dwconv_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int B, int H,
+                                      int W, int C, int K, int s, int p, int d, int Ho, int Wo, int relu_in) {
+  const int CQ = C >> 2, KK = K * K;
+  const f32x4* x4 = (const f32x4*)x;
+  GRID_STRIDE(o, (long)B * Ho * Wo * CQ) {
+    const int cq = o % CQ; const long q = o / CQ; const int ox = q % Wo, oy = (q / Wo) % Ho, n = q / ((long)Wo * Ho);
+    const float* wc = w + (cq * 4) * KK;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < K; ky++) {
+      const int iy = oy * s - p + ky * d;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < K; kx++) {
+        const int ix = ox * s - p + kx * d;
+        if (ix < 0 || ix >= W) continue;
+        f32x4 v = x4[(((long)n * H + iy) * W + ix) * CQ + cq];
+        if (relu_in) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        const int t = ky * K + kx;
+        const f32x4 wv = {wc[t], wc[KK + t], wc[2 * KK + t], wc[3 * KK + t]};
+        a += v * wv;
+      }
+    }
+    ((f32x4*)y)[o] = a;
+  }
+}
+__global__ void dwconv_bwd_input_vec_kernel(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ x,
+                                            float* __restrict__ dx, int B, int H, int W, int C, int K, int s, int p, int d, int Ho,
+                                            int Wo, int relu_in) {
+  const int CQ = C >> 2, KK = K * K;
+  const f32x4* dy4 = (const f32x4*)dy;
+  GRID_STRIDE(o, (long)B * H * W * CQ) {
+    const int cq = o % CQ; const long q = o / CQ; const int ix = q % W, iy = (q / W) % H, n = q / ((long)W * H);
+    const float* wc = w + (cq * 4) * KK;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < K; ky++) {
+      const int ty = iy + p - ky * d;
+      if (ty < 0 || ty % s) continue;
+      const int oy = ty / s;
+      if (oy >= Ho) continue;
+      for (int kx = 0; kx < K; kx++) {
+        const int tx = ix + p - kx * d;
+        if (tx < 0 || tx % s) continue;
+        const int ox = tx / s;
+        if (ox >= Wo) continue;
+        const int t = ky * K + kx;
+        const f32x4 wv = {wc[t], wc[KK + t], wc[2 * KK + t], wc[3 * KK + t]};
+        a += dy4[(((long)n * Ho + oy) * Wo + ox) * CQ + cq] * wv;
+      }
+    }
+    if (relu_in) {
+      const f32x4 xv = ((const f32x4*)x)[o];
+      a[0] = xv[0] > 0.f ? a[0] : 0.f; a[1] = xv[1] > 0.f ? a[1] : 0.f; a[2] = xv[2] > 0.f ? a[2] : 0.f; a[3] = xv[3] > 0.f ? a[3] : 0.f;
+    }
+    ((f32x4*)dx)[o] = a;
+  }
+}
+
 // Same reduction for C % 4 == 0 (every channel count of the search and derived networks): thread = (output pixel,
 // channel quad), one float4 of dy and K*K float4 of x per pixel (neighbours hit L1), K*K float4 accumulators in
 // registers; lanes that own the same channel quad meet by shuffles, waves by LDS.  16-B coalesced loads instead of the
@@ -611,15 +669,23 @@ int lctvqa_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, in
                       int relu_in, void* stream) {
   LCT_REQUIRE(K >= 1 && stride >= 1 && dil >= 1, "dwconv: bad args");
   int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
-  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(gs_blocks((long)B * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, w, y, B, H, W,
-                     C, K, stride, pad, dil, Ho, Wo, relu_in);
+  if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
+    hipLaunchKernelGGL(dwconv_fwd_vec_kernel, dim3(gs_blocks((long)B * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, w, y,
+                       B, H, W, C, K, stride, pad, dil, Ho, Wo, relu_in);
+  else
+    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(gs_blocks((long)B * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, w, y, B, H, W,
+                       C, K, stride, pad, dil, Ho, Wo, relu_in);
   return lct_check_launch("dwconv_fwd");
 }
 int lctvqa_dwconv_bwd_input(const float* dy, const float* w, const float* x, float* dx, int B, int H, int W, int C, int K,
                             int stride, int pad, int dil, int relu_in, void* stream) {
   int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
-  hipLaunchKernelGGL(dwconv_bwd_input_kernel, dim3(gs_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, w, x, dx,
-                     B, H, W, C, K, stride, pad, dil, Ho, Wo, relu_in);
+  if (C % 4 == 0 && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) & 15) == 0)
+    hipLaunchKernelGGL(dwconv_bwd_input_vec_kernel, dim3(gs_blocks((long)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, w,
+                       x, dx, B, H, W, C, K, stride, pad, dil, Ho, Wo, relu_in);
+  else
+    hipLaunchKernelGGL(dwconv_bwd_input_kernel, dim3(gs_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, w, x, dx,
+                       B, H, W, C, K, stride, pad, dil, Ho, Wo, relu_in);
   return lct_check_launch("dwconv_bwd_input");
 }
 long lctvqa_dwconv_bwd_weight_scratch_elems(int B, int H, int W, int C, int K, int stride, int pad, int dil) {
