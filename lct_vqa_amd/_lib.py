@@ -47,6 +47,8 @@ class _Lib:
     def __init__(self):
         self._dll = None
         self._sigs = parse_header()
+        self._fns = {}
+        self._wants_stream = {}
 
     def load(self):
         if self._dll is not None:
@@ -67,7 +69,12 @@ class _Lib:
         return self.load().lctvqa_last_error().decode()
 
     def raw(self, name):
-        return getattr(self.load(), 'lctvqa_' + name)
+        fn = self._fns.get(name)
+        if fn is None:
+            fn = getattr(self.load(), 'lctvqa_' + name)
+            self._fns[name] = fn
+            self._wants_stream[name] = len(fn.argtypes) if fn.argtypes else 0
+        return fn
 
     def query(self, name, *args):
         """Call a value-returning entry point (no error convention, no stream)."""
@@ -75,22 +82,28 @@ class _Lib:
 
     def __call__(self, name, *args):
         """Call lctvqa_<name>; tensors are passed as device pointers; the current torch stream is
-        appended when the C signature ends in `void* stream` and it was not given."""
-        fn = self.raw(name)
-        conv = []
-        for a in args:
-            if isinstance(a, torch.Tensor):
-                conv.append(ctypes.c_void_p(a.data_ptr()))
-            elif a is None:
-                conv.append(None)
-            else:
-                conv.append(a)
-        if len(conv) == len(fn.argtypes) - 1:
-            conv.append(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        appended when the C signature ends in `void* stream` and it was not given.  This sits on every launch of the
+        launch-bound paths (LSTM steps, PC-DARTS primitives: ~10^4 calls per step), so it avoids per-call object
+        construction: cached function objects, raw integer pointers, the raw current-stream handle."""
+        fn = self._fns.get(name) or self.raw(name)
+        conv = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
+        if len(conv) == self._wants_stream[name] - 1:
+            conv.append(_current_raw_stream())
         rc = fn(*conv)
-        if fn.restype is ctypes.c_int and rc != 0:
+        if rc != 0 and fn.restype is ctypes.c_int:
             raise RuntimeError(f'lctvqa_{name} failed (rc={rc}): {self.last_error()}')
         return rc
+
+
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+
+    def _current_raw_stream():
+        return _raw_stream(torch.cuda.current_device())
+except AttributeError:                                          # pragma: no cover - older torch
+
+    def _current_raw_stream():
+        return torch.cuda.current_stream().cuda_stream
 
 
 lib = _Lib()
