@@ -124,7 +124,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
   int tbase = tc * PLANE;
   if (tt < NTILE) {
     const int ty = tt / TX, tx = tt % TX;
-    const int g = (y0 + 4 * ty) / H;                            // image boundaries (= shared zero rows) above this tile
+    const int g = min((y0 + 4 * ty) / H, G);                    // image boundaries (= shared zero rows) above this tile;
+                                                                // tiles past the last image (never stored) stay inside the patch
     tbase = tc * PLANE + ((4 * ty + g) * RS + 4 * tx) * 4;
   }
   const int vwoff = tc * 128 + tt * 4;                          // + (xi*6+nu)*256
