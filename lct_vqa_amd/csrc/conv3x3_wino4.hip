@@ -61,7 +61,9 @@ __global__ void wino4_pack_kernel(const float* __restrict__ w, float* __restrict
 template <int TY, int TX, int GMAX, bool POOL>
 __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __restrict__ x, const float* __restrict__ up,
                                                                const float* __restrict__ bias, float* __restrict__ y, int Btot,
-                                                               int H, int W, int Cin, int Cout, int relu, int G) {
+                                                               int H, int W, int Cin, int Cout, int relu, int G, int Hp, int Wp) {
+  // Hp, Wp: H, W rounded up to the tile grid (4 rows, TW columns).  Rows H..Hp-1 / columns W..Wp-1 read as zeros and their
+  // outputs are dropped, so any map size works (14x14 runs as 16x16: 77 % useful).
   constexpr int NTILE = TY * TX;
   static_assert(NTILE <= 32, "patch holds too many tiles");
   constexpr int TH = 4 * TY, TW = 4 * TX, RS = TW + 2;
@@ -84,12 +86,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
   const int NT = Cout / 64;
   // workgroups are dealt to the 8 XCDs round-robin: the NT workgroups reading one input patch share an XCD (its L2)
   const int n_tile = (blockIdx.x >> 3) % NT, m_tile = ((blockIdx.x >> 3) / NT) * 8 + (blockIdx.x & 7);
-  const int CT = W / TW;
-  if (m_tile >= ((Btot * H + TH - 1) / TH) * CT) return;
+  const int CT = Wp / TW;
+  if (m_tile >= ((Btot * Hp + TH - 1) / TH) * CT) return;
   const int ct = m_tile % CT, rt = m_tile / CT;
   const int R0 = rt * TH, x0 = ct * TW;
-  const int Rtot = Btot * H;
-  const int n0img = R0 / H, y0 = R0 % H;
+  const int n0img = R0 / Hp, y0 = R0 % Hp;                      // stacked PADDED rows: R = n * Hp + y
   const int NCH = Cin / 8;
   const int PLIVE = (TH + 2 + G) * RS;
 
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
     const int xx = x0 - 1 + hx;
     int yv = y0 - 1 + hr;
     int n = n0img;
-    while (yv > H) { yv -= (H + 1); n++; }
+    while (yv > Hp) { yv -= (Hp + 1); n++; }
     const bool ok = (p < PLIVE) && (yv >= 0) && (yv < H) && (n < Btot) && (xx >= 0) && (xx < W);
     aoff[k] = ok ? (((n * H + yv) * W + xx) * Cin + q * 4) : -1;
     pdst[k] = (pc < 2 * AROUNDS && r * 64 < PLIVE) ? (q * PLANE + r * 256) : -1;      // wave-uniform
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
   int tbase = tc * PLANE;
   if (tt < NTILE) {
     const int ty = tt / TX, tx = tt % TX;
-    const int g = min((y0 + 4 * ty) / H, G);                    // image boundaries (= shared zero rows) above this tile;
+    const int g = min((y0 + 4 * ty) / Hp, G);                    // image boundaries (= shared zero rows) above this tile;
                                                                 // tiles past the last image (never stored) stay inside the patch
     tbase = tc * PLANE + ((4 * ty + g) * RS + 4 * tx) * 4;
   }
@@ -357,22 +358,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
 #endif
         const int ty = tile / TX, tx = tile % TX;
         const int R = R0 + 4 * ty;
-        if (R < Rtot) {
+        const int n = R / Hp, yy = R % Hp, xx = x0 + 4 * tx;
+        if (n < Btot) {
           if (POOL) {
-            const int n = R / H, yy = R % H;
 #pragma unroll
             for (int a = 0; a < 2; a++)
 #pragma unroll
               for (int b = 0; b < 2; b++) {
                 const float v = fmaxf(fmaxf(Y[2 * a][2 * b], Y[2 * a][2 * b + 1]), fmaxf(Y[2 * a + 1][2 * b], Y[2 * a + 1][2 * b + 1]));
-                const long opix = ((long)n * Ho + (yy >> 1) + a) * Wo + ((x0 >> 1) + 2 * tx + b);
-                y[opix * Cout + co] = v;
+                const int py = (yy >> 1) + a, px = (xx >> 1) + b;
+                if (py < Ho && px < Wo) y[(((long)n * Ho + py) * Wo + px) * Cout + co] = v;
               }
           } else {
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
-              for (int b = 0; b < 4; b++) y[((long)(R + a) * W + x0 + 4 * tx + b) * Cout + co] = Y[a][b];
+              for (int b = 0; b < 4; b++)
+                if (yy + a < H && xx + b < W) y[(((long)n * H + yy + a) * W + xx + b) * Cout + co] = Y[a][b];
           }
         }
       }
@@ -399,16 +401,21 @@ static int w4_max_boundaries(int H, int TH, long Rtot) {
   return best;
 }
 
-// patch (TY x TX tiles of 4x4 pixels): 1 = (4,8) 16x32 px, 2 = (8,4) 32x16, 3 = (16,2) 64x8, 4 = (32,1) 128x4
-static int w4_select(int W) {
-  if (W % 32 == 0) return 1;
-  if (W % 16 == 0) return 2;
-  if (W % 8 == 0) return 3;
-  if (W % 4 == 0) return 4;
-  return 0;
-}
+// patch (TY x TX tiles of 4x4 pixels): 1 = (4,8) 16x32 px, 2 = (8,4) 32x16, 3 = (16,2) 64x8, 4 = (32,1) 128x4.
+// The width is padded to a multiple of the patch width: pick the patch with the least padding, the widest on a tie.
+static int w4_tw(int sel) { return sel == 1 ? 32 : sel == 2 ? 16 : sel == 3 ? 8 : 4; }
 static int w4_th(int sel) { return sel == 1 ? 16 : sel == 2 ? 32 : sel == 3 ? 64 : 128; }
 static int w4_gmax(int sel) { return sel == 4 ? 5 : 2; }
+static int w4_select(int W) {
+  int best = 0, best_wp = 1 << 30;
+  for (int sel = 1; sel <= 4; sel++) {
+    const int tw = w4_tw(sel), wp = (W + tw - 1) / tw * tw;
+    if (wp < best_wp) { best_wp = wp; best = sel; }
+  }
+  return best;
+}
+static int w4_hp(int H) { return (H + 3) / 4 * 4; }
+static int w4_wp(int W, int sel) { const int tw = w4_tw(sel); return (W + tw - 1) / tw * tw; }
 
 template <int TY, int TX, int GMAX>
 static int launch_wino4(const float* x, const float* up, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
@@ -418,17 +425,17 @@ static int launch_wino4(const float* x, const float* up, const float* bias, floa
   constexpr int RAWSZ = 2 * AROUNDS * 64 * 4;
   constexpr int VSZ = 36 * 256;
   size_t lds = (size_t)(2 * VSZ + 2 * RAWSZ) * sizeof(float);
-  long Rtot = (long)B * H;
-  const int mtiles = cdiv(Rtot, 4 * TY) * (W / (4 * TX));
+  const int Hp = w4_hp(H), Wp = (W + 4 * TX - 1) / (4 * TX) * (4 * TX);
+  const int mtiles = cdiv((long)B * Hp, 4 * TY) * (Wp / (4 * TX));
   dim3 grid(((mtiles + 7) / 8) * 8 * (Cout / 64));
   if (pool) {
     auto k = conv3x3_wino4_kernel<TY, TX, GMAX, true>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, grid, dim3(512), lds, st, x, up, bias, y, B, H, W, Cin, Cout, relu, G);
+    hipLaunchKernelGGL(k, grid, dim3(512), lds, st, x, up, bias, y, B, H, W, Cin, Cout, relu, G, Hp, Wp);
   } else {
     auto k = conv3x3_wino4_kernel<TY, TX, GMAX, false>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, grid, dim3(512), lds, st, x, up, bias, y, B, H, W, Cin, Cout, relu, G);
+    hipLaunchKernelGGL(k, grid, dim3(512), lds, st, x, up, bias, y, B, H, W, Cin, Cout, relu, G, Hp, Wp);
   }
   return lct_check_launch("conv3x3_wino4");
 }
@@ -438,10 +445,13 @@ extern "C" {
 long lctvqa_conv3x3_wino4_packed_elems(int Cout, int Cin) { return (long)Cout * Cin * 36; }
 
 int lctvqa_conv3x3_wino4_supported(int B, int H, int W, int Cin, int Cout, int pool) {
-  if (Cin % 8 || Cin < 16 || Cout % 64 || (H & 3) || (W & 3)) return 0;
+  if (Cin % 8 || Cin < 16 || Cout % 64 || B < 1 || H < 2 || W < 2) return 0;
+  if (pool && ((H | W) & 1)) return 0;
   const int sel = w4_select(W);
-  if (!sel) return 0;
-  if (w4_max_boundaries(H, w4_th(sel), (long)B * H) > w4_gmax(sel)) return 0;
+  const int Hp = w4_hp(H);
+  // useful share of the padded tile grid: below 3/4 the F(2x2,3x3) kernel (no padding for even sizes) is the better choice
+  if ((long)H * W * 4 < (long)Hp * w4_wp(W, sel) * 3) return 0;
+  if (w4_max_boundaries(Hp, w4_th(sel), (long)B * Hp) > w4_gmax(sel)) return 0;
   if ((long)B * H * W * Cin >= (1L << 31)) return 0;
   return 1;
 }
@@ -461,7 +471,7 @@ int lctvqa_conv3x3_wino4_nhwc(const float* x, const float* u_packed, const float
   LCT_REQUIRE(lctvqa_conv3x3_wino4_supported(B, H, W, Cin, Cout, pool), "conv3x3_wino4: unsupported shape B=%d H=%d W=%d Cin=%d Cout=%d",
               B, H, W, Cin, Cout);
   const int sel = w4_select(W);
-  const int G = w4_max_boundaries(H, w4_th(sel), (long)B * H);
+  const int G = w4_max_boundaries(w4_hp(H), w4_th(sel), (long)B * w4_hp(H));
   switch (sel) {
     case 1: return launch_wino4<4, 8, 2>(x, u_packed, bias, y, B, H, W, Cin, Cout, relu, pool, G, st);
     case 2: return launch_wino4<8, 4, 2>(x, u_packed, bias, y, B, H, W, Cin, Cout, relu, pool, G, st);

@@ -65,6 +65,8 @@ def test_conv3x3_winograd(hip_lib, B, H, W, Cin, Cout, pool):
     (2, 56, 56, 128, 256, 0), (1, 56, 56, 256, 256, 1),   # (16,2) = 64x8 px
     (3, 28, 28, 256, 512, 0), (2, 28, 28, 512, 512, 1),   # (32,1) = 128x4 px: up to 5 image boundaries in a patch
     (5, 20, 20, 64, 64, 1), (1, 64, 48, 16, 64, 0), (2, 24, 8, 32, 128, 1), (6, 4, 4, 128, 64, 0),
+    (5, 14, 14, 512, 512, 0), (3, 14, 14, 512, 512, 1),   # padded tile grid: 14x14 runs as 16x16, outputs past 14 dropped
+    (2, 30, 30, 64, 128, 1), (3, 7, 7, 128, 64, 0), (2, 14, 30, 64, 64, 0),
 ])
 def test_conv3x3_winograd_f4x4(hip_lib, B, H, W, Cin, Cout, pool):
     """F(4x4,3x3): fp32 with the published transform constants; error budget 3e-5 of the layer's largest output on signed
@@ -79,7 +81,9 @@ def test_conv3x3_winograd_f4x4_full_res_and_limits(hip_lib):
         assert _wino_case(hip_lib, 1, H, H, Cin, Cout, pool, variant='wino4') < 3e-5
     for (H, Cin, Cout, pool) in [(224, 64, 64, 1), (112, 128, 128, 1), (56, 256, 256, 0), (28, 512, 512, 0)]:
         assert hip_lib.query('conv3x3_wino4_supported', 256, H, H, Cin, Cout, pool) == 1
-    assert hip_lib.query('conv3x3_wino4_supported', 256, 14, 14, 512, 512, 0) == 0      # 14 is not a multiple of 4: F(2x2,3x3)
+    assert hip_lib.query('conv3x3_wino4_supported', 256, 14, 14, 512, 512, 0) == 1      # runs on a 16x16 tile grid (77 % useful)
+    assert hip_lib.query('conv3x3_wino4_supported', 4, 10, 10, 64, 64, 0) == 0          # 69 % useful: left to F(2x2,3x3)
+    assert hip_lib.query('conv3x3_wino4_supported', 4, 7, 7, 64, 64, 1) == 0            # pooling needs even sizes
     assert hip_lib.query('conv3x3_wino4_supported', 4, 28, 28, 512, 32, 0) == 0
 
 
