@@ -70,3 +70,43 @@ def test_full_size_train_step_touches_exactly_the_trainable_parameters(full):
             assert (p.detach() - before[n]).abs().max() <= 1.0001e-3 + 1e-9, n    # |Adam step| <= lr on the first step
         else:
             assert not moved, n                                      # the frozen trunk (models.py:35-36)
+
+
+VGG_LAYERS = [(224, 64, 64, 1), (112, 64, 128, 0), (112, 128, 128, 1), (56, 128, 256, 0), (56, 256, 256, 0), (56, 256, 256, 1),
+              (28, 256, 512, 0), (28, 512, 512, 0), (28, 512, 512, 1), (14, 512, 512, 0), (14, 512, 512, 1)]
+
+
+@pytest.mark.parametrize('H,Cin,Cout,pool', VGG_LAYERS)
+def test_full_size_conv_layers_agree_across_algorithms_and_are_linear(hip_lib, H, Cin, Cout, pool):
+    """Every distinct trunk layer at the benchmark's size (B=256): the F(4x4,3x3) and F(2x2,3x3) kernels against the direct
+    kernel on the same inputs, and linearity of the un-activated convolution, conv(a x + z) = a conv(x) + conv(z)."""
+    B = 256 if H <= 112 else 64                                   # 224x224x64: 64 images keep the three buffers < 10 GB
+    g = torch.Generator().manual_seed(H * 1000 + Cin)
+    x = torch.randn(B, H, H, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(DEV)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    Ho = H // 2 if pool else H
+
+    def run(variant, xin, relu, pl, bias=b):
+        out = torch.full((B, H // 2 if pl else H, H // 2 if pl else H, Cout), float('nan'), device=DEV)
+        if variant == 'direct':
+            assert hip_lib.query('conv3x3_uses_mfma', B, H, H, Cin, Cout, pl)
+            wp = torch.empty(Cout * Cin * 9, device=DEV)
+            hip_lib('conv3x3_pack_weights', w, wp, Cout, Cin)
+            hip_lib('conv3x3_nhwc', xin, w, wp, bias, out, None, B, H, H, Cin, Cout, relu, pl)
+        else:
+            assert hip_lib.query(f'conv3x3_{variant}_supported', B, H, H, Cin, Cout, pl)
+            up = torch.empty(hip_lib.query(f'conv3x3_{variant}_packed_elems', Cout, Cin), device=DEV)
+            hip_lib(f'conv3x3_{variant}_pack_weights', w, up, Cout, Cin, 0)
+            hip_lib(f'conv3x3_{variant}_nhwc', xin, up, bias, out, B, H, H, Cin, Cout, relu, pl)
+        return out
+
+    ref = run('direct', x, 1, pool)
+    assert ref.shape == (B, Ho, Ho, Cout) and torch.isfinite(ref).all()
+    for variant, tol in (('wino4', 3e-5), ('wino', 5e-6)):
+        got = run(variant, x, 1, pool)
+        assert rel_err(got, ref) < tol, variant
+    z = torch.randn(B, H, H, Cin, generator=g).to(DEV)
+    lhs = run('wino4', 0.5 * x + z, 0, 0, None)
+    rhs = 0.5 * run('wino4', x, 0, 0, None) + run('wino4', z, 0, 0, None)
+    assert rel_err(lhs, rhs) < 1e-4                               # three F(4x4,3x3) evaluations, each within 3e-5
