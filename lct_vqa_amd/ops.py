@@ -594,7 +594,7 @@ _CONV_ALGOS = ('winograd', 'winograd2', 'direct')
 
 def set_conv_algo(name):
     """Trunk convolution algorithm, all fp32 on the MFMA pipe:
-    'winograd'  (default) F(4x4,3x3) where the shape allows (H, W multiples of 4), else F(2x2,3x3), else direct;
+    'winograd'  (default) F(4x4,3x3) where at least 3/4 of the (padded) 4x4-tile grid is useful, else F(2x2,3x3), else direct;
     'winograd2' F(2x2,3x3) where the shape allows, else direct;
     'direct'    the implicit-GEMM kernel only.
     Returns the previous setting."""
