@@ -1,159 +1,186 @@
-"""PC-DARTS search network (reference basic_vqa/pcdarts/model_search.py:11-250; darts_vqa adds
-save/load_arch_parameters, darts_vqa/pcdarts/model_search.py:204-217).  Activations are NHWC internally; the
-network takes the reference's NCHW image and returns the reference's [B, 256*7*7] feature (NCHW flatten order)."""
+"""PC-DARTS search network on the HIP primitives.
+
+Drop-in for reference basic_vqa/pcdarts/model_search.py:11-250 (and darts_vqa's copy, which adds
+``save_arch_parameters`` / ``load_arch_parameters``, darts_vqa/pcdarts/model_search.py:204-217): ``MixedOp``, ``Cell`` and
+``Network`` keep the reference's constructor arguments, attribute names (``_ops``, ``preprocess0/1``, ``stem``, ``cells``,
+``alphas_*``, ``betas_*``), module creation order (=> identical ``state_dict`` keys and, for the same seed, identical initial
+parameters and architecture parameters), ``new()``, ``_loss``, ``arch_parameters()`` and ``genotype()``.
+
+How it runs is this package's own:
+  * activations are NHWC; the network takes the reference's NCHW image and returns its ``[B, 256*7*7]`` feature in NCHW
+    flatten order (one kernel does the 7x7 average pool and the re-ordering);
+  * a MixedOp computes its 7 live branches on the first C/4 channels and hands them to ONE kernel that forms the
+    alpha-weighted sum, appends the bypass channels (2x2 max-pooled on reduction edges), applies the channel shuffle and
+    accumulates beta * result into the node's running sum -- the reference's sum / cat / shuffle / beta-scale / node-sum
+    chain never materialises; the 'none' branch is skipped (it adds zero and gets a zero gradient);
+  * the DAG bookkeeping (which edge feeds which node, where a node's edges sit in the flat alpha / beta tables) lives in
+    two small helpers, ``_node_slices`` and ``_edge_inputs``, shared by construction, forward and ``genotype()``.
+"""
 import weakref
 
+import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ... import darts_ops as D
 from .. import config as _config
 from .genotypes import PRIMITIVES, Genotype
 from .operations import OPS, FactorizedReduce, Identity, ReLUConvBN, Zero  # noqa: F401
 
+_ARCH_NAMES = ('alphas_normal', 'alphas_reduce', 'betas_normal', 'betas_reduce')
+
+
+def _node_slices(steps):
+    """[(first, last+1)] positions of each intermediate node's incoming edges in the flat edge tables: node i has 2 + i."""
+    out, first = [], 0
+    for i in range(steps):
+        out.append((first, first + 2 + i))
+        first += 2 + i
+    return out
+
+
+def _edge_inputs(steps):
+    """Input state index of every edge, in table order: 0, 1 | 0, 1, 2 | ..."""
+    return [j for i in range(steps) for j in range(2 + i)]
+
 
 def channel_shuffle(x, groups):
-    """Reference semantics on an NHWC tensor (only used by tests; MixedOp fuses the shuffle)."""
+    """The reference's channel shuffle on an NHWC tensor (tests only; MixedOp's combine kernel fuses it)."""
     B, H, W, C = x.shape
     return x.view(B, H, W, groups, C // groups).transpose(3, 4).reshape(B, H, W, C)
 
 
 class MixedOp(nn.Module):
+    """All primitives on a quarter of the channels (partial-channel connection, k = 4), the rest bypasses."""
 
     def __init__(self, C, stride):
-        super(MixedOp, self).__init__()
+        super().__init__()
+        self.k, self.stride = 4, stride
         self._ops = nn.ModuleList()
-        self.mp = nn.MaxPool2d(2, 2)
-        self.k = 4
-        self.stride = stride
-        for primitive in PRIMITIVES:
-            op = OPS[primitive](C // self.k, stride, False)
-            if 'pool' in primitive:
-                op = nn.Sequential(op, nn.BatchNorm2d(C // self.k, affine=False))
-            self._ops.append(op)
+        self.mp = nn.MaxPool2d(2, 2)                               # holder for the reference's attribute; the kernel pools
+        part = C // self.k
+        for name in PRIMITIVES:
+            op = OPS[name](part, stride, False)
+            self._ops.append(nn.Sequential(op, nn.BatchNorm2d(part, affine=False)) if 'pool' in name else op)
+        self._live = [i for i, op in enumerate(self._ops) if not isinstance(op, Zero)]
+        self._live_index = {}                                      # device -> int64 tensor of self._live
 
     def branches(self, x):
-        """-> (list of branch tensors on the first C/4 channels, indices of their primitives)."""
-        C = x.shape[3]
-        xtemp = D.SliceChannelsFn.apply(x, 0, C // self.k)
-        outs, idx = [], []
-        for k, op in enumerate(self._ops):
-            if isinstance(op, Zero):
-                continue
+        """(outputs of the live primitives on x[..., :C/4], their positions in PRIMITIVES)."""
+        part = D.SliceChannelsFn.apply(x, 0, x.shape[3] // self.k)
+        outs = []
+        for i in self._live:
+            op = self._ops[i]
             if isinstance(op, Identity):
-                outs.append(xtemp)
+                outs.append(part)
             elif isinstance(op, nn.Sequential):
-                outs.append(D.run_seq(op, xtemp))
+                outs.append(D.run_seq(op, part))
             else:
-                outs.append(op(xtemp))
-            idx.append(k)
-        return outs, idx
+                outs.append(op(part))
+        return outs, self._live
 
     def forward(self, x, weights, state=None, beta=None):
-        """state (+)= beta * channel_shuffle(cat(sum_k w_k op_k(x[:C/4]), bypass(x[C/4:])), 4).
-        With state=None and beta=None this is the reference's MixedOp.forward(x, weights)."""
-        outs, idx = self.branches(x)
-        wsel = weights[torch.as_tensor(idx, device=weights.device)]
+        """``state (+)= beta * shuffle(cat(sum_k w_k op_k(x[:C/4]), bypass(x[C/4:])))``; with the defaults this is the
+        reference's ``MixedOp.forward(x, weights)``."""
+        outs, live = self.branches(x)
+        idx = self._live_index.get(weights.device)
+        if idx is None:
+            idx = self._live_index[weights.device] = torch.as_tensor(live, device=weights.device)
         if beta is None:
             beta = torch.ones(1, dtype=torch.float32, device=x.device)
-        return D.MixedCombineFn.apply(state, x, wsel, beta.reshape(1), self.stride == 2, *outs)
+        return D.MixedCombineFn.apply(state, x, weights[idx], beta.reshape(1), self.stride == 2, *outs)
 
 
 class Cell(nn.Module):
 
     def __init__(self, steps, multiplier, C_prev_prev, C_prev, C, reduction, reduction_prev):
-        super(Cell, self).__init__()
-        self.reduction = reduction
-        if reduction_prev:
-            self.preprocess0 = FactorizedReduce(C_prev_prev, C, affine=False)
-        else:
-            self.preprocess0 = ReLUConvBN(C_prev_prev, C, 1, 1, 0, affine=False)
+        super().__init__()
+        self.reduction, self._steps, self._multiplier = reduction, steps, multiplier
+        first = FactorizedReduce(C_prev_prev, C, affine=False) if reduction_prev else ReLUConvBN(C_prev_prev, C, 1, 1, 0, affine=False)
+        self.preprocess0 = first
         self.preprocess1 = ReLUConvBN(C_prev, C, 1, 1, 0, affine=False)
-        self._steps = steps
-        self._multiplier = multiplier
         self._ops = nn.ModuleList()
-        self._bns = nn.ModuleList()
-        for i in range(self._steps):
-            for j in range(2 + i):
-                stride = 2 if reduction and j < 2 else 1
-                self._ops.append(MixedOp(C, stride))
+        self._bns = nn.ModuleList()                                # empty in the reference too; kept for the key layout
+        for src in _edge_inputs(steps):
+            self._ops.append(MixedOp(C, 2 if reduction and src < 2 else 1))
 
     def forward(self, s0, s1, weights, weights2):
-        s0 = self.preprocess0(s0)
-        s1 = self.preprocess1(s1)
-        states = [s0, s1]
-        offset = 0
-        for i in range(self._steps):
-            s = None
-            for j, h in enumerate(states):
-                s = self._ops[offset + j](h, weights[offset + j], s, weights2[offset + j])
-            offset += len(states)
-            states.append(s)
+        states = [self.preprocess0(s0), self.preprocess1(s1)]
+        for first, last in _node_slices(self._steps):
+            node = None
+            for e in range(first, last):                           # edge e reads state e - first; the kernel accumulates
+                node = self._ops[e](states[e - first], weights[e], node, weights2[e])
+            states.append(node)
         return torch.cat(states[-self._multiplier:], dim=3)
 
 
 class Network(nn.Module):
 
     def __init__(self, C, num_classes, layers, vqa_model=None, steps=4, multiplier=4, stem_multiplier=3):
-        super(Network, self).__init__()
-        self._C = C
-        self._num_classes = num_classes
-        self._layers = layers
+        super().__init__()
+        self._C, self._num_classes, self._layers = C, num_classes, layers
+        self._steps, self._multiplier = steps, multiplier
         self._criterion = nn.CrossEntropyLoss()
         self._vqa_model = weakref.ref(vqa_model) if vqa_model is not None else (lambda: None)
-        self._steps = steps
-        self._multiplier = multiplier
-        C_curr = stem_multiplier * C
-        self.stem = nn.Sequential(
-            nn.Conv2d(3, C_curr, 3, padding=1, bias=False),
-            nn.BatchNorm2d(C_curr))
-        C_prev_prev, C_prev, C_curr = C_curr, C_curr, C
+        width = stem_multiplier * C
+        self.stem = nn.Sequential(nn.Conv2d(3, width, 3, padding=1, bias=False), nn.BatchNorm2d(width))
         self.cells = nn.ModuleList()
-        reduction_prev = False
+        before_last, last, cur, was_reduction = width, width, C, False
         for i in range(layers):
-            if i in [layers // 3, 2 * layers // 3]:
-                C_curr *= 2
-                reduction = True
-            else:
-                reduction = False
-            cell = Cell(steps, multiplier, C_prev_prev, C_prev, C_curr, reduction, reduction_prev)
-            reduction_prev = reduction
-            self.cells += [cell]
-            C_prev_prev, C_prev = C_prev, multiplier * C_curr
+            is_reduction = i in (layers // 3, 2 * layers // 3)     # the channel count doubles where the map halves
+            if is_reduction:
+                cur *= 2
+            self.cells.append(Cell(steps, multiplier, before_last, last, cur, is_reduction, was_reduction))
+            before_last, last, was_reduction = last, multiplier * cur, is_reduction
         self.global_pooling = nn.AdaptiveAvgPool2d(7)
-        self.output_ch = 256
-        self.output_size = 7
+        self.output_ch, self.output_size = 256, 7
         self._initialize_alphas()
 
+    # ---- architecture parameters --------------------------------------------------------------------------------
+    def _initialize_alphas(self):
+        """alpha [edges, primitives] and beta [edges] per cell type, 1e-3 * N(0,1), drawn on the host in the reference's
+        order (normal alpha, reduce alpha, normal beta, reduce beta) and kept as plain leaf tensors, not Parameters."""
+        dev = _config.active().DEVICE
+        edges = len(_edge_inputs(self._steps))
+        shapes = {'alphas_normal': (edges, len(PRIMITIVES)), 'alphas_reduce': (edges, len(PRIMITIVES)),
+                  'betas_normal': (edges,), 'betas_reduce': (edges,)}
+        for name in _ARCH_NAMES:
+            setattr(self, name, (1e-3 * torch.randn(*shapes[name])).to(dev).requires_grad_(True))
+        self._arch_parameters = [getattr(self, name) for name in _ARCH_NAMES]
+
+    def arch_parameters(self):
+        return self._arch_parameters
+
+    def save_arch_parameters(self, path):
+        torch.save({name: getattr(self, name) for name in _ARCH_NAMES}, path)
+
+    def load_arch_parameters(self, path):
+        stored = torch.load(path, map_location=self.alphas_normal.device)
+        for name in _ARCH_NAMES:
+            getattr(self, name).data.copy_(stored[name].data)
+
     def new(self):
-        model_new = Network(self._C, self._num_classes, self._layers, self._vqa_model()).to(_config.active().DEVICE)
-        for x, y in zip(model_new.arch_parameters(), self.arch_parameters()):
-            x.data.copy_(y.data)
-        return model_new
+        """A fresh network of the same geometry on config.DEVICE carrying a copy of the architecture parameters."""
+        twin = Network(self._C, self._num_classes, self._layers, self._vqa_model()).to(_config.active().DEVICE)
+        for mine, theirs in zip(self.arch_parameters(), twin.arch_parameters()):
+            theirs.data.copy_(mine.data)
+        return twin
 
     def _edge_weights(self, alphas, betas):
-        weights = F.softmax(alphas, dim=-1)
-        n, start = 3, 2
-        weights2 = F.softmax(betas[0:2], dim=-1)
-        for _ in range(self._steps - 1):
-            end = start + n
-            weights2 = torch.cat([weights2, F.softmax(betas[start:end], dim=-1)], dim=0)
-            start = end
-            n += 1
-        return weights, weights2
+        """(softmax over primitives per edge, softmax over the incoming edges of each node)."""
+        per_node = [torch.softmax(betas[a:b], dim=-1) for a, b in _node_slices(self._steps)]
+        return torch.softmax(alphas, dim=-1), torch.cat(per_node, dim=0)
 
+    # ---- forward --------------------------------------------------------------------------------------------------
     def forward(self, input):
         N, _, H, W = input.shape
-        input = input.expand(N, 3, H, W).contiguous()
-        s = D.StemConvFn.apply(input, self.stem[0].weight)
-        s0 = s1 = D.batchnorm(self.stem[1], s)
+        image = input.expand(N, 3, H, W).contiguous()
+        stem = D.batchnorm(self.stem[1], D.StemConvFn.apply(image, self.stem[0].weight))
+        table = {False: self._edge_weights(self.alphas_normal, self.betas_normal),
+                 True: self._edge_weights(self.alphas_reduce, self.betas_reduce)}
+        s0 = s1 = stem
         for cell in self.cells:
-            if cell.reduction:
-                weights, weights2 = self._edge_weights(self.alphas_reduce, self.betas_reduce)
-            else:
-                weights, weights2 = self._edge_weights(self.alphas_normal, self.betas_normal)
-            s0, s1 = s1, cell(s0, s1, weights, weights2)
+            s0, s1 = s1, cell(s0, s1, *table[cell.reduction])
         return D.AvgPool7FlattenFn.apply(s1)
 
     def _loss(self, images, questions, labels):
@@ -161,54 +188,24 @@ class Network(nn.Module):
         logits, _ = self._vqa_model()(images, questions)
         return ops.cross_entropy(logits, labels)
 
-    def _initialize_alphas(self):
-        dev = _config.active().DEVICE
-        k = sum(1 for i in range(self._steps) for n in range(2 + i))
-        num_ops = len(PRIMITIVES)
-        self.alphas_normal = (1e-3 * torch.randn(k, num_ops)).to(dev).requires_grad_(True)
-        self.alphas_reduce = (1e-3 * torch.randn(k, num_ops)).to(dev).requires_grad_(True)
-        self.betas_normal = (1e-3 * torch.randn(k)).to(dev).requires_grad_(True)
-        self.betas_reduce = (1e-3 * torch.randn(k)).to(dev).requires_grad_(True)
-        self._arch_parameters = [self.alphas_normal, self.alphas_reduce, self.betas_normal, self.betas_reduce]
-
-    def arch_parameters(self):
-        return self._arch_parameters
-
-    def save_arch_parameters(self, path):
-        torch.save({'alphas_normal': self.alphas_normal, 'alphas_reduce': self.alphas_reduce,
-                    'betas_normal': self.betas_normal, 'betas_reduce': self.betas_reduce}, path)
-
-    def load_arch_parameters(self, path):
-        st = torch.load(path, map_location=self.alphas_normal.device)
-        for name in ('alphas_normal', 'alphas_reduce', 'betas_normal', 'betas_reduce'):
-            getattr(self, name).data.copy_(st[name].data)
-
+    # ---- discretisation -------------------------------------------------------------------------------------------
     def genotype(self):
-        none_idx = PRIMITIVES.index('none')
+        """For every node keep the two incoming edges with the strongest non-'none' primitive (strength = alpha-softmax x
+        beta-softmax) and that primitive; ties go to the lower index, edges are listed strongest first."""
+        none = PRIMITIVES.index('none')
 
-        def _parse(weights, weights2):
-            gene, n, start = [], 2, 0
-            for i in range(self._steps):
-                end = start + n
-                Wt = weights[start:end].copy()
-                W2 = weights2[start:end].copy()
-                for j in range(n):
-                    Wt[j, :] = Wt[j, :] * W2[j]
-                edges = sorted(range(i + 2),
-                               key=lambda x: -max(Wt[x][k] for k in range(len(Wt[x])) if k != none_idx))[:2]
-                for j in edges:
-                    k_best = None
-                    for k in range(len(Wt[j])):
-                        if k != none_idx and (k_best is None or Wt[j][k] > Wt[j][k_best]):
-                            k_best = k
-                    gene.append((PRIMITIVES[k_best], j))
-                start = end
-                n += 1
+        def decode(alphas, betas):
+            w, w2 = self._edge_weights(alphas, betas)
+            strength = (w * w2.unsqueeze(1)).detach().cpu().numpy().astype(np.float32)
+            strength[:, none] = -np.inf
+            gene = []
+            for first, last in _node_slices(self._steps):
+                best_op = strength[first:last].argmax(axis=1)                       # first maximum, like a strict '>' scan
+                best_val = strength[first:last].max(axis=1)
+                for j in sorted(range(last - first), key=lambda e: -best_val[e])[:2]:   # stable: lower edge wins a tie
+                    gene.append((PRIMITIVES[int(best_op[j])], j))
             return gene
 
-        wn, wn2 = self._edge_weights(self.alphas_normal, self.betas_normal)
-        wr, wr2 = self._edge_weights(self.alphas_reduce, self.betas_reduce)
-        gene_normal = _parse(wn.data.cpu().numpy(), wn2.data.cpu().numpy())
-        gene_reduce = _parse(wr.data.cpu().numpy(), wr2.data.cpu().numpy())
         concat = range(2 + self._steps - self._multiplier, self._steps + 2)
-        return Genotype(normal=gene_normal, normal_concat=concat, reduce=gene_reduce, reduce_concat=concat)
+        return Genotype(normal=decode(self.alphas_normal, self.betas_normal), normal_concat=concat,
+                        reduce=decode(self.alphas_reduce, self.betas_reduce), reduce_concat=concat)

@@ -1,0 +1,78 @@
+"""Shared machinery of the architecture-gradient steps (the callers of the hot path that SURVEY.md section 8 lists as
+a-15: reference basic_vqa/pcdarts/architect.py:12-109, architect_lct.py:13-235, darts_vqa/pcdarts/architect_vqa.py:10-145).
+
+What those steps need, expressed once:
+
+* ``grads``          d loss / d tensors with unreached tensors as zeros, and the reference's check of HOW MANY were unreached
+                     (36 for the W model with its frozen trunk, 2 for EF' under W's soft loss, 6 for ``qst_only``, else 0);
+* ``virtual_step``   a twin of a model one plain SGD step ahead, theta' = theta - lr * g (the reference's momentum and
+                     weight-decay terms are identically zero: its ``network_momentum`` / ``*_weight_decay`` are 0);
+* ``fd_grad``        a central finite difference of a gradient-valued closure along a direction in parameter space,
+                     (f(theta + R v) - f(theta - R v)) / 2R with R = r / ||v||, the Hessian-vector products of DARTS.
+
+The reference does this on concatenated copies of every parameter (``_concat``: two 622 MB vectors per unrolled W
+model).  Here nothing is concatenated: the twin comes from the model's own ``new()`` + ``load_state_dict`` and the
+parameter-space updates are one multi-tensor launch each, in place on the live parameters (restored afterwards) --
+exactly the in-place ``p.data`` writes the kernels are required to observe, which is why no kernel
+caches anything derived from a trainable parameter.
+"""
+import torch
+
+
+def grads(loss, tensors, expect_unused=None):
+    """Gradients of ``loss`` w.r.t. ``tensors`` as a list; tensors the graph does not reach get zeros.  When
+    ``expect_unused`` is given, the number of unreached tensors must equal it (the reference asserts these counts)."""
+    tensors = list(tensors)
+    got = torch.autograd.grad(loss, tensors, allow_unused=True)
+    unused = sum(g is None for g in got)
+    if expect_unused is not None and unused != expect_unused:
+        raise AssertionError(f'{unused} tensors received no gradient, expected {expect_unused}')
+    return [torch.zeros_like(t) if g is None else g for g, t in zip(got, tensors)]
+
+
+def global_norm(vectors):
+    """||concat(vectors)||_2 without concatenating."""
+    return torch.linalg.vector_norm(torch.stack(torch._foreach_norm(list(vectors))))
+
+
+@torch.no_grad()
+def shift_(params, direction, alpha):
+    """params += alpha * direction, in place and behind autograd's back (one multi-tensor launch)."""
+    torch._foreach_add_([p.data for p in params], list(direction), alpha=alpha)
+
+
+def virtual_step(model, g, lr):
+    """An independent copy of ``model`` (its own ``new()``: same class, same device, architecture parameters included)
+    whose parameters are theta - lr * g; buffers are copied as they are."""
+    twin = model.new()
+    twin.load_state_dict(model.state_dict())
+    shift_(list(twin.parameters()), g, -lr)
+    return twin
+
+
+def fd_grad(params, direction, closure, r=1e-2):
+    """Central difference of the list-valued ``closure()`` along ``direction`` in the space of ``params``.  The closure
+    is evaluated with the live parameters moved to theta + R v and theta - R v (R = r / ||v||); they are back at theta
+    (up to fp32 rounding of the three in-place adds, like the reference) when this returns."""
+    params, direction = list(params), list(direction)
+    R = float(r / global_norm(direction))
+    shift_(params, direction, R)
+    plus = closure()
+    shift_(params, direction, -2.0 * R)
+    minus = closure()
+    shift_(params, direction, R)
+    return [(a - b) / (2.0 * R) for a, b in zip(plus, minus)]
+
+
+def set_grads(tensors, values):
+    """tensor.grad = value (copied), whether or not a .grad exists already."""
+    for t, v in zip(tensors, values):
+        if t.grad is None:
+            t.grad = v.detach().clone()
+        else:
+            t.grad.detach().copy_(v)
+
+
+def arch_optimizer(arch_parameters, lr, weight_decay):
+    """Adam(betas=(0.5, 0.999)) on the architecture parameters (252 floats: host-side torch.optim is the right tool)."""
+    return torch.optim.Adam(arch_parameters, lr=lr, betas=(0.5, 0.999), weight_decay=weight_decay)

@@ -61,7 +61,7 @@ def _arch_vqa_steps(m, fx, Architect, img, qst, lab, vimg, vqst, vlab):
         args = types.SimpleNamespace(arch_learn_rate=6e-4, arch_wt_decay=1e-3, qst_only=bool(qst_only))
         arch = Architect(m, args)
         arch.optimizer.zero_grad()
-        arch._backward_step_unrolled(img, qst, lab, vimg, vqst, vlab, 1e-3, None)      # asserts the None-count (0 / 6)
+        arch.compute_grads(img, qst, lab, vimg, vqst, vlab, 1e-3)                     # asserts the None-count (0 / 6)
         close_arch([a.grad for a in m.arch_parameters()], fx[f'arch_grads_{qst_only}'], 2e-2)
         arch.optimizer.step()
         for a, r in zip(m.arch_parameters(), fx[f'arch_after_{qst_only}']):
@@ -104,7 +104,7 @@ def test_ef_darts_model_and_lct_architect(hip_lib):
         arch = ArchitectLct(ef, w, FusedAdam(ef.parameters(), lr=1e-3), FusedAdam(w.parameters(), lr=1e-3))
         arch.optimizer.zero_grad()
         with ops.dropout_disabled():
-            arch._backward_step_unrolled(img, qst, lab, vimg, vqst, vlab, 1e-3, 1e-3)  # asserts None-counts 0 / 36 / 2
+            arch.compute_grads(img, qst, lab, vimg, vqst, vlab, 1e-3, 1e-3)           # asserts None-counts 0 / 36 / 2
         close_arch([a.grad for a in ef.arch_parameters()], fx['lct_arch_grads'], 0.25)
         arch.optimizer.step()
         for a, r in zip(ef.arch_parameters(), fx['lct_arch_after']):
