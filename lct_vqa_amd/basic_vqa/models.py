@@ -16,12 +16,9 @@ class ImgEncoder(nn.Module):
     """Frozen VGG19 (minus last fc) -> fc -> / detached L2 norm (reference models.py:12-42)."""
 
     def __init__(self, embed_size):
-        super(ImgEncoder, self).__init__()
-        model = vgg.vgg19(pretrained=True)
-        in_features = model.classifier[-1].in_features
-        model.classifier = nn.Sequential(*list(model.classifier.children())[:-1])
-        self.model = model
-        self.fc = nn.Linear(in_features, embed_size)
+        super().__init__()
+        self.model, width = vgg.truncated_vgg19(pretrained=True)
+        self.fc = nn.Linear(width, embed_size)
 
     def trunk(self, image, conv_feature=None):
         """The frozen part only (VGG19 minus its last fc, under no_grad): [B,4096].  It does not depend on any
@@ -36,8 +33,7 @@ class ImgEncoder(nn.Module):
 
     def forward(self, image, trunk_feature=None, conv_feature=None):
         img_feature = self.trunk(image, conv_feature) if trunk_feature is None else trunk_feature
-        img_feature = ops.linear(img_feature, self.fc.weight, self.fc.bias)
-        return ops.L2NormFn.apply(img_feature)
+        return vgg.embed_feature(img_feature, self.fc)
 
 
 def _single_layer(lstm):

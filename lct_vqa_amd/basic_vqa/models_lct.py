@@ -19,9 +19,7 @@ class ImgEncoder(nn.Module):
         self.fc = nn.Linear(in_features, embed_size)
 
     def forward(self, image):
-        img_feature = self.darts(image)
-        img_feature = ops.linear(img_feature, self.fc.weight, self.fc.bias)
-        return ops.L2NormFn.apply(img_feature)
+        return vgg.embed_feature(self.darts(image), self.fc)
 
 
 class ImgEncoderFixed(nn.Module):
@@ -29,22 +27,15 @@ class ImgEncoderFixed(nn.Module):
     pretrained=True => trunk frozen under no_grad."""
 
     def __init__(self, embed_size, pretrained=True):
-        super(ImgEncoderFixed, self).__init__()
-        model = vgg.vgg19(pretrained=pretrained)
-        in_features = model.classifier[-1].in_features
-        model.classifier = nn.Sequential(*list(model.classifier.children())[:-1])
-        self.model = model
-        self.fc = nn.Linear(in_features, embed_size)
+        super().__init__()
+        self.model, width = vgg.truncated_vgg19(pretrained=pretrained)
+        self.fc = nn.Linear(width, embed_size)
         self.pretrained = pretrained
 
     def forward(self, image):
-        if self.pretrained:
-            with torch.no_grad():
-                img_feature = self.model(image)
-        else:
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not self.pretrained):      # frozen iff "pretrained"
             img_feature = self.model(image)
-        img_feature = ops.linear(img_feature, self.fc.weight, self.fc.bias)
-        return ops.L2NormFn.apply(img_feature)
+        return vgg.embed_feature(img_feature, self.fc)
 
 
 class QstEncoder(nn.Module):

@@ -15,18 +15,14 @@ class VggEncoder(nn.Module):
     """reference vqa_model.py:8-46"""
 
     def __init__(self, embed_size):
-        super(VggEncoder, self).__init__()
-        model = vgg.vgg19(pretrained=True)
-        in_features = model.classifier[-1].in_features
-        model.classifier = nn.Sequential(*list(model.classifier.children())[:-1])
-        self.model = model
-        self.fc = nn.Linear(in_features, embed_size)
+        super().__init__()
+        self.model, width = vgg.truncated_vgg19(pretrained=True)
+        self.fc = nn.Linear(width, embed_size)
 
     def forward(self, image):
         with torch.no_grad():
             img_feature = self.model(image)
-        img_feature = ops.linear(img_feature, self.fc.weight, self.fc.bias)
-        return ops.L2NormFn.apply(img_feature)
+        return vgg.embed_feature(img_feature, self.fc)
 
 
 class DartsEncoder(nn.Module):
@@ -39,9 +35,7 @@ class DartsEncoder(nn.Module):
         self.fc = nn.Linear(in_features, embed_size)
 
     def forward(self, image):
-        img_feature = self.darts(image)
-        img_feature = ops.linear(img_feature, self.fc.weight, self.fc.bias)
-        return ops.L2NormFn.apply(img_feature)
+        return vgg.embed_feature(self.darts(image), self.fc)
 
 
 def get_img_encoder(img_encoder_type, embed_size):

@@ -96,3 +96,17 @@ class VGG(nn.Module):
 
 def vgg19(pretrained=False, **kw):
     return VGG(**kw)
+
+
+def truncated_vgg19(pretrained=True):
+    """(VGG19 without its last classifier layer, width of what is left): the image trunk every encoder of the reference
+    builds (basic_vqa/models.py:23-28, models_lct.py:46-51, darts_vqa/vqa_model.py:19-22)."""
+    model = vgg19(pretrained=pretrained)
+    width = model.classifier[-1].in_features
+    model.classifier = nn.Sequential(*list(model.classifier.children())[:-1])
+    return model, width
+
+
+def embed_feature(feature, fc):
+    """fc(feature) divided by its (detached) L2 norm -- the tail of every image encoder (models.py:37-40)."""
+    return ops.L2NormFn.apply(ops.linear(feature, fc.weight, fc.bias))
