@@ -16,6 +16,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--iters', type=int, default=3)
+    ap.add_argument('--vqa', action='store_true', help='also time a darts_vqa weight step and an Architect step')
     args = ap.parse_args()
     from lct_vqa_amd.basic_vqa import config
     config.DEVICE = torch.device('cuda')
@@ -33,6 +34,48 @@ def main():
     macs = 1408.9e6 * (args.size / 224.0) ** 2
     print(f'DARTS encoder fwd+bwd B={args.batch} {args.size}x{args.size}: {dt * 1e3:.1f} ms  '
           f'({args.batch / dt:.1f} img/s, ~{3 * 2 * macs * args.batch / dt / 1e12:.2f} TFLOP/s, peak mem {torch.cuda.max_memory_allocated() / 1e9:.1f} GB)')
+    if args.vqa:
+        del net, out, g
+        darts_vqa_step(args)
+
+
+def darts_vqa_step(args):
+    """BASELINE configs[4] in fp32 on one GPU: darts_vqa VqaModel(img_encoder_type='darts') weight step
+    (CE(ans) + CE(qst), clip, Adam) and the 2-level Architect.step that the driver runs beside it."""
+    import types
+    from lct_vqa_amd import ops
+    from lct_vqa_amd.darts_vqa import config as dconfig, factory
+    from lct_vqa_amd.basic_vqa import config as bconfig
+    dconfig.DEVICE = bconfig.DEVICE = torch.device('cuda')
+    a = types.SimpleNamespace(unified=False, embed_size=512, word_embed_size=300, num_layers=1, hidden_size=512, arch_type='darts',
+                              learn_rate=1e-3, step_size=10, gamma=0.1, arch_learn_rate=6e-4, arch_wt_decay=1e-3, qst_only=False)
+    ds = types.SimpleNamespace(qst_vocab=types.SimpleNamespace(vocab_size=17858), ans_vocab=types.SimpleNamespace(vocab_size=3129))
+    torch.manual_seed(10)
+    model = factory.get_vqa_model(a, ds).to('cuda').train()
+    opt = factory.get_optimizer(a, model)
+    arch = factory.get_architect(a, model)
+    B, S = args.batch, args.size
+    g = torch.Generator().manual_seed(10)
+    img = torch.randn(B, 3, S, S, generator=g).cuda()
+    qst = torch.randint(17858, (B, 14), generator=g); qst[:, 0] = 2
+    qst = qst.cuda()
+    lab = torch.randint(3129, (B,), generator=g).cuda()
+
+    def weight_step():
+        opt.zero_grad()
+        loss = model._loss(img, qst, lab, False)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        opt.step()
+
+    for name, fn in (('weight step', weight_step), ('Architect.step (2nd order)', lambda: arch.step(img, qst, lab, img, qst, lab, 1e-3, opt))):
+        for it in range(args.iters + 1):
+            if it == 1:
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.iters
+        print(f'darts_vqa {name} B={B} {S}x{S}: {dt * 1e3:.1f} ms  ({B / dt:.1f} pairs/s)')
 
 
 if __name__ == '__main__':
