@@ -354,6 +354,51 @@ __global__ void pool3x3_bwd_kernel(const float* __restrict__ dy, const float* __
   }
 }
 
+// float4 form (C % 4 == 0): thread = (input pixel, channel quad); the first-maximum search of every covering window runs
+// on four channels at once.
+__global__ void pool3x3_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int B,
+                                       int H, int W, int C, int s, int Ho, int Wo, int kind) {
+  const int CQ = C >> 2;
+  const f32x4* dy4 = (const f32x4*)dy;
+  const f32x4* x4 = (const f32x4*)x;
+  GRID_STRIDE(o, (long)B * H * W * CQ) {
+    const int cq = o % CQ; const long q = o / CQ; const int ix = q % W, iy = (q / W) % H, n = q / ((long)W * H);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int oy = (iy + 1 - 2 + s - 1) / s; oy * s - 1 <= iy && oy < Ho; oy++) {
+      if (oy < 0) continue;
+      for (int ox = (ix + 1 - 2 + s - 1) / s; ox * s - 1 <= ix && ox < Wo; ox++) {
+        if (ox < 0) continue;
+        const f32x4 g = dy4[(((long)n * Ho + oy) * Wo + ox) * CQ + cq];
+        if (kind) {
+          const int y0 = max(oy * s - 1, 0), y1 = min(oy * s + 1, H - 1), x0 = max(ox * s - 1, 0), x1 = min(ox * s + 1, W - 1);
+          a += g / (float)((y1 - y0 + 1) * (x1 - x0 + 1));
+        } else {
+          // per channel: is (iy,ix) the FIRST maximum (scan order) of window (oy,ox)?
+          f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+          int pos[4] = {-1, -1, -1, -1};
+          for (int ky = 0; ky < 3; ky++) {
+            const int yy = oy * s - 1 + ky;
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < 3; kx++) {
+              const int xx = ox * s - 1 + kx;
+              if (xx < 0 || xx >= W) continue;
+              const f32x4 v = x4[(((long)n * H + yy) * W + xx) * CQ + cq];
+#pragma unroll
+              for (int e = 0; e < 4; e++)
+                if (v[e] > best[e]) { best[e] = v[e]; pos[e] = yy * W + xx; }
+            }
+          }
+          const int me = iy * W + ix;
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            if (pos[e] == me) a[e] += g[e];
+        }
+      }
+    }
+    ((f32x4*)dx)[o] = a;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // spatial subsample with optional ReLU (FactorizedReduce, operations.py:100-104):
 //   y[n,oy,ox,:] = relu?(x[n, 2*oy+off, 2*ox+off, :])   and its backward (scatter, zero elsewhere)
@@ -750,8 +795,12 @@ int lctvqa_pool3x3_fwd(const float* x, float* y, int B, int H, int W, int C, int
 }
 int lctvqa_pool3x3_bwd(const float* dy, const float* x, float* dx, int B, int H, int W, int C, int stride, int kind, void* stream) {
   int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-  hipLaunchKernelGGL(pool3x3_bwd_kernel, dim3(gs_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, B, H, W,
-                     C, stride, Ho, Wo, kind);
+  if (C % 4 == 0 && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) & 15) == 0)
+    hipLaunchKernelGGL(pool3x3_bwd_vec_kernel, dim3(gs_blocks((long)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, x, dx,
+                       B, H, W, C, stride, Ho, Wo, kind);
+  else
+    hipLaunchKernelGGL(pool3x3_bwd_kernel, dim3(gs_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, B, H, W,
+                       C, stride, Ho, Wo, kind);
   return lct_check_launch("pool3x3_bwd");
 }
 
