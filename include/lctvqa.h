@@ -180,6 +180,12 @@ int lctvqa_dwconv_bwd_weight(const float* dy, const float* x, float* dw, float* 
                              int stride, int pad, int dil, int relu_in, void* stream);
 /* 1x1-conv weight gradient for small channel counts (Cout*Cin <= 4096): dw[Cout][Cin] = sum_p dy[p][Cout] x relu?(x[p][Cin]),
  * P = B*H*W pixels (operations.py:28,42,57,61 backward; replaces a P-deep 128x128 GEMM tile that is >98 % padding) */
+/* 1x1 conv with few channels (Cin, Cout in {4,8,16,32,64}; operations.py:28,42,57,61), thread-per-pixel instead of a GEMM tile:
+ * transpose = 0: out[P][Cout] = relu_in?(in[P][Cin]) . w[Cout][Cin]^T;   transpose = 1 (input gradient): out[P][Cin] =
+ * in[P][Cout] . w[Cout][Cin], multiplied by (relu_mask_x[P][Cin] > 0) when relu_mask_x is given */
+int lctvqa_pwconv_small_supported(long P, int Cout, int Cin);
+int lctvqa_pwconv_small(const float* in, const float* w, const float* relu_mask_x, float* out, long P, int Cout, int Cin, int relu_in,
+                        int transpose, void* stream);
 long lctvqa_pwconv_wgrad_small_scratch_elems(long P, int Cout, int Cin);
 int lctvqa_pwconv_wgrad_small_supported(long P, int Cout, int Cin);
 int lctvqa_pwconv_wgrad_small(const float* dy, const float* x, float* dw, float* scratch, long P, int Cout, int Cin, int relu_in,

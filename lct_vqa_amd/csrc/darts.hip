@@ -241,6 +241,51 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_vec_kernel(const float*
   }
 }
 
+// 1x1 convolution for small channel counts (Cin, Cout multiples of 4, Cout <= 64: the DARTS cells), forward and input
+// gradient in one kernel:   out[p][o] = sum_i relu?(in[p][i]) * W(o,i)   [* (mask[p][o] > 0)]
+//   forward : in = x,  W(o,i) = w[o][i],  relu? = the ReLU in front of the conv
+//   dgrad   : in = dy, W(o,i) = w[i][o] (TRANSPOSE),  mask = x (gradient of the same ReLU)
+// A P x 16 x 16 product is pure memory traffic; the generic 128x128 MFMA GEMM spends its time on padding.  thread = pixel:
+// reads its input row once (float4s), keeps all outputs in registers, takes the weights from LDS (every lane of a wave
+// reads the same address: broadcast), writes float4s.
+template <int NOUT, bool TRANSPOSE>
+__global__ __launch_bounds__(256) void pwconv_small_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                           const float* __restrict__ mask, float* __restrict__ out, long P, int NIN,
+                                                           int relu_in) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];    // [NOUT][NIN]
+  for (int t = threadIdx.x; t < NOUT * NIN; t += blockDim.x) {
+    const int o = t / NIN, i = t % NIN;
+    sw[t] = TRANSPOSE ? w[(long)i * NOUT + o] : w[t];
+  }
+  __syncthreads();
+  const int NQ = NIN >> 2;
+  const f32x4* in4 = (const f32x4*)in;
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+    float acc[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; o++) acc[o] = 0.f;
+    for (int q = 0; q < NQ; q++) {
+      f32x4 v = in4[p * NQ + q];
+      if (relu_in) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+#pragma unroll
+      for (int o = 0; o < NOUT; o++) {
+        const f32x4 wv = *(const f32x4*)(sw + o * NIN + 4 * q);
+        acc[o] = fmaf(v[0], wv[0], fmaf(v[1], wv[1], fmaf(v[2], wv[2], fmaf(v[3], wv[3], acc[o]))));
+      }
+    }
+    f32x4* o4 = (f32x4*)(out + p * NOUT);
+#pragma unroll
+    for (int oq = 0; oq < NOUT / 4; oq++) {
+      f32x4 r = {acc[4 * oq], acc[4 * oq + 1], acc[4 * oq + 2], acc[4 * oq + 3]};
+      if (mask) {
+        const f32x4 m = ((const f32x4*)(mask + p * NOUT))[oq];
+        r[0] = m[0] > 0.f ? r[0] : 0.f; r[1] = m[1] > 0.f ? r[1] : 0.f; r[2] = m[2] > 0.f ? r[2] : 0.f; r[3] = m[3] > 0.f ? r[3] : 0.f;
+      }
+      o4[oq] = r;
+    }
+  }
+}
+
 // 1x1-convolution weight gradient for small channel counts (Cout * Cin <= 4096; the DARTS cells: 4..64 channels):
 //   dw[co][ci] = sum_p dy[p][co] * relu?(x[p][ci]),  P = B*H*W pixels (10^5..10^6): a 16x16 "GEMM" with K = P, for which a
 // 128x128 MFMA tile is >98 % padding.  A block stages 256 pixels of dy and x in LDS (coalesced), thread = (output o,
@@ -695,6 +740,21 @@ static int red_blocks(long P, long* per_blk) {
   return (int)((P + *per_blk - 1) / *per_blk);
 }
 
+template <bool TR>
+static int launch_pwconv_small(const float* in, const float* w, const float* mask, float* out, long P, int NOUT, int NIN, int relu_in,
+                               hipStream_t st) {
+  long nb = (P + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  size_t lds = (size_t)NOUT * NIN * sizeof(float);
+#define PW_CASE(N) case N: hipLaunchKernelGGL((pwconv_small_kernel<N, TR>), dim3((int)nb), dim3(256), lds, st, in, w, mask, out, P, NIN, relu_in); break;
+  switch (NOUT) {
+    PW_CASE(4) PW_CASE(8) PW_CASE(16) PW_CASE(32) PW_CASE(64)
+    default: lct_set_error("pwconv_small: unsupported output width %d", NOUT); return LCT_EUNSUPPORTED;
+  }
+#undef PW_CASE
+  return lct_check_launch("pwconv_small");
+}
+
 extern "C" {
 
 int lctvqa_slice_channels(const float* x, long ldx, int c0, float* y, int Cn, long P, void* stream) {
@@ -764,6 +824,22 @@ int lctvqa_dwconv_bwd_weight(const float* dy, const float* x, float* dw, float* 
   if (rc) return rc;
   hipLaunchKernelGGL(dwconv_bwd_weight_finish_kernel, dim3(C * K * K), dim3(64), 0, (hipStream_t)stream, scratch, nb, C, K * K, dw);
   return lct_check_launch("dwconv_bwd_weight_finish");
+}
+
+// forward (transpose = 0: x [P][Cin], w [Cout][Cin] -> y [P][Cout], relu_in on x) and input gradient (transpose = 1:
+// dy [P][Cout], the same w -> dx [P][Cin], masked by relu_mask_x > 0 when given) of a 1x1 conv with few channels
+int lctvqa_pwconv_small_supported(long P, int Cout, int Cin) {
+  const int ok_out[] = {4, 8, 16, 32, 64};
+  bool o = false, i = false;
+  for (int k = 0; k < 5; k++) { o |= (Cout == ok_out[k]); i |= (Cin == ok_out[k]); }
+  return P >= 1 && o && i;
+}
+int lctvqa_pwconv_small(const float* in, const float* w, const float* relu_mask_x, float* out, long P, int Cout, int Cin, int relu_in,
+                        int transpose, void* stream) {
+  LCT_REQUIRE(lctvqa_pwconv_small_supported(P, Cout, Cin), "pwconv_small: unsupported P=%ld Cout=%d Cin=%d", P, Cout, Cin);
+  LCT_REQUIRE((((uintptr_t)in | (uintptr_t)out | (uintptr_t)relu_mask_x) & 15) == 0, "pwconv_small: buffers must be 16-B aligned");
+  if (transpose) return launch_pwconv_small<true>(in, w, relu_mask_x, out, P, Cin, Cout, 0, (hipStream_t)stream);
+  return launch_pwconv_small<false>(in, w, nullptr, out, P, Cout, Cin, relu_in, (hipStream_t)stream);
 }
 
 long lctvqa_pwconv_wgrad_small_scratch_elems(long P, int Cout, int Cin) {

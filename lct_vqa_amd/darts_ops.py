@@ -84,7 +84,11 @@ class PwConvFn(torch.autograd.Function):
         B, H, W, Cin = x.shape
         Cout = w.shape[0]
         P = B * H * W
-        y = _gemm_ex(x, Cin, 1, w, Cin, 1, P, Cout, Cin, 1 if relu_in else 0)
+        if lib.query('pwconv_small_supported', P, Cout, Cin):
+            y = torch.empty((P, Cout), dtype=torch.float32, device=x.device)
+            lib('pwconv_small', x, w, None, y, P, Cout, Cin, int(bool(relu_in)), 0)
+        else:
+            y = _gemm_ex(x, Cin, 1, w, Cin, 1, P, Cout, Cin, 1 if relu_in else 0)
         ctx.save_for_backward(x, w)
         ctx.relu_in = bool(relu_in)
         return y.reshape(B, H, W, Cout)
@@ -98,11 +102,15 @@ class PwConvFn(torch.autograd.Function):
         P = B * H * W
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = _gemm_ex(dy, Cout, 1, w, 1, Cin, P, Cin, Cout, 0)            # dY . W
-            if ctx.relu_in:
-                out = torch.empty_like(dx)
-                lib('act_bwd', dx, x, None, 1.0, out, dx.numel(), 1)          # * (x > 0)
-                dx = out
+            if lib.query('pwconv_small_supported', P, Cout, Cin):
+                dx = torch.empty((P, Cin), dtype=torch.float32, device=x.device)
+                lib('pwconv_small', dy, w, x if ctx.relu_in else None, dx, P, Cout, Cin, 0, 1)    # dY . W, * (x > 0) fused
+            else:
+                dx = _gemm_ex(dy, Cout, 1, w, 1, Cin, P, Cin, Cout, 0)        # dY . W
+                if ctx.relu_in:
+                    out = torch.empty_like(dx)
+                    lib('act_bwd', dx, x, None, 1.0, out, dx.numel(), 1)      # * (x > 0)
+                    dx = out
             dx = dx.reshape(B, H, W, Cin)
         if ctx.needs_input_grad[1]:
             if lib.query('pwconv_wgrad_small_supported', P, Cout, Cin):
