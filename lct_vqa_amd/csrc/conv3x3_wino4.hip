@@ -179,27 +179,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
   // transform work of the main loop cut into slices pinned between the MFMAs of step q (slot i = 0, 1)
   auto tslice = [&](const float* rwn, float* Vn, int q, int i, int nu) __attribute__((always_inline)) {
     if (nu > 5) return;
-    // steps 0..5, slot 1: row q; steps 7, 8: the four column slices
+    // steps 0..5, slot 1: row q; steps 6, 7: the four column slices (every wave has at least 8 steps per phase)
     if (i == 1 && q < 6) trow(rwn, q, nu);
-    if (q >= 7) tcol(Vn, nu, (q - 7) * 2 + i);
+    if (q == 6 || q == 7) tcol(Vn, nu, (q - 6) * 2 + i);
   };
 
-  f32x16 acc[9];
-#pragma unroll
-  for (int q = 0; q < 9; q++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
-
-  // packed weights: [32-channel group][chunk][36][2 quads][32 ch][4]; this wave: group 2 n_tile + cg, planes 9 xg ..
-  const long UCH = 36 * 256;                                    // floats per (group, chunk)
-  const float* ub = up + (long)(n_tile * 2 + cg) * NCH * UCH + (xg * 9) * 256 + (h * 32 + j) * 4;
-  const float* va = V + (xg * 9) * 256 + h * 128 + j * 4;
-
-  // weights: ring of three (xi,nu) slots; the slot of step q is refilled right behind its MFMAs with the weights of step
-  // q+3 (this chunk's for q < 6, the next chunk's q-6 otherwise).  A slot per step (a whole phase of lead, as in the
-  // F(2x2,3x3) kernels) would need 24 more registers than the 256 of a wave at two waves per SIMD.
-  f32x4 Bw[3];
-  f32x4 Aa, Ab;
+#ifndef W4_UNEVEN
+#define W4_UNEVEN 1
+#endif
 #ifndef W4_X_NOT
 #define W4_X_NOT 0
 #endif
@@ -212,7 +199,136 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
 #ifndef W4_X_NOEPI
 #define W4_X_NOEPI 0
 #endif
+  // -DW4_DIAG: per-wave s_memtime stamps (ticks parked at the end-of-phase wait + barrier, K-loop ticks, epilogue ticks)
+  // written to y instead of the result; read by tools/diag_wino4.py
+#ifdef W4_DIAG
+  long dg_wait = 0, dg_t = 0;
+  const long dg_start = __builtin_amdgcn_s_memtime();
+#define W4_DIAG_T0 dg_t = __builtin_amdgcn_s_memtime();
+#define W4_DIAG_T1 dg_wait += __builtin_amdgcn_s_memtime() - dg_t;
+#else
+#define W4_DIAG_T0
+#define W4_DIAG_T1
+#endif
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
+  const long UCH = 36 * 256;                                    // floats of packed weights per (32-channel group, chunk)
+
+#if W4_UNEVEN
+  // ---- main loop, uneven split.  The 72 accumulator tiles t = cg * 36 + (xi*6+nu) of the workgroup are dealt out as
+  // 8 to each of waves 0..5 (which also carry a transform column) and 12 to waves 6 and 7 (which do not): measured with
+  // the even 9/9 split, waves 6/7 spent 31-37 % of the K loop parked at the phase barrier while the SIMDs carrying two
+  // transform waves set the pace (-DW4_DIAG).  Tile ranges: wave w < 6: [8w, 8w+8), wave 6: [48, 60), wave 7: [60, 72).
+  f32x16 acc[12];
+#pragma unroll
+  for (int q = 0; q < 12; q++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
+  const float* ubg0 = up + (long)(n_tile * 2) * NCH * UCH + (h * 32 + j) * 4;     // channel group cg = 0 / 1 of this n_tile
+  const float* ubg1 = ubg0 + (long)NCH * UCH;
+  const float* va0 = V + h * 128 + j * 4;
+  const int t0w = wave < 6 ? 8 * wave : 48 + 12 * (wave - 6);
+  // weights: ring of four slots; the slot of step s is refilled right behind its MFMAs with the weights of step s+4
+  // (this chunk's, or the next chunk's s+4-NTW): three steps of lead in 16 registers
+  f32x4 Bw[4];
+  f32x4 Aa, Ab;
+#define W4_XN(T0, S) (((T0) + (S)) % 36)
+#define W4_UB(T0, S) ((((T0) + (S)) / 36) ? ubg1 : ubg0)
+#define W4_MF(S, ACUR, E) acc[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(ACUR[E], Bw[(S) % 4][E], acc[S], 0, 0, 0)
+  // one tile: 4 MFMAs (8 channels); the other work is pinned between them in source order
+#define W4_STEP(S, ACUR, ANEXT, NXT, NU, T0, NTW)                                                      \
+  if ((S) < (NTW)) {                                                                                  \
+    W4_MF(S, ACUR, 0);                                                                                \
+    if ((S) + 1 < (NTW)) ANEXT = *(const f32x4*)(vc + W4_XN(T0, (S) + 1) * 256);                       \
+    W4_SB();                                                                                          \
+    W4_MF(S, ACUR, 1);                                                                                \
+    if (NXT && !W4_X_NOT) tslice(rwn, Vn, S, 0, NU);                                                  \
+    W4_SB();                                                                                          \
+    W4_MF(S, ACUR, 2);                                                                                \
+    if (NXT && !W4_X_NOT) tslice(rwn, Vn, S, 1, NU);                                                  \
+    W4_SB();                                                                                          \
+    W4_MF(S, ACUR, 3);                                                                                \
+    if (W4_X_NOB) {                                                                                   \
+    } else if ((S) + 4 < (NTW)) {                                                                     \
+      Bw[(S) % 4] = *(const f32x4*)(W4_UB(T0, (S) + 4) + (long)chunk * UCH + W4_XN(T0, (S) + 4) * 256);   \
+    } else if (NXT) {                                                                                 \
+      Bw[(S) % 4] = *(const f32x4*)(W4_UB(T0, (S) + 4 - (NTW)) + (long)(chunk + 1) * UCH + W4_XN(T0, (S) + 4 - (NTW)) * 256); \
+    }                                                                                                 \
+    W4_SB();                                                                                          \
+  }
+#define W4_PHASE(NXT, NU, T0, NTW)                                                                    \
+  {                                                                                                   \
+    const float* vc = va0 + (chunk & 1) * VSZ;                                                        \
+    float* Vn = V + ((chunk + 1) & 1) * VSZ;                                                          \
+    const float* rwn = raw + ((chunk + 1) & 1) * RAWSZ;                                               \
+    Aa = *(const f32x4*)(vc + W4_XN(T0, 0) * 256);                                                    \
+    W4_STEP(0, Aa, Ab, NXT, NU, T0, NTW) W4_STEP(1, Ab, Aa, NXT, NU, T0, NTW) W4_STEP(2, Aa, Ab, NXT, NU, T0, NTW)     \
+    W4_STEP(3, Ab, Aa, NXT, NU, T0, NTW) W4_STEP(4, Aa, Ab, NXT, NU, T0, NTW) W4_STEP(5, Ab, Aa, NXT, NU, T0, NTW)     \
+    W4_STEP(6, Aa, Ab, NXT, NU, T0, NTW) W4_STEP(7, Ab, Aa, NXT, NU, T0, NTW) W4_STEP(8, Aa, Ab, NXT, NU, T0, NTW)     \
+    W4_STEP(9, Ab, Aa, NXT, NU, T0, NTW) W4_STEP(10, Aa, Ab, NXT, NU, T0, NTW) W4_STEP(11, Ab, Aa, NXT, NU, T0, NTW)   \
+  }
+  // End of a phase: the raw patch of chunk+2 (LDS-DMA issued at the start of the phase) must have landed; the NTW weight
+  // loads issued after it stay in flight.  Bare barrier (not __syncthreads(), whose fence would drain them); lgkmcnt(0)
+  // retires the transform's LDS stores.
+#define W4_MAIN(NU, T0, NTW)                                                                          \
+  {                                                                                                   \
+    int chunk = 0;                                                                                    \
+    for (; chunk < NCH - 1; chunk++) {                                                                \
+      W4_PHASE(true, NU, T0, NTW)                                                                     \
+      W4_DIAG_T0                                                                                      \
+      if ((NTW) == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");         \
+      else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");                   \
+      W4_DIAG_T1                                                                                      \
+      if (chunk + 3 < NCH && !W4_X_NORAW) stage_raw(chunk + 3, raw + ((chunk + 1) & 1) * RAWSZ);      \
+    }                                                                                                 \
+    W4_PHASE(false, NU, T0, NTW)                                                                      \
+  }
+
+  stage_raw(0, raw);
+  if (NCH > 1) stage_raw(1, raw + RAWSZ);
+#pragma unroll
+  for (int sl = 0; sl < 4; sl++) {
+    const int t = t0w + sl;
+    Bw[sl] = *(const f32x4*)((t >= 36 ? ubg1 : ubg0) + (t % 36) * 256);
+  }
+  // builtin (not asm): the compiler's waitcnt bookkeeping then sees the prologue loads retired and derives the counted
+  // waits of the loop from the loop's own issue order.  0x0F70 = vmcnt(0), expcnt/lgkmcnt untouched.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  transform_all(raw, V, wave);
+  __syncthreads();
+  if (NCH > 2) stage_raw(2, raw);
+
+  switch (wave) {
+    case 0: W4_MAIN(0, 0, 8) break;
+    case 1: W4_MAIN(1, 8, 8) break;
+    case 2: W4_MAIN(2, 16, 8) break;
+    case 3: W4_MAIN(3, 24, 8) break;
+    case 4: W4_MAIN(4, 32, 8) break;
+    case 5: W4_MAIN(5, 40, 8) break;
+    case 6: W4_MAIN(6, 48, 12) break;
+    default: W4_MAIN(6, 60, 12) break;
+  }
+#undef W4_MAIN
+#undef W4_PHASE
+#undef W4_STEP
+#undef W4_MF
+#else
+  // ---- main loop, even split: wave (xg, cg) accumulates the 9 GEMMs 9 xg .. 9 xg + 8 of channel group cg
+  f32x16 acc[9];
+#pragma unroll
+  for (int q = 0; q < 9; q++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
+
+  // packed weights: [32-channel group][chunk][36][2 quads][32 ch][4]; this wave: group 2 n_tile + cg, planes 9 xg ..
+  const float* ub = up + (long)(n_tile * 2 + cg) * NCH * UCH + (xg * 9) * 256 + (h * 32 + j) * 4;
+  const float* va = V + (xg * 9) * 256 + h * 128 + j * 4;
+
+  // weights: ring of three (xi,nu) slots; the slot of step q is refilled right behind its MFMAs with the weights of step
+  // q+3 (this chunk's for q < 6, the next chunk's q-6 otherwise).  A slot per step (a whole phase of lead, as in the
+  // F(2x2,3x3) kernels) would need 24 more registers than the 256 of a wave at two waves per SIMD.
+  f32x4 Bw[3];
+  f32x4 Aa, Ab;
 #define W4_MF(Q, ACUR, E) acc[Q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ACUR[E], Bw[(Q) % 3][E], acc[Q], 0, 0, 0)
   // one (xi,nu): 4 MFMAs (8 channels); the other work is pinned between them in source order
 #define W4_STEP(Q, ACUR, ANEXT, NXT, NU)                                                               \
@@ -262,17 +378,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
     W4_PHASE(false, NU)                                                                               \
   }
 
-  // -DW4_DIAG: per-wave s_memtime stamps (ticks parked at the end-of-phase wait + barrier, K-loop ticks, epilogue ticks)
-  // written to y instead of the result; read by tools/diag_wino4.py
-#ifdef W4_DIAG
-  long dg_wait = 0, dg_t = 0;
-  const long dg_start = __builtin_amdgcn_s_memtime();
-#define W4_DIAG_T0 dg_t = __builtin_amdgcn_s_memtime();
-#define W4_DIAG_T1 dg_wait += __builtin_amdgcn_s_memtime() - dg_t;
-#else
-#define W4_DIAG_T0
-#define W4_DIAG_T1
-#endif
   stage_raw(0, raw);
   if (NCH > 1) stage_raw(1, raw + RAWSZ);
 #pragma unroll
@@ -298,6 +403,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
 #undef W4_PHASE
 #undef W4_STEP
 #undef W4_MF
+
+#endif
 #undef W4_SB
 
 #ifdef W4_DIAG
@@ -310,12 +417,31 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
 #pragma unroll
   for (int rnd = 0; rnd < (W4_X_NOEPI ? (relu == 12345 ? 4 : 0) : 4); rnd++) {
     __syncthreads();                                            // V (first round) / the previous round's reads are done
+#if W4_UNEVEN
+#define W4_EPI_WRITE(T0, NTW)                                                                         \
+    _Pragma("unroll") for (int sq = 0; sq < (NTW); sq++) {                                             \
+      float* d = xch + (((((T0) + sq) / 36) * 4) * 36 + ((T0) + sq) % 36) * 64 + lane;                 \
+      _Pragma("unroll") for (int rr = 0; rr < 4; rr++) d[rr * 36 * 64] = acc[sq][4 * rnd + rr];        \
+    }
+    switch (wave) {
+      case 0: W4_EPI_WRITE(0, 8) break;
+      case 1: W4_EPI_WRITE(8, 8) break;
+      case 2: W4_EPI_WRITE(16, 8) break;
+      case 3: W4_EPI_WRITE(24, 8) break;
+      case 4: W4_EPI_WRITE(32, 8) break;
+      case 5: W4_EPI_WRITE(40, 8) break;
+      case 6: W4_EPI_WRITE(48, 12) break;
+      default: W4_EPI_WRITE(60, 12) break;
+    }
+#undef W4_EPI_WRITE
+#else
 #pragma unroll
     for (int q = 0; q < 9; q++) {
       float* d = xch + ((cg * 4) * 36 + xg * 9 + q) * 64 + lane;
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) d[rr * 36 * 64] = acc[q][4 * rnd + rr];
     }
+#endif
     __syncthreads();
     {
       const int unit = wave, c = unit >> 2, rr = unit & 3;
