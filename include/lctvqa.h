@@ -126,6 +126,18 @@ int lctvqa_lstm_step_bwd_fused(const float* dg_t, const float* w_hh, const float
                                int B, int H, void* stream);
 int lctvqa_lstm_cell_bwd(const float* dh_rec, const float* dh_ext, const float* dc_next, const float* gates,
                          const float* c_prev, const float* c_cur, float* dgates, float* dc_prev, int B, int H, void* stream);
+/* whole-sequence recurrence (the T dependent steps of nn.LSTM, models.py:61, models_lct.py:107-108): W_hh is re-ordered
+ * once per call into MFMA-fragment order (wpack: lctvqa_lstm_seq_scratch_elems(H) floats), then the T steps are launched
+ * back to back.  lctvqa_lstm_seq_packed(B,H) tells whether the shape runs on the packed kernels (H = 64/128/256/512) or
+ * falls back to the per-step kernels above.  fwd: h_all/c_all [T+1][B][H], slot 0 = initial state; fills slots 1..T and
+ * gates [T][B][4H].  bwd: steps T-2..0 (the caller has run lctvqa_lstm_cell_bwd for step T-1 into dgates[T-1] and
+ * dc_buf[0]); dout [T][B][H] or NULL; dc_buf [2][B][H], result in half (T-1)&1 */
+long lctvqa_lstm_seq_scratch_elems(int H);
+int lctvqa_lstm_seq_packed(int B, int H);
+int lctvqa_lstm_seq_fwd(const float* xp, const float* w_hh, const float* b_hh, float* h_all, float* c_all, float* gates,
+                        float* wpack, int T, int B, int H, void* stream);
+int lctvqa_lstm_seq_bwd(float* dgates, const float* w_hh, const float* dout, const float* gates, const float* c_all,
+                        float* dc_buf, float* wpack, int T, int B, int H, void* stream);
 /* GRU cell (nn.GRU, gates r,z,n): the "LSTM/GRU" question-encoder variant of BASELINE.json (not in the reference;
  * oracle = torch.nn.GRU).  xp/hp: [B][3H] projections incl. their biases; saved [B][4H] = r,z,n,hp_n */
 int lctvqa_gru_cell_fwd(const float* xp, const float* hp, const float* h_prev, float* saved, float* h_out, int B, int H,

@@ -769,6 +769,263 @@ extern "C" int lctvqa_lstm_step_bwd_fused(const float* dg_t, const float* w_hh, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Whole-sequence LSTM recurrence (the T dependent steps of nn.LSTM; reference basic_vqa/models.py:61,
+// models_lct.py:107-108,140-157).  One C call per direction: W_hh is re-ordered ONCE per sequence into MFMA-fragment
+// order, so every weight load of every step is one lane-contiguous 1-KB piece (the per-step kernels above read rows
+// of W_hh 16 B at a time, 64 cache lines per load instruction), then the T steps are launched back to back.  The
+// exchange of h_t between the workgroups of a step is the kernel boundary: on gfx950 a dependent launch costs
+// ~1.5 us, an in-kernel grid barrier with its agent-scope release/acquire 4-7 us (MI355X_MICROARCH.md, price list),
+// so a persistent kernel spinning on a barrier per step would be the slower form of the same data flow.
+// ------------------------------------------------------------------------------------------
+// forward pack: [H/16 unit tiles][H/16 k groups][2 kk][2 tiles][64 lanes][4]; tile 0 = gates (i,f), tile 1 = (g,o);
+// lane (j, hh): column j = (gate&1)*16 + unit, k = grp*16 + (2kk+hh)*4 + e
+__global__ void lstm_pack_whh_fwd_kernel(const float* __restrict__ w_hh, float* __restrict__ p, int H) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int ng = H / 16;
+  if (idx >= (long)H * H) return;                       // 4H*H floats = H*H float4s
+  const int lane = idx & 63, tile = (idx >> 6) & 1, kk = (idx >> 7) & 1;
+  const long rest = idx >> 8;
+  const int grp = rest % ng, ut = rest / ng;
+  const int j = lane & 31, hh = lane >> 5;
+  const int gate = tile * 2 + (j >> 4), unit = ut * 16 + (j & 15);
+  ((f32x4*)p)[idx] = *(const f32x4*)(w_hh + ((long)gate * H + unit) * H + grp * 16 + (2 * kk + hh) * 4);
+}
+
+// backward pack: [H/32 unit tiles][4H/64 super-groups][8 q][64 lanes][4]; lane (j, hh): value[e] = W_hh[kc+e][u0+j],
+// kc = sg*64 + (q>>1)*16 + (2*(q&1)+hh)*4
+__global__ void lstm_pack_whh_bwd_kernel(const float* __restrict__ w_hh, float* __restrict__ p, int H) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)H * H) return;
+  const int nsg = 4 * H / 64;
+  const int lane = idx & 63, q = (idx >> 6) & 7;
+  const long rest = idx >> 9;
+  const int sg = rest % nsg, ut = rest / nsg;
+  const int j = lane & 31, hh = lane >> 5;
+  const int kc = sg * 64 + (q >> 1) * 16 + (2 * (q & 1) + hh) * 4;
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; e++) v[e] = w_hh[(long)(kc + e) * H + ut * 32 + j];
+  ((f32x4*)p)[idx] = v;
+}
+
+// one time step on the packed weights.  Workgroup = 32 batch rows x 16 hidden units x 4 gates (two 32x32 accumulator
+// tiles per wave), the 4 waves split K = H into quarters of NG 16-deep groups; ALL of a wave's operand loads are issued
+// before its first MFMA (NG * 6 float4 registers), partial tiles meet in LDS, the cell update is the epilogue.
+template <int NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void lstm_step2_kernel(const float* __restrict__ xp, const float* __restrict__ h_prev,
+                                                         const float* __restrict__ c_prev, const float* __restrict__ wp,
+                                                         const float* __restrict__ b_hh, float* __restrict__ gates,
+                                                         float* __restrict__ c_out, float* __restrict__ h_out, int B) {
+  constexpr int H = 64 * NG, NGRP = H / 16, RSTR = 80;   // RSTR: padded register stride of the exchange buffer
+  __shared__ __attribute__((aligned(16))) float red[4 * 2 * 16 * RSTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  constexpr int NUT = H / 16;
+  const int ut = blockIdx.x % NUT, bt = blockIdx.x / NUT;
+  const int b0 = bt * 32, u0 = ut * 16;
+  const int arow = min(b0 + j, B - 1);                  // rows >= B are computed but never stored
+  f32x4 A[NG][2], Bf[NG][2][2];
+#pragma unroll
+  for (int n = 0; n < NG; n++) {
+    const int grp = wave * NG + n;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      A[n][kk] = *(const f32x4*)(h_prev + (long)arow * H + grp * 16 + (2 * kk + hh) * 4);
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+        Bf[n][kk][t] = *(const f32x4*)(wp + (((((long)ut * NGRP + grp) * 2 + kk) * 2 + t) * 64 + lane) * 4);
+    }
+  }
+  // epilogue operands of this thread's two (row, unit) outputs, requested before the MFMAs
+  const int u = tid & 15, rlo = tid >> 4;
+  float xin[2][4], bh[4], cp[2];
+#pragma unroll
+  for (int g = 0; g < 4; g++) bh[g] = b_hh[g * H + u0 + u];
+#pragma unroll
+  for (int o = 0; o < 2; o++) {
+    const int row = min(b0 + rlo + 16 * o, B - 1);
+#pragma unroll
+    for (int g = 0; g < 4; g++) xin[o][g] = xp[(long)row * 4 * H + g * H + u0 + u];
+    cp[o] = c_prev[(long)row * H + u0 + u];
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+  __builtin_amdgcn_sched_barrier(0);                    // keep every load above in front of the first MFMA
+#pragma unroll
+  for (int n = 0; n < NG; n++)
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[n][kk][e], Bf[n][kk][t][e], acc[t], 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[((wave * 2 + t) * 16 + r) * RSTR + lane] = acc[t][r];
+  __syncthreads();
+#pragma unroll
+  for (int o = 0; o < 2; o++) {
+    const int rl = rlo + 16 * o;                        // accumulator row rl = (r&3) + 8*(r>>2) + 4*hh
+    const int r = (rl & 3) + 4 * (rl >> 3), rh = (rl >> 2) & 1;
+    float pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; w++) sacc += red[((w * 2 + (g >> 1)) * 16 + r) * RSTR + rh * 32 + (g & 1) * 16 + u];
+      pre[g] = sacc + xin[o][g] + bh[g];
+    }
+    const int row = b0 + rl;
+    if (row < B) {
+      const long g0 = (long)row * 4 * H + u0 + u, oo_ = (long)row * H + u0 + u;
+      const float i = sigmoidf_(pre[0]), f = sigmoidf_(pre[1]), g = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+      const float c = f * cp[o] + i * g;
+      gates[g0] = i; gates[g0 + H] = f; gates[g0 + 2 * H] = g; gates[g0 + 3 * H] = og;
+      c_out[oo_] = c;
+      h_out[oo_] = og * tanhf(c);
+    }
+  }
+}
+
+// BPTT step on the packed (transposed-fragment) weights: as lstm_step_bwd_fused_kernel, with 1-KB weight pieces and the
+// operands of two 64-deep super-groups in flight ahead of the MFMAs.
+__global__ __launch_bounds__(256) void lstm_step2_bwd_kernel(const float* __restrict__ dg_t, const float* __restrict__ wp,
+                                                             const float* __restrict__ dh_ext, const float* __restrict__ dc_next,
+                                                             const float* __restrict__ gates_p, const float* __restrict__ c_pp,
+                                                             const float* __restrict__ c_p, float* __restrict__ dg_p,
+                                                             float* __restrict__ dc_prev, int B, int H) {
+  __shared__ float red[4][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  const int nut = H / 32;
+  const int ut = blockIdx.x % nut, bt = blockIdx.x / nut;
+  const int b0 = bt * 32, u0 = ut * 32;
+  const int K = 4 * H, nsg = K / 64;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.f;
+  const int arow = min(b0 + j, B - 1);
+  const float* ap = dg_t + (long)arow * K;
+  const float* bp = wp + ((long)ut * nsg * 8 * 64 + lane) * 4;
+  f32x4 A0[8], A1[8], A2[8], B0[8], B1[8], B2[8];
+  auto ld = [&](int sg, f32x4 (&A)[8], f32x4 (&Bf)[8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      A[q] = *(const f32x4*)(ap + sg * 64 + (q >> 1) * 16 + (2 * (q & 1) + hh) * 4);
+      Bf[q] = *(const f32x4*)(bp + ((long)sg * 8 + q) * 256);
+    }
+  };
+  auto mm = [&](const f32x4 (&A)[8], const f32x4 (&Bf)[8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[q][e], Bf[q][e], acc, 0, 0, 0);
+  };
+  int sg = wave;                                        // this wave's super-groups: wave, wave + 4, ...
+  if (sg < nsg) ld(sg, A0, B0);
+  if (sg + 4 < nsg) ld(sg + 4, A1, B1);
+  while (sg < nsg) {
+    if (sg + 8 < nsg) ld(sg + 8, A2, B2);
+    mm(A0, B0);
+    sg += 4;
+    if (sg >= nsg) break;
+    if (sg + 8 < nsg) ld(sg + 8, A0, B0);
+    mm(A1, B1);
+    sg += 4;
+    if (sg >= nsg) break;
+    if (sg + 8 < nsg) ld(sg + 8, A1, B1);
+    mm(A2, B2);
+    sg += 4;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r++) red[wave][r][lane] = acc[r];
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 4; rr++) {
+    const int r = wave * 4 + rr;
+    const int row = b0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    const int u = u0 + j;
+    float dh = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+    if (row < B) {
+      const long o = (long)row * H + u, g0 = (long)row * 4 * H + u;
+      if (dh_ext) dh += dh_ext[o];
+      const float i = gates_p[g0], f = gates_p[g0 + H], g = gates_p[g0 + 2 * H], oo = gates_p[g0 + 3 * H];
+      const float tc = tanhf(c_p[o]);
+      const float dc = (dc_next ? dc_next[o] : 0.f) + dh * oo * (1.f - tc * tc);
+      dg_p[g0] = dc * g * i * (1.f - i);
+      dg_p[g0 + H] = dc * c_pp[o] * f * (1.f - f);
+      dg_p[g0 + 2 * H] = dc * i * (1.f - g * g);
+      dg_p[g0 + 3 * H] = dh * tc * oo * (1.f - oo);
+      dc_prev[o] = dc * f;
+    }
+  }
+}
+
+extern "C" long lctvqa_lstm_seq_scratch_elems(int H) { return 4L * H * H; }
+extern "C" int lctvqa_lstm_seq_packed(int B, int H) { return (B >= 1 && (H == 64 || H == 128 || H == 256 || H == 512)) ? 1 : 0; }
+
+// h_all / c_all: [T+1][B][H] with slot 0 = the initial state (set by the caller); fills slots 1..T and gates [T][B][4H].
+// wpack: lctvqa_lstm_seq_scratch_elems(H) floats of scratch (untouched when the shape runs on the per-step kernels).
+extern "C" int lctvqa_lstm_seq_fwd(const float* xp, const float* w_hh, const float* b_hh, float* h_all, float* c_all, float* gates,
+                                   float* wpack, int T, int B, int H, void* stream) {
+  LCT_REQUIRE(T >= 1 && lctvqa_lstm_step_fused_supported(B, H), "lstm_seq_fwd: need T >= 1, H %% 32 == 0 (got T=%d H=%d)", T, H);
+  LCT_REQUIRE((((uintptr_t)h_all | (uintptr_t)w_hh | (uintptr_t)wpack) & 15) == 0, "lstm_seq_fwd: h_all / w_hh / wpack must be 16-B aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const long BH = (long)B * H;
+  if (!lctvqa_lstm_seq_packed(B, H)) {
+    for (int t = 0; t < T; t++) {
+      int rc = lctvqa_lstm_step_fused(xp + t * 4 * BH, h_all + t * BH, c_all + t * BH, w_hh, b_hh, gates + t * 4 * BH,
+                                      c_all + (t + 1) * BH, h_all + (t + 1) * BH, B, H, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  hipLaunchKernelGGL(lstm_pack_whh_fwd_kernel, dim3(cdiv((long)H * H, 256)), dim3(256), 0, st, w_hh, wpack, H);
+  const dim3 grid(cdiv(B, 32) * (H / 16));
+  for (int t = 0; t < T; t++) {
+    const float *x = xp + t * 4 * BH, *hp = h_all + t * BH, *cp = c_all + t * BH;
+    float *g = gates + t * 4 * BH, *co = c_all + (t + 1) * BH, *ho = h_all + (t + 1) * BH;
+    switch (H) {
+      case 64: hipLaunchKernelGGL(lstm_step2_kernel<1>, grid, dim3(256), 0, st, x, hp, cp, wpack, b_hh, g, co, ho, B); break;
+      case 128: hipLaunchKernelGGL(lstm_step2_kernel<2>, grid, dim3(256), 0, st, x, hp, cp, wpack, b_hh, g, co, ho, B); break;
+      case 256: hipLaunchKernelGGL(lstm_step2_kernel<4>, grid, dim3(256), 0, st, x, hp, cp, wpack, b_hh, g, co, ho, B); break;
+      default: hipLaunchKernelGGL(lstm_step2_kernel<8>, grid, dim3(256), 0, st, x, hp, cp, wpack, b_hh, g, co, ho, B); break;
+    }
+  }
+  return lct_check_launch("lstm_seq_fwd");
+}
+
+// Steps t = T-2 .. 0 of BPTT (step T-1 is the plain cell backward, lctvqa_lstm_cell_bwd, done by the caller into
+// dgates[T-1] and dc_buf[0]).  dout: dL/dh_t from the sequence output [T][B][H] or NULL.  dc_buf: [2][B][H]; step i reads
+// half i&1 and writes the other, so dL/dc_0's factor ends in half (T-1)&1.
+extern "C" int lctvqa_lstm_seq_bwd(float* dgates, const float* w_hh, const float* dout, const float* gates, const float* c_all,
+                                   float* dc_buf, float* wpack, int T, int B, int H, void* stream) {
+  LCT_REQUIRE(T >= 1 && lctvqa_lstm_step_fused_supported(B, H), "lstm_seq_bwd: need T >= 1, H %% 32 == 0 (got T=%d H=%d)", T, H);
+  LCT_REQUIRE((((uintptr_t)dgates | (uintptr_t)wpack) & 15) == 0, "lstm_seq_bwd: dgates / wpack must be 16-B aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const long BH = (long)B * H;
+  const bool packed = lctvqa_lstm_seq_packed(B, H) && T > 1;
+  if (packed) hipLaunchKernelGGL(lstm_pack_whh_bwd_kernel, dim3(cdiv((long)H * H, 256)), dim3(256), 0, st, w_hh, wpack, H);
+  for (int t = T - 2, i = 0; t >= 0; t--, i++) {
+    const float* dext = dout ? dout + t * BH : nullptr;
+    float *dcin = dc_buf + (i & 1) * BH, *dcout = dc_buf + ((i + 1) & 1) * BH;
+    if (packed) {
+      hipLaunchKernelGGL(lstm_step2_bwd_kernel, dim3(cdiv(B, 32) * (H / 32)), dim3(256), 0, st, dgates + (t + 1) * 4 * BH, wpack, dext,
+                         dcin, gates + t * 4 * BH, c_all + t * BH, c_all + (t + 1) * BH, dgates + t * 4 * BH, dcout, B, H);
+    } else {
+      int rc = lctvqa_lstm_step_bwd_fused(dgates + (t + 1) * 4 * BH, w_hh, dext, dcin, gates + t * 4 * BH, c_all + t * BH,
+                                          c_all + (t + 1) * BH, dgates + t * 4 * BH, dcout, B, H, stream);
+      if (rc) return rc;
+    }
+  }
+  return lct_check_launch("lstm_seq_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
 // Input pipeline, device side (reference basic_vqa/data_loader_v2.py:53-55,82-86: PIL fromarray -> ToTensor ->
 // Normalize(mean,std) per sample on the host): the uint8 HWC image store rows are copied to HBM as they are
 // (3 B/pixel over PCIe instead of 12) and converted here:  y[n][c][h][w] = (x[n][h][w][c]/255 - mean[c]) / std[c]

@@ -209,6 +209,11 @@ def embed(idx, weight, apply_tanh=True):
     return EmbedFn.apply(idx, weight, apply_tanh)
 
 
+def _lstm_scratch(B, H, dev):
+    """Scratch for the packed W_hh of one LSTM sequence call (fresh per call: the weights may have changed)."""
+    return torch.empty(lib.query('lstm_seq_scratch_elems', H), dtype=torch.float32, device=dev)
+
+
 class LSTMFn(torch.autograd.Function):
     """Single-layer nn.LSTM over a [T,B,I] sequence (reference basic_vqa/models.py:61,
     models_lct.py:107-108).  Returns (out [T,B,H], h_T [B,H], c_T [B,H])."""
@@ -232,8 +237,8 @@ class LSTMFn(torch.autograd.Function):
             h_all[0].copy_(h0.reshape(B, H))
             c_all[0].copy_(c0.reshape(B, H))
         if lib.query('lstm_step_fused_supported', B, H):
-            for t in range(T):                       # one fused launch per time step
-                lib('lstm_step_fused', xp[t], h_all[t], c_all[t], w_hh, b_hh, gates[t], c_all[t + 1], h_all[t + 1], B, H)
+            # the whole recurrence in one C call: W_hh packed once, one fused launch per time step
+            lib('lstm_seq_fwd', xp, w_hh, b_hh, h_all, c_all, gates, _lstm_scratch(B, H, dev), T, B, H)
         else:
             hp = torch.empty((B, 4 * H), dtype=torch.float32, device=dev)
             for t in range(T):
@@ -253,19 +258,24 @@ class LSTMFn(torch.autograd.Function):
         dh_rec = _chk(dhT) if dhT is not None else None
         dc = _chk(dcT) if dcT is not None else None
         dgates = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
-        fused = bool(lib.query('lstm_step_fused_supported', B, H))
-        for t in range(T - 1, -1, -1):
-            dc_prev = torch.empty((B, H), dtype=torch.float32, device=dev)
-            if fused and t < T - 1:
-                # dh_rec = dgates[t+1] . W_hh and the cell backward of step t in one launch
-                lib('lstm_step_bwd_fused', dgates[t + 1], w_hh, dout[t] if dout is not None else None, dc, gates[t],
-                    c_all[t], c_all[t + 1], dgates[t], dc_prev, B, H)
-            else:
+        if lib.query('lstm_step_fused_supported', B, H):
+            # step T-1 is a plain cell backward; steps T-2..0 (dh_rec = dgates[t+1] . W_hh fused with the cell backward
+            # of step t) run in one C call on W_hh packed once
+            dc_buf = torch.empty((2, B, H), dtype=torch.float32, device=dev)
+            lib('lstm_cell_bwd', dh_rec, dout[T - 1] if dout is not None else None, dc, gates[T - 1],
+                c_all[T - 1], c_all[T], dgates[T - 1], dc_buf[0], B, H)
+            lib('lstm_seq_bwd', dgates, w_hh, dout, gates, c_all, dc_buf, _lstm_scratch(B, H, dev), T, B, H)
+            dc = dc_buf[(T - 1) & 1]
+            if ctx.has_init:
+                dh_rec = linear_bwd_input(dgates[0], w_hh)
+        else:
+            for t in range(T - 1, -1, -1):
+                dc_prev = torch.empty((B, H), dtype=torch.float32, device=dev)
                 lib('lstm_cell_bwd', dh_rec, dout[t] if dout is not None else None, dc, gates[t],
                     c_all[t], c_all[t + 1], dgates[t], dc_prev, B, H)
-            dc = dc_prev
-            if (not fused and t > 0) or (t == 0 and ctx.has_init):
-                dh_rec = linear_bwd_input(dgates[t], w_hh)
+                dc = dc_prev
+                if t > 0 or ctx.has_init:
+                    dh_rec = linear_bwd_input(dgates[t], w_hh)
         dg2 = dgates.reshape(T * B, 4 * H)
         ni = ctx.needs_input_grad
         dx = linear_bwd_input(dg2, w_ih).reshape(T, B, I) if ni[0] else None

@@ -226,6 +226,37 @@ def test_lstm_embed_fwd_bwd(ops):
             assert rel_err(a, r) < 1e-4
 
 
+@pytest.mark.parametrize('H,B,T', [(32, 37, 4), (64, 37, 5), (128, 70, 3), (256, 33, 4), (512, 256, 14), (512, 5, 1), (96, 9, 3)])
+def test_lstm_sequence_kernels_vs_torch(ops, H, B, T):
+    """The recurrence runs as one C call per direction (lctvqa_lstm_seq_fwd / _bwd): on W_hh packed in MFMA-fragment
+    order for H = 64/128/256/512, on the per-step kernels otherwise (H = 32, 96).  Oracle: torch.nn.LSTM on the CPU."""
+    from lct_vqa_amd._lib import lib
+    assert bool(lib.query('lstm_seq_packed', B, H)) == (H in (64, 128, 256, 512))
+    torch.manual_seed(40 + H)
+    We = 20
+    lstm = torch.nn.LSTM(We, H, 1)
+    x = torch.randn(T, B, We)
+    h0, c0 = torch.randn(B, H) * 0.3, torch.randn(B, H) * 0.3
+    wout = torch.randn(T, B, H) * 0.1
+    for use_init in (False, True):
+        xr = x.clone().requires_grad_()
+        h0r, c0r = h0.clone().requires_grad_(), c0.clone().requires_grad_()
+        out, (h, c) = lstm(xr, (h0r.view(1, B, H), c0r.view(1, B, H)) if use_init else None)
+        loss = (out * wout).sum() + (h * 0.7).sum() + (c * c).sum()
+        wrt = [xr] + list(lstm.parameters()) + ([h0r, c0r] if use_init else [])
+        ref = torch.autograd.grad(loss, wrt)
+        pd = [p.detach().to(DEV).requires_grad_() for p in lstm.parameters()]
+        xd = x.to(DEV).requires_grad_()
+        h0d = h0.to(DEV).requires_grad_() if use_init else None
+        c0d = c0.to(DEV).requires_grad_() if use_init else None
+        od, hd, cd = ops.lstm(xd, pd[0], pd[1], pd[2], pd[3], h0d, c0d)
+        assert rel_err(od, out) < 2e-5 and rel_err(hd, h[0]) < 2e-5 and rel_err(cd, c[0]) < 2e-5
+        lossd = (od * wout.to(DEV)).sum() + (hd * 0.7).sum() + (cd * cd).sum()
+        got = torch.autograd.grad(lossd, [xd] + pd + ([h0d, c0d] if use_init else []))
+        for a, r in zip(got, ref):
+            assert rel_err(a, r) < 1e-4
+
+
 def test_head_ops_and_losses(ops):
     g = torch.Generator().manual_seed(5)
     a, b = torch.randn(6, 32, generator=g), torch.randn(6, 32, generator=g)
