@@ -17,7 +17,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL across processes needs it on this driver
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -46,6 +48,8 @@ def parse():
     ap.add_argument('--workload', default='w', choices=['w', 'lct'],
                     help="'w' = BASELINE configs[1] (default, the headline metric); 'lct' = stage-1 + stage-2 step of "
                          "experiment.py:216-268 (EF fixed encoder + generate + W soft loss), reported under its own metric name")
+    ap.add_argument('--lct-no-share', dest='lct_share_trunk', action='store_false',
+                    help="--workload lct: evaluate the examiner's frozen trunk separately for stage 1 and stage 2 (default: once per batch)")
     ap.add_argument('--conv-algo', default=None, choices=['winograd', 'winograd2', 'direct'],
                     help='trunk convolution algorithm (default: LCTVQA_CONV_ALGO or winograd = F(4x4,3x3) / F(2x2,3x3) / direct by shape; all fp32)')
     return ap.parse_args()
@@ -169,13 +173,17 @@ def main():
 
         def step():  # noqa: F811
             ef_opt.zero_grad()
-            l1 = ef._loss(img, qst, lab)
+            # the examiner's trunk is frozen (pretrained): stage 1's forward and stage 2's generate see the same images
+            # through the same weights, so its convolutional part runs once per batch (--lct-no-share: twice, as the
+            # reference's two calls do)
+            conv = ef.img_encoder.conv_features(img) if args.lct_share_trunk else None
+            l1 = ef._loss(img, qst, lab, conv)
             l1.backward()
             if ef_red is not None:
                 ef_red.finish()
             ef_opt.step(max_grad_norm=config.GRAD_CLIP)
             with torch.no_grad():
-                pq, pa = ef.generate(img)
+                pq, pa = ef.generate(img, conv)
                 pa = ops.softmax_rows(pa, 1.0)
             opt.zero_grad()
             l2 = model._soft_loss(img, qst, lab, pq, pa)
@@ -321,12 +329,20 @@ def main():
         'value': round(value, 2),
         'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'basic_vqa VGG19+LSTM fp32 W-model train step (frozen VGG19 trunk, fwd+CE+bwd+clip+Adam), '
-                               'batch %d per GPU, 224x224x3 images, 14-token questions, 3129 answers, QV=17858' % B,
+        'config': {'workload': ('basic_vqa VGG19+LSTM fp32 W-model train step (frozen VGG19 trunk, fwd+CE+bwd+clip+Adam), '
+                                'batch %d per GPU, 224x224x3 images, 14-token questions, 3129 answers, QV=17858' % B)
+                               if args.workload == 'w' else
+                               ('basic_vqa LCT stage-1 + stage-2 step fp32 (experiment.py:216-268): examiner (models_lct, frozen '
+                                'pretrained VGG19) fwd+loss+bwd+clip+Adam, examiner.generate (14 tokens), W soft-loss '
+                                'fwd+bwd+clip+Adam; batch %d per GPU, 224x224x3, QV=17858, A=3129; frozen-trunk conv features '
+                                'evaluated %s' % (B, 'once per model and batch (examiner: shared by stage 1 and generate; W: '
+                                                     'shared by its two forwards)' if args.lct_share_trunk else
+                                                  'per call for the examiner, once for W')),
                    'global_batch': world * B, 'seq_len': 14, 'parallelism': f'dp{world}',
                    'schedule': 'trunk(i+1) || head(i) on two HIP streams' if pipelined else 'single stream'},
         'loss': round(float(loss.item()), 5),
-        'model_flops_per_step': 39.48e9 * B, 'model_tflops': round(39.48e9 * B / (ms * 1e-3) / 1e12, 2),
+        'model_flops_per_step': 39.48e9 * B if args.workload == 'w' else None,
+        'model_tflops': round(39.48e9 * B / (ms * 1e-3) / 1e12, 2) if args.workload == 'w' else None,
         'roofline': roofline,
     }
     if not args.no_cpu_baseline and world == 1:

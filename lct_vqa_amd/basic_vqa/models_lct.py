@@ -32,9 +32,19 @@ class ImgEncoderFixed(nn.Module):
         self.fc = nn.Linear(width, embed_size)
         self.pretrained = pretrained
 
-    def forward(self, image):
+    def conv_features(self, image):
+        """vgg19.features + avgpool of a FROZEN trunk (deterministic, no dropout in it): a driver that owns the loop may
+        evaluate it once per batch and hand it to forward / generate of that batch (stage 1 and stage 2 of
+        experiment.py:216-245 see the same images through the same frozen weights)."""
+        if not self.pretrained:
+            raise RuntimeError('conv_features: the trunk is trainable (pretrained=False); its features are not shareable')
+        return self.model.conv_features(image)
+
+    def forward(self, image, conv_feature=None):
+        if conv_feature is not None and not self.pretrained:
+            raise RuntimeError('conv_feature given for a trainable trunk')
         with torch.set_grad_enabled(torch.is_grad_enabled() and not self.pretrained):      # frozen iff "pretrained"
-            img_feature = self.model(image)
+            img_feature = self.model(image, conv_feature)
         return vgg.embed_feature(img_feature, self.fc)
 
 
@@ -127,14 +137,17 @@ class VqaModel(nn.Module):
 
     _head = WModel._head
 
-    def forward(self, img, qst):
-        img_feature = self.img_encoder(img)
+    def _encode_image(self, img, conv_feature):
+        return self.img_encoder(img) if conv_feature is None else self.img_encoder(img, conv_feature)
+
+    def forward(self, img, qst, conv_feature=None):
+        img_feature = self._encode_image(img, conv_feature)
         qst_feature, qst_out = self.qst_encoder(qst, img_feature)
         return self._head(img_feature, qst_feature), qst_out
 
-    def generate(self, img):
+    def generate(self, img, conv_feature=None):
         """(generated questions, answer logits for them) -- reference models_lct.py:220-241."""
-        img_feature = self.img_encoder(img)
+        img_feature = self._encode_image(img, conv_feature)
         qst = self.qst_encoder.generate(img_feature)
         qst_feature, _ = self.qst_encoder(qst, img_feature)
         return qst, self._head(img_feature, qst_feature)
@@ -150,9 +163,9 @@ class VqaModel(nn.Module):
     def arch_parameters(self):
         return self.img_encoder.darts.arch_parameters()
 
-    def _loss(self, images, questions, labels):
+    def _loss(self, images, questions, labels, conv_feature=None):
         """CE(ans) + CE(qst_out[:, :-1], qst[:, 1:]); <pad>=0 is not ignored (models_lct.py:250-257)."""
-        ans_out, qst_out = self(images, questions)
+        ans_out, qst_out = self(images, questions, conv_feature)
         ans_loss = ops.cross_entropy(ans_out, labels)
         qst = questions[:, 1:].flatten()
         qst_out = qst_out[:, :-1].flatten(end_dim=1)

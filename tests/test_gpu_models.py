@@ -61,6 +61,15 @@ def test_ef_small_against_reference_goldens(pkg):
     assert rel_err(ans, fx['eval_ans']) < 1e-3 and rel_err(qo, fx['eval_qst_out']) < 1e-3
     assert torch.equal(gq.cpu(), fx['gen_qst'])          # greedy token ids: bit-exact
     assert rel_err(ga, fx['gen_ans']) < 1e-3
+    # a driver that owns the loop may evaluate the frozen trunk's conv features once per batch and share them between
+    # stage 1 (forward / _loss) and stage 2 (generate): same goldens through that path
+    with torch.no_grad():
+        conv = m.img_encoder.conv_features(img)
+        ans_s, qo_s = m(img, qst, conv)
+        gq_s, ga_s = m.generate(img, conv)
+    assert rel_err(ans_s, fx['eval_ans']) < 1e-3 and rel_err(qo_s, fx['eval_qst_out']) < 1e-3
+    assert torch.equal(gq_s.cpu(), fx['gen_qst']) and rel_err(ga_s, fx['gen_ans']) < 1e-3
+    assert rel_err(m._loss(img, qst, lab, conv), fx['loss']) < 1e-4
     loss = m._loss(img, qst, lab)
     assert rel_err(loss, fx['loss']) < 1e-4
     grads = torch.autograd.grad(loss, list(m.parameters()), allow_unused=True)
