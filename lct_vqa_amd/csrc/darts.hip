@@ -175,66 +175,185 @@ __global__ void dwconv_bwd_input_vec_kernel(const float* __restrict__ dy, const 
   }
 }
 
+// Compile-time-K forms of the two float4 kernels above (K = 3, 5, 7; item count < 2^31): the per-channel-quad weights are
+// staged once per workgroup in LDS as float4 [tap][quad] (the loop reads them as broadcasts), every tap is loaded from a
+// clamped, always valid address and zeroed afterwards when it lies outside the image, so the K*K loads of an item are
+// independent and all in flight together (with a branch per tap each load waited for the previous one).
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_fwd_vecK_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              float* __restrict__ y, int B, int H, int W, int C, int s, int p, int d,
+                                                              int Ho, int Wo, int relu_in) {
+  constexpr int KK = K * K;
+  extern __shared__ __attribute__((aligned(16))) f32x4 swq[];     // [KK][CQ]
+  const int CQ = C >> 2;
+  for (int t = threadIdx.x; t < KK * CQ; t += blockDim.x) {
+    const int tap = t / CQ, c = (t % CQ) * 4;
+    swq[t] = f32x4{w[c * KK + tap], w[(c + 1) * KK + tap], w[(c + 2) * KK + tap], w[(c + 3) * KK + tap]};
+  }
+  __syncthreads();
+  const f32x4* x4 = (const f32x4*)x;
+  const int items = B * Ho * Wo * CQ;
+  const int cq = threadIdx.x % CQ;                              // grid stride is a multiple of CQ
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < items; i += gridDim.x * blockDim.x) {
+    const int q = i / CQ;
+    const int ox = q % Wo, oy = (q / Wo) % Ho, n = q / (Wo * Ho);
+    f32x4 v[KK];
+    bool ok[KK];
+#pragma unroll
+    for (int ky = 0; ky < K; ky++) {
+      const int iy = oy * s - p + ky * d;
+      const bool oky = iy >= 0 && iy < H;
+      const int rowb = (n * H + min(max(iy, 0), H - 1)) * W;
+#pragma unroll
+      for (int kx = 0; kx < K; kx++) {
+        const int ix = ox * s - p + kx * d;
+        ok[ky * K + kx] = oky && ix >= 0 && ix < W;
+        v[ky * K + kx] = x4[(long)(rowb + min(max(ix, 0), W - 1)) * CQ + cq];
+      }
+    }
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < KK; t++) {
+      f32x4 u = v[t];
+      if (relu_in) { u[0] = fmaxf(u[0], 0.f); u[1] = fmaxf(u[1], 0.f); u[2] = fmaxf(u[2], 0.f); u[3] = fmaxf(u[3], 0.f); }
+      if (!ok[t]) u = f32x4{0.f, 0.f, 0.f, 0.f};
+      a += u * swq[t * CQ + cq];
+    }
+    ((f32x4*)y)[i] = a;
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_bwd_input_vecK_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                    const float* __restrict__ x, float* __restrict__ dx, int B, int H,
+                                                                    int W, int C, int s, int p, int d, int Ho, int Wo, int relu_in) {
+  constexpr int KK = K * K;
+  extern __shared__ __attribute__((aligned(16))) f32x4 swq[];     // [KK][CQ]
+  const int CQ = C >> 2;
+  for (int t = threadIdx.x; t < KK * CQ; t += blockDim.x) {
+    const int tap = t / CQ, c = (t % CQ) * 4;
+    swq[t] = f32x4{w[c * KK + tap], w[(c + 1) * KK + tap], w[(c + 2) * KK + tap], w[(c + 3) * KK + tap]};
+  }
+  __syncthreads();
+  const f32x4* dy4 = (const f32x4*)dy;
+  const int items = B * H * W * CQ;
+  const int cq = threadIdx.x % CQ;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < items; i += gridDim.x * blockDim.x) {
+    const int q = i / CQ;
+    const int ix = q % W, iy = (q / W) % H, n = q / (W * H);
+    f32x4 v[KK];
+    bool ok[KK];
+#pragma unroll
+    for (int ky = 0; ky < K; ky++) {
+      const int ty = iy + p - ky * d;                           // = oy * s for the output row that used this tap
+      const int oy = max(ty, 0) / s;
+      const bool oky = ty >= 0 && (ty % s) == 0 && oy < Ho;
+      const int rowb = (n * Ho + min(oy, Ho - 1)) * Wo;
+#pragma unroll
+      for (int kx = 0; kx < K; kx++) {
+        const int tx = ix + p - kx * d;
+        const int ox = max(tx, 0) / s;
+        ok[ky * K + kx] = oky && tx >= 0 && (tx % s) == 0 && ox < Wo;
+        v[ky * K + kx] = dy4[(long)(rowb + min(ox, Wo - 1)) * CQ + cq];
+      }
+    }
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < KK; t++) {
+      f32x4 u = v[t];
+      if (!ok[t]) u = f32x4{0.f, 0.f, 0.f, 0.f};
+      a += u * swq[t * CQ + cq];
+    }
+    if (relu_in) {
+      const f32x4 xv = ((const f32x4*)x)[i];
+      a[0] = xv[0] > 0.f ? a[0] : 0.f; a[1] = xv[1] > 0.f ? a[1] : 0.f; a[2] = xv[2] > 0.f ? a[2] : 0.f; a[3] = xv[3] > 0.f ? a[3] : 0.f;
+    }
+    ((f32x4*)dx)[i] = a;
+  }
+}
+
 // Same reduction for C % 4 == 0 (every channel count of the search and derived networks): thread = (output pixel,
 // channel quad), one float4 of dy and K*K float4 of x per pixel (neighbours hit L1), K*K float4 accumulators in
 // registers; lanes that own the same channel quad meet by shuffles, waves by LDS.  16-B coalesced loads instead of the
 // scalar 4-B gathers of the generic kernel.   part[blk][tap*C + c] as above.
+// v + (v rotated right by N lanes inside its row of 16 lanes): one DPP add, no LDS
+template <int N>
+__device__ __forceinline__ float row_ror_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, false));
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                     float* __restrict__ part, int B, int H, int W, int C, int s, int p,
                                                                     int d, int Ho, int Wo, int relu_in) {
   constexpr int KK = K * K;
-  __shared__ f32x4 red[4][KK][4];                               // [wave][tap][channel quad (<= 4 per pass)]
-  const int CQ = C >> 2;
-  const long items = (long)B * Ho * Wo * CQ;
+  __shared__ f32x4 red[16][KK][4];                              // [wave * 4 + row of 16 lanes][tap][channel quad (<= 4 per pass)]
+  const int CQ = C >> 2;                                        // power of two, 1..16 (host-checked)
+  const int items = B * Ho * Wo * CQ;                           // < 2^31 (host-checked)
   const f32x4* dy4 = (const f32x4*)dy;
   const f32x4* x4 = (const f32x4*)x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // the grid stride is a multiple of CQ (CQ is a power of two <= 64, blockDim = 256), so a thread keeps its channel quad
+  // the grid stride is a multiple of CQ (blockDim = 256), so a thread keeps its channel quad
   const int cq = threadIdx.x % CQ;
   f32x4 acc[KK];
 #pragma unroll
   for (int t = 0; t < KK; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < items; i += (long)gridDim.x * blockDim.x) {
-    const long q = i / CQ;
-    const int ox = q % Wo, oy = (q / Wo) % Ho, n = q / ((long)Wo * Ho);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < items; i += gridDim.x * blockDim.x) {
+    const int q = i / CQ;
+    const int ox = q % Wo, oy = (q / Wo) % Ho, n = q / (Wo * Ho);
     const f32x4 g = dy4[i];
+    // every tap is loaded from a clamped (always valid) address and zeroed afterwards when it lies outside the image:
+    // no branches, so the K*K loads of an item are all in flight together
+    f32x4 v[KK];
+    bool ok[KK];
 #pragma unroll
     for (int ky = 0; ky < K; ky++) {
       const int iy = oy * s - p + ky * d;
-      if (iy < 0 || iy >= H) continue;
+      const bool oky = iy >= 0 && iy < H;
+      const int rowb = (n * H + min(max(iy, 0), H - 1)) * W;
 #pragma unroll
       for (int kx = 0; kx < K; kx++) {
         const int ix = ox * s - p + kx * d;
-        if (ix < 0 || ix >= W) continue;
-        f32x4 v = x4[(((long)n * H + iy) * W + ix) * CQ + cq];
-        if (relu_in) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        acc[ky * K + kx] += g * v;
+        ok[ky * K + kx] = oky && ix >= 0 && ix < W;
+        v[ky * K + kx] = x4[(long)(rowb + min(max(ix, 0), W - 1)) * CQ + cq];
       }
     }
+#pragma unroll
+    for (int t = 0; t < KK; t++) {
+      f32x4 u = v[t];
+      if (relu_in) { u[0] = fmaxf(u[0], 0.f); u[1] = fmaxf(u[1], 0.f); u[2] = fmaxf(u[2], 0.f); u[3] = fmaxf(u[3], 0.f); }
+      if (!ok[t]) u = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[t] += g * u;
+    }
   }
-  // lanes with equal (lane % CQ) hold partial sums of the same channel quad
+  // lanes with equal (lane % CQ) hold partial sums of the same channel quad: fold them inside each row of 16 lanes by DPP
+  // rotations (lane l += lane l+8, +4, ... down to CQ), the 16 rows of the workgroup meet in LDS
 #pragma unroll
   for (int t = 0; t < KK; t++) {
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      float v = acc[t][e];
-      for (int o = 32; o >= CQ; o >>= 1) v += __shfl_xor(v, o, 64);
-      acc[t][e] = v;
+      float a = acc[t][e];
+      if (CQ <= 8) a = row_ror_add<8>(a);
+      if (CQ <= 4) a = row_ror_add<4>(a);
+      if (CQ <= 2) a = row_ror_add<2>(a);
+      if (CQ <= 1) a = row_ror_add<1>(a);
+      acc[t][e] = a;
     }
   }
-  // CQ <= 4 per pass through the LDS buffer (CQ = 1, 2, 4 in one pass; 8, 16 in several)
-  for (int c0 = 0; c0 < CQ; c0 += 4) {
+  const int rl = lane & 15, row = wave * 4 + (lane >> 4);
+  for (int c0 = 0; c0 < CQ; c0 += 4) {          // CQ <= 4 in one pass through the LDS buffer, 8 / 16 in two / four
     __syncthreads();
-    if (lane >= c0 && lane < c0 + 4 && lane < CQ) {
+    if (rl >= c0 && rl < c0 + 4 && rl < CQ) {
 #pragma unroll
-      for (int t = 0; t < KK; t++) red[wave][t][lane - c0] = acc[t];
+      for (int t = 0; t < KK; t++) red[row][t][rl - c0] = acc[t];
     }
     __syncthreads();
     const int nq = min(4, CQ - c0);
     for (int o = threadIdx.x; o < KK * nq; o += blockDim.x) {
       const int t = o / nq, qd = o % nq;
-      const f32x4 sum = red[0][t][qd] + red[1][t][qd] + red[2][t][qd] + red[3][t][qd];
+      f32x4 sum = red[0][t][qd];
+#pragma unroll
+      for (int r = 1; r < 16; r++) sum += red[r][t][qd];
       float* dst = part + (long)blockIdx.x * KK * C + t * C + (c0 + qd) * 4;
       dst[0] = sum[0]; dst[1] = sum[1]; dst[2] = sum[2]; dst[3] = sum[3];
     }
@@ -732,6 +851,13 @@ __global__ void copy_into_channels_kernel(const float* __restrict__ x, int Cn, f
   GRID_STRIDE(o, P * Cn) { long p = o / Cn; int c = o % Cn; y[p * ldy + c0 + c] = x[o]; }
 }
 
+// blocks of the float4 depthwise weight-gradient kernels: one per CU -- their epilogue (K*K*4 wave reductions per wave)
+// costs as much as ~10 items of the main loop, so fewer, longer-running waves win over occupancy
+static int dw_wgrad_blocks(long items) {
+  long nb = (items + 255) / 256;
+  if (nb > 512) nb = 512;                               // two resident workgroups per CU (227 VGPRs at K = 5)
+  return (int)(nb < 1 ? 1 : nb);
+}
 static int red_blocks(long P, long* per_blk) {
   long nb = (P + 511) / 512;
   if (nb > 1024) nb = 1024;
@@ -774,7 +900,15 @@ int lctvqa_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, in
                       int relu_in, void* stream) {
   LCT_REQUIRE(K >= 1 && stride >= 1 && dil >= 1, "dwconv: bad args");
   int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
-  if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
+  const bool pow2q = C % 4 == 0 && ((C / 4) & (C / 4 - 1)) == 0 && C <= 256;
+  if (pow2q && (K == 3 || K == 5 || K == 7) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && (long)B * H * W * C < (1L << 31)) {
+    const dim3 grid(gs_blocks((long)B * Ho * Wo * (C / 4), 2048));
+    const size_t lds = (size_t)K * K * (C / 4) * sizeof(f32x4);
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 3) hipLaunchKernelGGL(dwconv_fwd_vecK_kernel<3>, grid, dim3(256), lds, st, x, w, y, B, H, W, C, stride, pad, dil, Ho, Wo, relu_in);
+    else if (K == 5) hipLaunchKernelGGL(dwconv_fwd_vecK_kernel<5>, grid, dim3(256), lds, st, x, w, y, B, H, W, C, stride, pad, dil, Ho, Wo, relu_in);
+    else hipLaunchKernelGGL(dwconv_fwd_vecK_kernel<7>, grid, dim3(256), lds, st, x, w, y, B, H, W, C, stride, pad, dil, Ho, Wo, relu_in);
+  } else if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
     hipLaunchKernelGGL(dwconv_fwd_vec_kernel, dim3(gs_blocks((long)B * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, w, y,
                        B, H, W, C, K, stride, pad, dil, Ho, Wo, relu_in);
   else
@@ -785,7 +919,16 @@ int lctvqa_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, in
 int lctvqa_dwconv_bwd_input(const float* dy, const float* w, const float* x, float* dx, int B, int H, int W, int C, int K,
                             int stride, int pad, int dil, int relu_in, void* stream) {
   int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
-  if (C % 4 == 0 && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) & 15) == 0)
+  const bool pow2q = C % 4 == 0 && ((C / 4) & (C / 4 - 1)) == 0 && C <= 256;
+  if (pow2q && (K == 3 || K == 5 || K == 7) && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) & 15) == 0 &&
+      (long)B * H * W * C < (1L << 31)) {
+    const dim3 grid(gs_blocks((long)B * H * W * (C / 4), 2048));
+    const size_t lds = (size_t)K * K * (C / 4) * sizeof(f32x4);
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 3) hipLaunchKernelGGL(dwconv_bwd_input_vecK_kernel<3>, grid, dim3(256), lds, st, dy, w, x, dx, B, H, W, C, stride, pad, dil, Ho, Wo, relu_in);
+    else if (K == 5) hipLaunchKernelGGL(dwconv_bwd_input_vecK_kernel<5>, grid, dim3(256), lds, st, dy, w, x, dx, B, H, W, C, stride, pad, dil, Ho, Wo, relu_in);
+    else hipLaunchKernelGGL(dwconv_bwd_input_vecK_kernel<7>, grid, dim3(256), lds, st, dy, w, x, dx, B, H, W, C, stride, pad, dil, Ho, Wo, relu_in);
+  } else if (C % 4 == 0 && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) & 15) == 0)
     hipLaunchKernelGGL(dwconv_bwd_input_vec_kernel, dim3(gs_blocks((long)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, w,
                        x, dx, B, H, W, C, K, stride, pad, dil, Ho, Wo, relu_in);
   else
@@ -804,9 +947,10 @@ int lctvqa_dwconv_bwd_weight(const float* dy, const float* x, float* dw, float* 
   int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
   long per;
   int nb = red_blocks((long)B * Ho * Wo, &per);
-  const bool vec = (C % 4 == 0) && C <= 256 && ((C / 4) & (C / 4 - 1)) == 0 && (K == 3 || K == 5 || K == 7) &&
-                   (((uintptr_t)dy | (uintptr_t)x) & 15) == 0;
-  if (vec) {            // same nb blocks and the same part[blk][tap*C + c] layout, grid-stride over (pixel, channel quad) items
+  const bool vec = (C % 4 == 0) && C <= 64 && ((C / 4) & (C / 4 - 1)) == 0 && (K == 3 || K == 5 || K == 7) &&
+                   (((uintptr_t)dy | (uintptr_t)x) & 15) == 0 && (long)B * H * W * C < (1L << 31);
+  if (vec) {            // at most nb blocks and the same part[blk][tap*C + c] layout, grid-stride over (pixel, channel quad) items
+    nb = min(nb, dw_wgrad_blocks((long)B * Ho * Wo * (C / 4)));
     if (K == 3)
       hipLaunchKernelGGL(dwconv_bwd_weight_vec_kernel<3>, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, x, scratch, B, H, W, C, stride,
                          pad, dil, Ho, Wo, relu_in);
