@@ -450,6 +450,71 @@ __global__ __launch_bounds__(256) void pwconv_wgrad_small_kernel(const float* __
     }
   }
 }
+// The same gradient for the cells' own 1x1 convs (Cin in {4, 8, 16}, Cout in {4, 8, 16}: every pointwise conv inside a MixedOp):
+// thread = (pixel, quad of output channels); one float4 of dy and CIN/4 float4s of x per item, the 4 x CIN outer product
+// accumulates in registers, so the kernel streams dy and x once with 16-B coalesced loads and no barrier in the loop.  Lanes
+// of one output quad fold inside each row of 16 lanes by DPP rotations, the 16 rows of the workgroup meet in LDS
+// (the structure of dwconv_bwd_weight_vec_kernel).  part[blk][co * CIN + ci] as above.
+template <int CIN>
+__global__ __launch_bounds__(256) void pwconv_wgrad_quad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                float* __restrict__ part, int P, int Cout, int relu_in) {
+  constexpr int NQ = CIN / 4;
+  __shared__ f32x4 red[16][4][4][NQ];                           // [row of 16 lanes][output quad][e][input quad]
+  const int CQ = Cout >> 2;                                     // 1, 2 or 4
+  const int items = P * CQ;
+  const f32x4* dy4 = (const f32x4*)dy;
+  const f32x4* x4 = (const f32x4*)x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 acc[4][NQ];
+#pragma unroll
+  for (int e = 0; e < 4; e++)
+#pragma unroll
+    for (int n = 0; n < NQ; n++) acc[e][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < items; i += gridDim.x * blockDim.x) {
+    const int pix = i / CQ;
+    const f32x4 g = dy4[i];
+    f32x4 xv[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; n++) xv[n] = x4[(long)pix * NQ + n];
+#pragma unroll
+    for (int n = 0; n < NQ; n++) {
+      f32x4 u = xv[n];
+      if (relu_in) { u[0] = fmaxf(u[0], 0.f); u[1] = fmaxf(u[1], 0.f); u[2] = fmaxf(u[2], 0.f); u[3] = fmaxf(u[3], 0.f); }
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc[e][n] += g[e] * u;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++)
+#pragma unroll
+    for (int n = 0; n < NQ; n++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float a = acc[e][n][k];
+        a = row_ror_add<8>(a);
+        a = row_ror_add<4>(a);
+        if (CQ <= 2) a = row_ror_add<2>(a);
+        if (CQ <= 1) a = row_ror_add<1>(a);
+        acc[e][n][k] = a;
+      }
+  const int rl = lane & 15, row = wave * 4 + (lane >> 4);
+  if (rl < CQ) {
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+      for (int n = 0; n < NQ; n++) red[row][rl][e][n] = acc[e][n];
+  }
+  __syncthreads();
+  const int NO = Cout * CIN;
+  for (int o = threadIdx.x; o < NO; o += blockDim.x) {
+    const int co = o / CIN, ci = o % CIN;
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) sum += red[r][co >> 2][co & 3][ci >> 2][ci & 3];
+    part[(long)blockIdx.x * NO + o] = sum;
+  }
+}
+
 // out[t] = sum_blk part[blk][t]   (one wave per output)
 __global__ __launch_bounds__(64) void colsum_partials_kernel(const float* __restrict__ part, int nblk, int NO, float* __restrict__ out) {
   const int t = blockIdx.x;
@@ -999,8 +1064,18 @@ int lctvqa_pwconv_wgrad_small(const float* dy, const float* x, float* dw, float*
   LCT_REQUIRE(lctvqa_pwconv_wgrad_small_supported(P, Cout, Cin), "pwconv_wgrad_small: unsupported P=%ld Cout=%d Cin=%d", P, Cout, Cin);
   long per;
   int nb = red_blocks(P, &per);
-  size_t lds = (size_t)(Cout + Cin) * 256 * sizeof(float);
-  hipLaunchKernelGGL(pwconv_wgrad_small_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, dy, x, scratch, P, Cout, Cin, relu_in, per);
+  const bool quad = (Cin == 4 || Cin == 8 || Cin == 16) && (Cout == 4 || Cout == 8 || Cout == 16) && P * (Cout / 4) < (1L << 31) &&
+                    (((uintptr_t)dy | (uintptr_t)x) & 15) == 0;
+  if (quad) {           // at most nb blocks (the scratch is sized for nb), same part layout
+    nb = (int)min((long)nb, (P * (Cout / 4) + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (Cin == 4) hipLaunchKernelGGL(pwconv_wgrad_quad_kernel<4>, dim3(nb), dim3(256), 0, st, dy, x, scratch, (int)P, Cout, relu_in);
+    else if (Cin == 8) hipLaunchKernelGGL(pwconv_wgrad_quad_kernel<8>, dim3(nb), dim3(256), 0, st, dy, x, scratch, (int)P, Cout, relu_in);
+    else hipLaunchKernelGGL(pwconv_wgrad_quad_kernel<16>, dim3(nb), dim3(256), 0, st, dy, x, scratch, (int)P, Cout, relu_in);
+  } else {
+    size_t lds = (size_t)(Cout + Cin) * 256 * sizeof(float);
+    hipLaunchKernelGGL(pwconv_wgrad_small_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, dy, x, scratch, P, Cout, Cin, relu_in, per);
+  }
   int rc = lct_check_launch("pwconv_wgrad_small");
   if (rc) return rc;
   hipLaunchKernelGGL(colsum_partials_kernel, dim3(Cout * Cin), dim3(64), 0, (hipStream_t)stream, scratch, nb, Cout * Cin, dw);
