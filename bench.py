@@ -45,6 +45,10 @@ def parse():
                     help='run the frozen trunk of a batch as this many sub-batches on streams of their own (pipelined mode).  2 is '
                          '1.4 %% faster (tails of one part filled by the other); default 1 because overlapping conv kernels make the '
                          'per-launch durations behind the roofline fields meaningless')
+    ap.add_argument('--head-after', type=int, default=8,
+                    help='pipelined mode: hold the head of batch i until the trunk of batch i+1 has launched past conv layer N '
+                         '(1..16; 0 = start it as soon as its own trunk is done).  Default 8 = after conv3_4: the head shares the chip with the '
+                         '28x28 layers; 0.8 %% faster than 0, 12 and later leave it too little time')
     ap.add_argument('--workload', default='w', choices=['w', 'lct'],
                     help="'w' = BASELINE configs[1] (default, the headline metric); 'lct' = stage-1 + stage-2 step of "
                          "experiment.py:216-268 (EF fixed encoder + generate + W soft loss), reported under its own metric name")
@@ -208,6 +212,7 @@ def main():
         # i run on the main stream.  Every timed step still performs one trunk and one head pass; the pipeline is
         # primed and drained INSIDE the timed region (K trunks + K heads between the two barriers).
         main_stream = torch.cuda.current_stream()
+        ops.set_trunk_marker(args.head_after)
         nsplit = max(1, args.trunk_split)
         trunk_streams = [torch.cuda.Stream() for _ in range(nsplit)]
         trunk_stream = trunk_streams[0]
@@ -241,6 +246,11 @@ def main():
                 feat, ev = nxt
                 if i + 1 < k:
                     nxt = launch_trunk()
+                    if args.head_after and ops.trunk_marker_event() is not None:
+                        # start this batch's head only when the NEXT batch's trunk has passed conv layer --head-after: the
+                        # head's small kernels then share the chip with layers whose grids leave idle tails (28x28: 12.25
+                        # rounds of 256 CUs) instead of landing on conv1_2 / conv2_1
+                        main_stream.wait_event(ops.trunk_marker_event())
                 main_stream.wait_event(ev)
                 opt.zero_grad()
                 out = ops.cross_entropy(model(img, qst, feat), lab)
@@ -339,7 +349,7 @@ def main():
                                                      'shared by its two forwards)' if args.lct_share_trunk else
                                                   'per call for the examiner, once for W')),
                    'global_batch': world * B, 'seq_len': 14, 'parallelism': f'dp{world}',
-                   'schedule': 'trunk(i+1) || head(i) on two HIP streams' if pipelined else 'single stream'},
+                   'schedule': ('trunk(i+1) || head(i) on two HIP streams' + (', head starts after conv layer %d of trunk(i+1)' % args.head_after if args.head_after else '')) if pipelined else 'single stream'},
         'loss': round(float(loss.item()), 5),
         'model_flops_per_step': 39.48e9 * B if args.workload == 'w' else None,
         'model_tflops': round(39.48e9 * B / (ms * 1e-3) / 1e12, 2) if args.workload == 'w' else None,

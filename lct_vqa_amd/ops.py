@@ -710,6 +710,21 @@ def _pool(cur, B, H, W):
     return out
 
 
+_trunk_mark = {'after': 0, 'event': None}
+
+
+def set_trunk_marker(after_conv):
+    """Schedule hook for drivers that overlap the frozen trunk with other work (bench.py): every trunk forward records
+    a HIP event on its stream right after launching conv layer number ``after_conv`` (1 = conv1_1 ... 16 = conv5_4;
+    0 = off); ``trunk_marker_event()`` returns the one of the most recent forward."""
+    _trunk_mark['after'] = int(after_conv)
+    _trunk_mark['event'] = None
+
+
+def trunk_marker_event():
+    return _trunk_mark['event']
+
+
 def vgg_features_forward(image, convs, fuse_pool=True, keep=None, cache=False):
     """vgg19.features + avgpool + flatten.  image NCHW [B,3,H,W]; convs: list of (weight OIHW, bias) with 'M'
     marking MaxPool2d(2,2).  When ``keep`` (a list) is given it receives, per conv layer,
@@ -721,7 +736,7 @@ def vgg_features_forward(image, convs, fuse_pool=True, keep=None, cache=False):
         raise RuntimeError('VGG19 expects 3 input channels')
     dev = image.device
     fuse = fuse_pool and keep is None
-    cur, i, n = None, 0, len(convs)
+    cur, i, n, nconv = None, 0, len(convs), 0
     while i < n:
         item = convs[i]
         if isinstance(item, str):                            # un-fused MaxPool2d(2,2)
@@ -742,6 +757,11 @@ def vgg_features_forward(image, convs, fuse_pool=True, keep=None, cache=False):
         if keep is not None:
             keep.append((out, H, W, 1 if pool_next else 0))
         cur = out
+        nconv += 1
+        if _trunk_mark['after'] == nconv:                    # schedule hook (set_trunk_marker): this point of the stream
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            _trunk_mark['event'] = ev
         if fused:
             H, W = H // 2, W // 2
             i += 2
