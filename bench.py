@@ -49,6 +49,9 @@ def parse():
                     help='pipelined mode: hold the head of batch i until the trunk of batch i+1 has launched past conv layer N '
                          '(1..16; 0 = start it as soon as its own trunk is done).  Default 8 = after conv3_4: the head shares the chip with the '
                          '28x28 layers; 0.8 %% faster than 0, 12 and later leave it too little time')
+    ap.add_argument('--stem-after', type=int, default=0,
+                    help='pipelined mode: run conv1_1 of batch i+1 on a stream of its own, released when the trunk of batch i has '
+                         'launched past conv layer N (0 = conv1_1 stays at the head of its own trunk)')
     ap.add_argument('--workload', default='w', choices=['w', 'lct'],
                     help="'w' = BASELINE configs[1] (default, the headline metric); 'lct' = stage-1 + stage-2 step of "
                          "experiment.py:216-268 (EF fixed encoder + generate + W soft loss), reported under its own metric name")
@@ -212,13 +215,31 @@ def main():
         # i run on the main stream.  Every timed step still performs one trunk and one head pass; the pipeline is
         # primed and drained INSIDE the timed region (K trunks + K heads between the two barriers).
         main_stream = torch.cuda.current_stream()
-        ops.set_trunk_marker(args.head_after)
         nsplit = max(1, args.trunk_split)
+        stem_after = args.stem_after if nsplit == 1 else 0
+        ops.set_trunk_marker(args.head_after, stem_after)
         trunk_streams = [torch.cuda.Stream() for _ in range(nsplit)]
         trunk_stream = trunk_streams[0]
+        stem_stream = torch.cuda.Stream()
         img_parts = [p.contiguous() for p in img.chunk(nsplit)]
+        vgg = model.img_encoder.model
 
-        def launch_trunk():
+        def launch_stem(after_event):
+            # conv1_1 of the NEXT batch (HBM-write bound, 3.3 GB) on a stream of its own, released when the current trunk
+            # has passed conv layer --stem-after: it runs beside MFMA-bound layers instead of in front of conv1_2
+            if not stem_after:
+                return None
+            stem_stream.wait_stream(main_stream)
+            if after_event is not None:
+                stem_stream.wait_event(after_event)
+            with torch.cuda.stream(stem_stream):
+                out = vgg.stem(img)
+                ev = torch.cuda.Event()
+                ev.record(stem_stream)
+            out.record_stream(trunk_stream)
+            return out, ev
+
+        def launch_trunk(stem=None):
             # The frozen trunk has no cross-sample coupling: its batch is cut into `nsplit` parts that run the 15 conv layers
             # on streams of their own, so the workgroups of one part fill the tail of the other's kernels (a layer's grid
             # is not a multiple of the 256 CUs: 12.25 rounds for the 28x28 layers) and the HBM-bound conv1_1 / the
@@ -227,7 +248,11 @@ def main():
             for st, part in zip(trunk_streams, img_parts):
                 st.wait_stream(main_stream)
                 with torch.cuda.stream(st):
-                    feats.append(model.img_encoder.trunk(part))
+                    if stem is not None:
+                        st.wait_event(stem[1])
+                        feats.append(model.img_encoder.trunk(part, stem=stem[0]))
+                    else:
+                        feats.append(model.img_encoder.trunk(part))
             for st in trunk_streams[1:]:
                 trunk_stream.wait_stream(st)
             with torch.cuda.stream(trunk_stream):
@@ -240,17 +265,18 @@ def main():
             return f, ev
 
         def run_steps(k):
-            nxt = launch_trunk()
+            nxt = launch_trunk(launch_stem(None))
             out = None
             for i in range(k):
                 feat, ev = nxt
                 if i + 1 < k:
-                    nxt = launch_trunk()
-                    if args.head_after and ops.trunk_marker_event() is not None:
+                    stem = launch_stem(ops.trunk_marker_event(stem_after))         # marker of trunk(i), launched last round
+                    nxt = launch_trunk(stem)
+                    if args.head_after and ops.trunk_marker_event(args.head_after) is not None:
                         # start this batch's head only when the NEXT batch's trunk has passed conv layer --head-after: the
                         # head's small kernels then share the chip with layers whose grids leave idle tails (28x28: 12.25
                         # rounds of 256 CUs) instead of landing on conv1_2 / conv2_1
-                        main_stream.wait_event(ops.trunk_marker_event())
+                        main_stream.wait_event(ops.trunk_marker_event(args.head_after))
                 main_stream.wait_event(ev)
                 opt.zero_grad()
                 out = ops.cross_entropy(model(img, qst, feat), lab)

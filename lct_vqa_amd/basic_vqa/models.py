@@ -20,12 +20,12 @@ class ImgEncoder(nn.Module):
         self.model, width = vgg.truncated_vgg19(pretrained=True)
         self.fc = nn.Linear(width, embed_size)
 
-    def trunk(self, image, conv_feature=None):
+    def trunk(self, image, conv_feature=None, stem=None):
         """The frozen part only (VGG19 minus its last fc, under no_grad): [B,4096].  It does not depend on any
         trainable parameter, so a caller may run it for batch i+1 on a second HIP stream while batch i's
         head/backward/optimizer runs (bench.py)."""
         with torch.no_grad():
-            return self.model(image, conv_feature)
+            return self.model(image, conv_feature, stem)
 
     def conv_features(self, image):
         """vgg19.features + avgpool of the frozen trunk (no dropout in it): shareable between forwards of one batch."""

@@ -710,22 +710,35 @@ def _pool(cur, B, H, W):
     return out
 
 
-_trunk_mark = {'after': 0, 'event': None}
+_trunk_mark = {'after': (), 'events': {}}
 
 
-def set_trunk_marker(after_conv):
+def set_trunk_marker(*after_convs):
     """Schedule hook for drivers that overlap the frozen trunk with other work (bench.py): every trunk forward records
-    a HIP event on its stream right after launching conv layer number ``after_conv`` (1 = conv1_1 ... 16 = conv5_4;
-    0 = off); ``trunk_marker_event()`` returns the one of the most recent forward."""
-    _trunk_mark['after'] = int(after_conv)
-    _trunk_mark['event'] = None
+    a HIP event on its stream right after launching conv layer number n for each n given (1 = conv1_1 ... 16 = conv5_4;
+    none or 0 = off); ``trunk_marker_event(n)`` returns the one of the most recent forward."""
+    _trunk_mark['after'] = tuple(int(a) for a in after_convs if int(a) > 0)
+    _trunk_mark['events'] = {}
 
 
-def trunk_marker_event():
-    return _trunk_mark['event']
+def trunk_marker_event(after_conv):
+    return _trunk_mark['events'].get(int(after_conv))
 
 
-def vgg_features_forward(image, convs, fuse_pool=True, keep=None, cache=False):
+def vgg_stem_forward(image, w, b):
+    """conv1_1 + ReLU of vgg19.features: NCHW image [B,3,H,W] -> NHWC [B,H,W,64].  HBM-write bound (3.3 GB at B=256): a
+    driver may run it for the next batch on a stream of its own beside the MFMA-bound layers of the current one and hand
+    the result to ``vgg_features_forward(..., stem=)``."""
+    image, w = _chk(image, 'image'), _chk(w)
+    B, C, H, W = image.shape
+    if C != 3:
+        raise RuntimeError('VGG19 expects 3 input channels')
+    out = torch.empty((B, H, W, w.shape[0]), dtype=torch.float32, device=image.device)
+    lib('conv3x3_first_nchw', image, w, b, out, B, H, W, w.shape[0], 1)
+    return out
+
+
+def vgg_features_forward(image, convs, fuse_pool=True, keep=None, cache=False, stem=None):
     """vgg19.features + avgpool + flatten.  image NCHW [B,3,H,W]; convs: list of (weight OIHW, bias) with 'M'
     marking MaxPool2d(2,2).  When ``keep`` (a list) is given it receives, per conv layer,
     (activation after ReLU [un-pooled], H, W, pooled_after) for the backward pass; pools are then NOT
@@ -748,8 +761,13 @@ def vgg_features_forward(image, convs, fuse_pool=True, keep=None, cache=False):
         w = _chk(w)
         pool_next = (i + 1 < n) and isinstance(convs[i + 1], str)
         if cur is None:                                      # first layer: NCHW image -> NHWC
-            out = torch.empty((B, H, W, w.shape[0]), dtype=torch.float32, device=dev)
-            lib('conv3x3_first_nchw', image, w, b, out, B, H, W, w.shape[0], 1)
+            if stem is not None:                             # precomputed by vgg_stem_forward on the same image / weights
+                out = _chk(stem, 'stem')
+                if tuple(out.shape) != (B, H, W, w.shape[0]):
+                    raise RuntimeError(f'stem has shape {tuple(out.shape)}, expected {(B, H, W, w.shape[0])}')
+            else:
+                out = torch.empty((B, H, W, w.shape[0]), dtype=torch.float32, device=dev)
+                lib('conv3x3_first_nchw', image, w, b, out, B, H, W, w.shape[0], 1)
             fused = 0
         else:
             fused = 1 if (fuse and pool_next and H % 2 == 0 and W % 2 == 0) else 0
@@ -758,10 +776,10 @@ def vgg_features_forward(image, convs, fuse_pool=True, keep=None, cache=False):
             keep.append((out, H, W, 1 if pool_next else 0))
         cur = out
         nconv += 1
-        if _trunk_mark['after'] == nconv:                    # schedule hook (set_trunk_marker): this point of the stream
+        if nconv in _trunk_mark['after']:                    # schedule hook (set_trunk_marker): this point of the stream
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
-            _trunk_mark['event'] = ev
+            _trunk_mark['events'][nconv] = ev
         if fused:
             H, W = H // 2, W // 2
             i += 2
@@ -773,12 +791,13 @@ def vgg_features_forward(image, convs, fuse_pool=True, keep=None, cache=False):
     return flat, (H, W, Cl)
 
 
-def vgg_trunk_forward(image, convs, fcs, train, conv_feature=None, cache=False):
+def vgg_trunk_forward(image, convs, fcs, train, conv_feature=None, cache=False, stem=None):
     """torchvision vgg19 (reference basic_vqa/models.py:23-28,36), forward only (frozen trunk).
     fcs: list of (weight, bias, act, drop_p) for the classifier.  Returns [B, fcs[-1] out features].
     conv_feature: the flattened features+avgpool output [B, 25088] of an earlier call on the same image and weights
     (deterministic: the dropouts live in the classifier, which is always re-run)."""
-    x = conv_feature if conv_feature is not None else vgg_features_forward(image, convs, fuse_pool=True, keep=None, cache=cache)[0]
+    x = conv_feature if conv_feature is not None else vgg_features_forward(image, convs, fuse_pool=True, keep=None, cache=cache,
+                                                                           stem=stem)[0]
     B, dev = x.shape[0], x.device
     for (w, b, act, drop_p) in fcs:
         m = dropout_mask((B, w.shape[0]), dev, drop_p) if (train and drop_p > 0) else None

@@ -75,14 +75,20 @@ class VGG(nn.Module):
         with torch.no_grad():
             return ops.vgg_features_forward(x, convs, fuse_pool=True, keep=None, cache=self.cache_packed_weights)[0]
 
-    def forward(self, x, conv_feature=None):
+    def stem(self, x):
+        """conv1_1 + ReLU alone (NHWC), for a driver that runs it ahead on its own stream: pass it back as ``stem``."""
+        convs, _ = self._plan()
+        with torch.no_grad():
+            return ops.vgg_stem_forward(x, *convs[0])
+
+    def forward(self, x, conv_feature=None, stem=None):
         convs, fcs = self._plan()
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not needs_grad:
             with torch.no_grad():
-                return ops.vgg_trunk_forward(x, convs, fcs, True, conv_feature, cache=self.cache_packed_weights)
-        if conv_feature is not None:
-            raise RuntimeError('conv_feature can only be re-used with a trunk that needs no gradient')
+                return ops.vgg_trunk_forward(x, convs, fcs, True, conv_feature, cache=self.cache_packed_weights, stem=stem)
+        if conv_feature is not None or stem is not None:
+            raise RuntimeError('conv_feature / stem can only be re-used with a trunk that needs no gradient')
         # trainable trunk (reference models_lct.py:62-63): autograd through the HIP backward kernels
         plan = ['M' if isinstance(c, str) else 'C' for c in convs]
         params = [t for c in convs if not isinstance(c, str) for t in c]
