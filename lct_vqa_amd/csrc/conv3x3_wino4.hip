@@ -9,14 +9,15 @@
 // output on the trunk's shapes (direct fp32: 2-3e-7; tools/sim_f43.py), far inside the 1e-3 logit gate.
 //
 // Structure (one workgroup = 8 waves, two per SIMD, 256 registers each):
-//  * a workgroup owns 32 tiles (TY x TX tiles of 4x4 output pixels) x 64 output channels.  Wave (xg, cg) accumulates 9 of
-//    the 36 transformed-domain GEMMs (xi*6+nu = 9 xg .. 9 xg + 8) for 32 tiles x 32 channels = 144 accumulator
-//    registers; the second wave of a SIMD fills the first one's issue gaps;
+//  * a workgroup owns 32 tiles (TY x TX tiles of 4x4 output pixels) x 64 output channels = 72 accumulator tiles
+//    (36 transformed-domain GEMMs xi*6+nu x two 32-channel groups; 32 tiles x 32 channels = 16 registers each), dealt out
+//    8 to each of the six waves that also carry a transform column and 12 to the two that do not; the second wave of a
+//    SIMD fills the first one's issue gaps;
 //  * K loop in 8-channel chunks: raw halo patch HBM->LDS by LDS-DMA (planar per channel quad, stacked rows with one
 //    shared zero row per image boundary); input transform B^T d B by waves 0..5: thread = (tile, channel quad), wave =
 //    output column nu, so every wave runs straight-line code for its column; V[36][2 quads][32 tiles][4] double
 //    buffered, the transform of chunk c+1 cut into slices pinned between the MFMAs of chunk c; weights U = G g G^T
-//    straight from L2 into one register slot per (xi,nu), refilled a whole phase ahead (counted vmcnt, bare barrier);
+//    straight from L2 into a 4-slot register ring refilled right behind the MFMAs (counted vmcnt, bare barrier);
 //  * epilogue: the 36 accumulators of a (tile, channel) live in 4 waves: they are exchanged through LDS in 4 rounds
 //    (8 (channel group, register) units = 73.7 KB per round), each wave output-transforms A^T M A one unit per round,
 //    adds bias, ReLU, optional 2x2 max-pool in registers, NHWC stores 128 B contiguous per half wave.
@@ -81,7 +82,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cg = wave & 1, xg = wave >> 1;
   const int j = lane & 31, h = lane >> 5;
   const int NT = Cout / 64;
   // workgroups are dealt to the 8 XCDs round-robin: the NT workgroups reading one input patch share an XCD (its L2)
@@ -184,21 +184,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
     if (q == 6 || q == 7) tcol(Vn, nu, (q - 6) * 2 + i);
   };
 
-#ifndef W4_UNEVEN
-#define W4_UNEVEN 1
-#endif
-#ifndef W4_X_NOT
-#define W4_X_NOT 0
-#endif
-#ifndef W4_X_NOB
-#define W4_X_NOB 0
-#endif
-#ifndef W4_X_NORAW
-#define W4_X_NORAW 0
-#endif
-#ifndef W4_X_NOEPI
-#define W4_X_NOEPI 0
-#endif
   // -DW4_DIAG: per-wave s_memtime stamps (ticks parked at the end-of-phase wait + barrier, K-loop ticks, epilogue ticks)
   // written to y instead of the result; read by tools/diag_wino4.py
 #ifdef W4_DIAG
@@ -213,7 +198,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
   const long UCH = 36 * 256;                                    // floats of packed weights per (32-channel group, chunk)
 
-#if W4_UNEVEN
   // ---- main loop, uneven split.  The 72 accumulator tiles t = cg * 36 + (xi*6+nu) of the workgroup are dealt out as
   // 8 to each of waves 0..5 (which also carry a transform column) and 12 to waves 6 and 7 (which do not): measured with
   // the even 9/9 split, waves 6/7 spent 31-37 % of the K loop parked at the phase barrier while the SIMDs carrying two
@@ -241,14 +225,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
     if ((S) + 1 < (NTW)) ANEXT = *(const f32x4*)(vc + W4_XN(T0, (S) + 1) * 256);                       \
     W4_SB();                                                                                          \
     W4_MF(S, ACUR, 1);                                                                                \
-    if (NXT && !W4_X_NOT) tslice(rwn, Vn, S, 0, NU);                                                  \
+    if (NXT) tslice(rwn, Vn, S, 0, NU);                                                  \
     W4_SB();                                                                                          \
     W4_MF(S, ACUR, 2);                                                                                \
-    if (NXT && !W4_X_NOT) tslice(rwn, Vn, S, 1, NU);                                                  \
+    if (NXT) tslice(rwn, Vn, S, 1, NU);                                                  \
     W4_SB();                                                                                          \
     W4_MF(S, ACUR, 3);                                                                                \
-    if (W4_X_NOB) {                                                                                   \
-    } else if ((S) + 4 < (NTW)) {                                                                     \
+    if ((S) + 4 < (NTW)) {                                                                            \
       Bw[(S) % 4] = *(const f32x4*)(W4_UB(T0, (S) + 4) + (long)chunk * UCH + W4_XN(T0, (S) + 4) * 256);   \
     } else if (NXT) {                                                                                 \
       Bw[(S) % 4] = *(const f32x4*)(W4_UB(T0, (S) + 4 - (NTW)) + (long)(chunk + 1) * UCH + W4_XN(T0, (S) + 4 - (NTW)) * 256); \
@@ -278,7 +261,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
       if ((NTW) == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");         \
       else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");                   \
       W4_DIAG_T1                                                                                      \
-      if (chunk + 3 < NCH && !W4_X_NORAW) stage_raw(chunk + 3, raw + ((chunk + 1) & 1) * RAWSZ);      \
+      if (chunk + 3 < NCH) stage_raw(chunk + 3, raw + ((chunk + 1) & 1) * RAWSZ);      \
     }                                                                                                 \
     W4_PHASE(false, NU, T0, NTW)                                                                      \
   }
@@ -312,99 +295,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
 #undef W4_PHASE
 #undef W4_STEP
 #undef W4_MF
-#else
-  // ---- main loop, even split: wave (xg, cg) accumulates the 9 GEMMs 9 xg .. 9 xg + 8 of channel group cg
-  f32x16 acc[9];
-#pragma unroll
-  for (int q = 0; q < 9; q++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
-
-  // packed weights: [32-channel group][chunk][36][2 quads][32 ch][4]; this wave: group 2 n_tile + cg, planes 9 xg ..
-  const float* ub = up + (long)(n_tile * 2 + cg) * NCH * UCH + (xg * 9) * 256 + (h * 32 + j) * 4;
-  const float* va = V + (xg * 9) * 256 + h * 128 + j * 4;
-
-  // weights: ring of three (xi,nu) slots; the slot of step q is refilled right behind its MFMAs with the weights of step
-  // q+3 (this chunk's for q < 6, the next chunk's q-6 otherwise).  A slot per step (a whole phase of lead, as in the
-  // F(2x2,3x3) kernels) would need 24 more registers than the 256 of a wave at two waves per SIMD.
-  f32x4 Bw[3];
-  f32x4 Aa, Ab;
-#define W4_MF(Q, ACUR, E) acc[Q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ACUR[E], Bw[(Q) % 3][E], acc[Q], 0, 0, 0)
-  // one (xi,nu): 4 MFMAs (8 channels); the other work is pinned between them in source order
-#define W4_STEP(Q, ACUR, ANEXT, NXT, NU)                                                               \
-  {                                                                                                   \
-    W4_MF(Q, ACUR, 0);                                                                                \
-    if ((Q) + 1 < 9) ANEXT = *(const f32x4*)(vc + ((Q) + 1) * 256);                                    \
-    W4_SB();                                                                                          \
-    W4_MF(Q, ACUR, 1);                                                                                \
-    if (NXT && !W4_X_NOT) tslice(rwn, Vn, Q, 0, NU);                                                  \
-    W4_SB();                                                                                          \
-    W4_MF(Q, ACUR, 2);                                                                                \
-    if (NXT && !W4_X_NOT) tslice(rwn, Vn, Q, 1, NU);                                                  \
-    W4_SB();                                                                                          \
-    W4_MF(Q, ACUR, 3);                                                                                \
-    if (W4_X_NOB) {                                                                                   \
-    } else if ((Q) < 6) {                                                                             \
-      Bw[(Q) % 3] = *(const f32x4*)(uc + ((Q) + 3) * 256);                                             \
-    } else if (NXT) {                                                                                 \
-      Bw[(Q) % 3] = *(const f32x4*)(uc + UCH + ((Q) - 6) * 256);                                       \
-    }                                                                                                 \
-    W4_SB();                                                                                          \
-  }
-#define W4_PHASE(NXT, NU)                                                                             \
-  {                                                                                                   \
-    const float* vc = va + (chunk & 1) * VSZ;                                                         \
-    float* Vn = V + ((chunk + 1) & 1) * VSZ;                                                          \
-    const float* rwn = raw + ((chunk + 1) & 1) * RAWSZ;                                               \
-    const float* uc = ub + (long)chunk * UCH;                                                         \
-    Aa = *(const f32x4*)(vc);                                                                         \
-    W4_STEP(0, Aa, Ab, NXT, NU) W4_STEP(1, Ab, Aa, NXT, NU) W4_STEP(2, Aa, Ab, NXT, NU)                \
-    W4_STEP(3, Ab, Aa, NXT, NU) W4_STEP(4, Aa, Ab, NXT, NU) W4_STEP(5, Ab, Aa, NXT, NU)                \
-    W4_STEP(6, Aa, Ab, NXT, NU) W4_STEP(7, Ab, Aa, NXT, NU) W4_STEP(8, Aa, Ab, NXT, NU)                \
-  }
-  // End of a phase: the raw patch of chunk+2 (LDS-DMA issued at the start of the phase) must have landed; the 9 weight
-  // loads of the next chunk, issued after it, stay in flight.  Bare barrier (not __syncthreads(), whose fence would
-  // drain them); lgkmcnt(0) retires the transform's LDS stores.
-#define W4_MAIN(NU)                                                                                   \
-  {                                                                                                   \
-    int chunk = 0;                                                                                    \
-    for (; chunk < NCH - 1; chunk++) {                                                                \
-      W4_PHASE(true, NU)                                                                              \
-      W4_DIAG_T0                                                                                      \
-      asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");                        \
-      W4_DIAG_T1                                                                                      \
-      if (chunk + 3 < NCH && !W4_X_NORAW) stage_raw(chunk + 3, raw + ((chunk + 1) & 1) * RAWSZ);      \
-    }                                                                                                 \
-    W4_PHASE(false, NU)                                                                               \
-  }
-
-  stage_raw(0, raw);
-  if (NCH > 1) stage_raw(1, raw + RAWSZ);
-#pragma unroll
-  for (int q = 0; q < 3; q++) Bw[q] = *(const f32x4*)(ub + q * 256);
-  // builtin (not asm): the compiler's waitcnt bookkeeping then sees the prologue loads retired and derives the counted
-  // waits of the loop from the loop's own issue order.  0x0F70 = vmcnt(0), expcnt/lgkmcnt untouched.
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
-  transform_all(raw, V, wave);
-  __syncthreads();
-  if (NCH > 2) stage_raw(2, raw);
-
-  switch (wave) {
-    case 0: W4_MAIN(0) break;
-    case 1: W4_MAIN(1) break;
-    case 2: W4_MAIN(2) break;
-    case 3: W4_MAIN(3) break;
-    case 4: W4_MAIN(4) break;
-    case 5: W4_MAIN(5) break;
-    default: W4_MAIN(6) break;
-  }
-#undef W4_MAIN
-#undef W4_PHASE
-#undef W4_STEP
-#undef W4_MF
-
-#endif
 #undef W4_SB
 
 #ifdef W4_DIAG
@@ -415,9 +305,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
   float* xch = V;                                               // [8 units][36][64 lanes] floats = 73.7 KB = both V buffers
   const int Ho = H >> 1, Wo = W >> 1;
 #pragma unroll
-  for (int rnd = 0; rnd < (W4_X_NOEPI ? (relu == 12345 ? 4 : 0) : 4); rnd++) {
+  for (int rnd = 0; rnd < 4; rnd++) {
     __syncthreads();                                            // V (first round) / the previous round's reads are done
-#if W4_UNEVEN
 #define W4_EPI_WRITE(T0, NTW)                                                                         \
     _Pragma("unroll") for (int sq = 0; sq < (NTW); sq++) {                                             \
       float* d = xch + (((((T0) + sq) / 36) * 4) * 36 + ((T0) + sq) % 36) * 64 + lane;                 \
@@ -434,14 +323,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
       default: W4_EPI_WRITE(60, 12) break;
     }
 #undef W4_EPI_WRITE
-#else
-#pragma unroll
-    for (int q = 0; q < 9; q++) {
-      float* d = xch + ((cg * 4) * 36 + xg * 9 + q) * 64 + lane;
-#pragma unroll
-      for (int rr = 0; rr < 4; rr++) d[rr * 36 * 64] = acc[q][4 * rnd + rr];
-    }
-#endif
     __syncthreads();
     {
       const int unit = wave, c = unit >> 2, rr = unit & 3;
