@@ -209,11 +209,12 @@ int lctvqa_pool3x3_bwd(const float* dy, const float* x, float* dx, int B, int H,
 int lctvqa_subsample2_fwd(const float* x, float* y, int B, int H, int W, int C, int off, int relu, void* stream);
 int lctvqa_subsample2_bwd(const float* dy0, const float* dy1, const float* x, float* dx, int B, int H, int W, int C, int relu,
                           void* stream);
-/* BatchNorm2d over P = B*H*W rows of C channels (row strides ldx/ldy): batch statistics when training, else running */
+/* BatchNorm2d over P = B*H*W rows of C channels (row strides ldx/ldy): batch statistics when training (running estimates
+ * and the int64 num_batches_tracked counter updated in the same call when given), else running statistics */
 long lctvqa_bn_scratch_doubles(long P, int C);
 int lctvqa_batchnorm_fwd(const float* x, long ldx, float* y, long ldy, long P, int C, const float* gamma, const float* beta,
-                         float* run_mean, float* run_var, float* mean, float* invstd, double* scratch, int training, float momentum,
-                         float eps, void* stream);
+                         float* run_mean, float* run_var, long* batches_tracked, float* mean, float* invstd, double* scratch,
+                         int training, float momentum, float eps, void* stream);
 int lctvqa_batchnorm_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* invstd,
                          const float* gamma, float* dx, float* dgamma, float* dbeta, float* sums, double* scratch, long P, int C,
                          int training, void* stream);

@@ -689,8 +689,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // mean/invstd (+ running stats update: momentum m, unbiased variance); one wave per channel
 __global__ __launch_bounds__(64) void bn_stats_finish_kernel(const double* __restrict__ part, int nblk, int C, long P, float eps,
                                                              float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                                             float* __restrict__ run_mean, float* __restrict__ run_var) {
+                                                             float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                             long* __restrict__ batches_tracked) {
   const int c = blockIdx.x;
+  if (batches_tracked && c == 0 && threadIdx.x == 0) batches_tracked[0] += 1;   // nn.BatchNorm2d.num_batches_tracked
   double a = 0.0, b = 0.0;
   for (int k = threadIdx.x; k < nblk; k += 64) { a += part[((long)k * 2) * C + c]; b += part[((long)k * 2 + 1) * C + c]; }
   a = wave_sum_d(a); b = wave_sum_d(b);
@@ -1118,11 +1120,12 @@ long lctvqa_bn_scratch_doubles(long P, int C) {
   int nb = red_blocks(P, &per);
   return (long)nb * 2 * C;
 }
-// training != 0: batch statistics (+ running update when run_mean != NULL); else running statistics.
+// training != 0: batch statistics (+ running update when run_mean != NULL, + 1 on the int64 batches_tracked counter when it
+// is given); else running statistics.
 // writes mean[C], invstd[C] (saved for backward) and y.
 int lctvqa_batchnorm_fwd(const float* x, long ldx, float* y, long ldy, long P, int C, const float* gamma, const float* beta,
-                         float* run_mean, float* run_var, float* mean, float* invstd, double* scratch, int training, float momentum,
-                         float eps, void* stream) {
+                         float* run_mean, float* run_var, long* batches_tracked, float* mean, float* invstd, double* scratch,
+                         int training, float momentum, float eps, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   LCT_REQUIRE(C >= 1 && C <= 256 && P >= 1, "batchnorm: need 1 <= C <= 256");
   if (training) {
@@ -1132,7 +1135,7 @@ int lctvqa_batchnorm_fwd(const float* x, long ldx, float* y, long ldy, long P, i
     int rc = lct_check_launch("bn_stats_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(C), dim3(64), 0, st, scratch, nb, C, P, eps, momentum, mean, invstd, run_mean,
-                       run_var);
+                       run_var, batches_tracked);
   } else {
     LCT_REQUIRE(run_mean && run_var, "batchnorm eval: running statistics required");
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, run_mean, run_var, eps, C, mean, invstd);

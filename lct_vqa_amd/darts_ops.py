@@ -122,21 +122,43 @@ class PwConvFn(torch.autograd.Function):
         return dx, dw, None
 
 
+def _bn_forward(x, gamma, beta, run_mean, run_var, tracked, training, momentum, eps):
+    """One lctvqa_batchnorm_fwd call on an NHWC tensor: (y, mean, invstd).  ``tracked``: the holder's int64
+    num_batches_tracked, incremented by the same call in training mode."""
+    C = x.shape[-1]
+    P = x.numel() // C
+    dev = x.device
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=dev)
+    invstd = torch.empty(C, dtype=torch.float32, device=dev)
+    scratch = torch.empty(lib.query('bn_scratch_doubles', P, C), dtype=torch.float64, device=dev)
+    lib('batchnorm_fwd', x, C, y, C, P, C, gamma, beta, run_mean, run_var, tracked if training else None, mean, invstd, scratch,
+        int(training), float(momentum), float(eps))
+    return y, mean, invstd
+
+
+def _bn_backward(dy, x, mean, invstd, gamma, training):
+    C = x.shape[-1]
+    P = x.numel() // C
+    dev = x.device
+    dx = torch.empty_like(x)
+    sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    scratch = torch.empty(lib.query('bn_scratch_doubles', P, C), dtype=torch.float64, device=dev)
+    dg = db = None
+    if gamma is not None:
+        dg = torch.empty(C, dtype=torch.float32, device=dev)
+        db = torch.empty(C, dtype=torch.float32, device=dev)
+    lib('batchnorm_bwd', dy, C, x, C, mean, invstd, gamma, dx, dg, db, sums, scratch, P, C, int(training))
+    return dx, dg, db
+
+
 class BatchNormFn(torch.autograd.Function):
     """nn.BatchNorm2d: batch statistics + running update in train mode, running statistics in eval."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, run_mean, run_var, training, momentum, eps):
+    def forward(ctx, x, gamma, beta, run_mean, run_var, tracked, training, momentum, eps):
         x = _chk(x)
-        B, H, W, C = x.shape
-        P = B * H * W
-        dev = x.device
-        y = torch.empty_like(x)
-        mean = torch.empty(C, dtype=torch.float32, device=dev)
-        invstd = torch.empty(C, dtype=torch.float32, device=dev)
-        scratch = torch.empty(lib.query('bn_scratch_doubles', P, C), dtype=torch.float64, device=dev)
-        lib('batchnorm_fwd', x, C, y, C, P, C, gamma, beta, run_mean, run_var, mean, invstd, scratch, int(training),
-            float(momentum), float(eps))
+        y, mean, invstd = _bn_forward(x, gamma, beta, run_mean, run_var, tracked, training, momentum, eps)
         ctx.save_for_backward(x, mean, invstd, gamma)
         ctx.training = int(training)
         return y
@@ -144,19 +166,8 @@ class BatchNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, mean, invstd, gamma = ctx.saved_tensors
-        dy = _chk(dy)
-        B, H, W, C = x.shape
-        P = B * H * W
-        dev = x.device
-        dx = torch.empty_like(x)
-        sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
-        scratch = torch.empty(lib.query('bn_scratch_doubles', P, C), dtype=torch.float64, device=dev)
-        dg = db = None
-        if gamma is not None:
-            dg = torch.empty(C, dtype=torch.float32, device=dev)
-            db = torch.empty(C, dtype=torch.float32, device=dev)
-        lib('batchnorm_bwd', dy, C, x, C, mean, invstd, gamma, dx, dg, db, sums, scratch, P, C, ctx.training)
-        return dx, dg, db, None, None, None, None, None
+        dx, dg, db = _bn_backward(_chk(dy), x, mean, invstd, gamma, ctx.training)
+        return dx, dg, db, None, None, None, None, None, None
 
 
 class Pool3x3Fn(torch.autograd.Function):
@@ -307,23 +318,105 @@ class AvgPool7FlattenFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------ interpreter
-def batchnorm(bn, x):
-    """Run an nn.BatchNorm2d holder on an NHWC tensor through the HIP kernels (buffers updated in place)."""
+def _bn_args(bn):
+    """(gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps) of an nn.BatchNorm2d holder."""
     training = bn.training or not bn.track_running_stats
-    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
-    return BatchNormFn.apply(x, bn.weight if bn.affine else None, bn.bias if bn.affine else None, rm, rv, training,
-                             bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+    rm, rv, nbt = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if bn.track_running_stats else (None, None, None)
+    if bn.momentum is None:
+        raise NotImplementedError('BatchNorm2d(momentum=None) (cumulative average) in a DARTS op')
+    return (bn.weight if bn.affine else None, bn.bias if bn.affine else None, rm, rv, nbt, training, bn.momentum, bn.eps)
+
+
+def batchnorm(bn, x):
+    """Run an nn.BatchNorm2d holder on an NHWC tensor through the HIP kernels (buffers, including num_batches_tracked,
+    updated in place by the kernels)."""
+    return BatchNormFn.apply(x, *_bn_args(bn))
+
+
+class DwPwBnFn(torch.autograd.Function):
+    """One stage of sep_conv / dil_conv (operations.py:39-63): (ReLU ->) depthwise KxK -> 1x1 -> BatchNorm2d as ONE autograd
+    node: the same kernel launches as DwConvFn -> PwConvFn -> BatchNormFn, a third of their host work (the PC-DARTS path is
+    host-bound at small batch)."""
+
+    @staticmethod
+    def supported(x, w_dw, w_pw):
+        P = x.shape[0] * x.shape[1] * x.shape[2]            # >= the stage's output pixel count
+        Cout, Cin = w_pw.shape[0], w_pw.shape[1]
+        return bool(lib.query('pwconv_small_supported', P, Cout, Cin) and lib.query('pwconv_wgrad_small_supported', P, Cout, Cin))
+
+    @staticmethod
+    def forward(ctx, x, w_dw, w_pw, gamma, beta, run_mean, run_var, tracked, training, momentum, eps, stride, pad, dil, relu_in):
+        x, w_dw, w_pw = _chk(x), _chk(w_dw), _chk(w_pw)
+        B, H, W, C = x.shape
+        K = w_dw.shape[-1]
+        Ho = (H + 2 * pad - dil * (K - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (K - 1) - 1) // stride + 1
+        Cout = w_pw.shape[0]
+        P = B * Ho * Wo
+        y1 = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+        lib('dwconv_fwd', x, w_dw, y1, B, H, W, C, K, stride, pad, dil, int(relu_in))
+        y2 = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+        lib('pwconv_small', y1, w_pw, None, y2, P, Cout, C, 0, 0)
+        y3, mean, invstd = _bn_forward(y2, gamma, beta, run_mean, run_var, tracked, training, momentum, eps)
+        ctx.save_for_backward(x, w_dw, y1, w_pw, y2, mean, invstd, gamma)
+        ctx.cfg = (stride, pad, dil, int(relu_in), int(training))
+        return y3
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_dw, y1, w_pw, y2, mean, invstd, gamma = ctx.saved_tensors
+        stride, pad, dil, relu_in, training = ctx.cfg
+        need = ctx.needs_input_grad
+        B, H, W, C = x.shape
+        K = w_dw.shape[-1]
+        Cout = w_pw.shape[0]
+        P = y2.numel() // Cout
+        dev = x.device
+        d2, dg, db = _bn_backward(_chk(dy), y2, mean, invstd, gamma, training)
+        dw_pw = dw_dw = dx = None
+        if need[2]:
+            dw_pw = torch.empty_like(w_pw)
+            scratch = torch.empty(lib.query('pwconv_wgrad_small_scratch_elems', P, Cout, C), dtype=torch.float32, device=dev)
+            lib('pwconv_wgrad_small', d2, y1, dw_pw, scratch, P, Cout, C, 0)
+        if need[0] or need[1]:
+            d1 = torch.empty_like(y1)
+            lib('pwconv_small', d2, w_pw, None, d1, P, Cout, C, 0, 1)                   # dY . W
+            if need[1]:
+                dw_dw = torch.empty_like(w_dw)
+                n = lib.query('dwconv_bwd_weight_scratch_elems', B, H, W, C, K, stride, pad, dil)
+                scratch = torch.empty(n, dtype=torch.float32, device=dev)
+                lib('dwconv_bwd_weight', d1, x, dw_dw, scratch, B, H, W, C, K, stride, pad, dil, relu_in)
+            if need[0]:
+                dx = torch.empty_like(x)
+                lib('dwconv_bwd_input', d1, w_dw, x, dx, B, H, W, C, K, stride, pad, dil, relu_in)
+        return (dx, dw_dw, dw_pw, dg, db) + (None,) * 10
+
+
+def _is_depthwise(m):
+    return isinstance(m, nn.Conv2d) and m.bias is None and m.groups == m.in_channels == m.out_channels and m.kernel_size[0] > 1
+
+
+def _is_pointwise(m):
+    return isinstance(m, nn.Conv2d) and m.bias is None and m.kernel_size[0] == 1 and m.groups == 1 and m.stride[0] == 1
 
 
 def run_seq(seq, x):
     """Execute a reference-shaped Sequential (ReLU / Conv2d(depthwise or 1x1, bias=False) / BatchNorm2d /
     AvgPool2d(3) / MaxPool2d(3)) on an NHWC tensor.  A ReLU is fused into the convolution that follows it."""
     relu = False
-    for m in seq:
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        i += 1
         if isinstance(m, nn.ReLU):
             relu = True
+        elif (_is_depthwise(m) and i + 1 < len(mods) and _is_pointwise(mods[i]) and isinstance(mods[i + 1], nn.BatchNorm2d)
+              and DwPwBnFn.supported(x, m.weight, mods[i].weight)):
+            # (ReLU ->) depthwise -> 1x1 -> BN: one autograd node
+            x = DwPwBnFn.apply(x, m.weight, mods[i].weight, *_bn_args(mods[i + 1]), m.stride[0], m.padding[0], m.dilation[0], relu)
+            relu = False
+            i += 2
         elif isinstance(m, nn.Conv2d):
             if m.bias is not None:
                 raise NotImplementedError('conv bias in a DARTS op')
