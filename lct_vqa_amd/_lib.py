@@ -49,6 +49,7 @@ class _Lib:
         self._sigs = parse_header()
         self._fns = {}
         self._wants_stream = {}
+        self._memo = {}
 
     def load(self):
         if self._dll is not None:
@@ -77,8 +78,13 @@ class _Lib:
         return fn
 
     def query(self, name, *args):
-        """Call a value-returning entry point (no error convention, no stream)."""
-        return self.raw(name)(*args)
+        """Call a value-returning entry point (no error convention, no stream).  These are pure functions of their integer
+        arguments (sizes of scratch buffers, "is this shape supported"), asked again for every launch: memoised."""
+        key = (name, args)
+        hit = self._memo.get(key)
+        if hit is None:
+            hit = self._memo[key] = self.raw(name)(*args)
+        return hit
 
     def __call__(self, name, *args):
         """Call lctvqa_<name>; tensors are passed as device pointers; the current torch stream is

@@ -7,8 +7,22 @@ import ctypes
 import torch
 import torch.nn as nn
 
-from ._lib import lib
+from ._lib import lib, _current_raw_stream
 from .ops import _chk, _workspace, colsum  # noqa: F401
+
+
+_scratch_pool = {}
+
+
+def _scratch(n, dtype, dev):
+    """Scratch that lives only inside ONE C call (per-block partial sums a finish kernel of the same call consumes): one
+    growing buffer per (device, dtype, stream) instead of an allocation per launch.  Launches on a stream run in order, so the
+    next user overwrites it only after the previous one has finished with it."""
+    key = (dev.index, dtype, _current_raw_stream())
+    buf = _scratch_pool.get(key)
+    if buf is None or buf.numel() < n:
+        buf = _scratch_pool[key] = torch.empty(max(int(n), 1 << 16), dtype=dtype, device=dev)
+    return buf
 
 
 def _gemm_ex(A, a_ms, a_ks, Bm, b_ns, b_ks, M, N, K, relu_ab):
@@ -70,7 +84,7 @@ class DwConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             n = lib.query('dwconv_bwd_weight_scratch_elems', B, H, W, C, K, stride, pad, dil)
-            scratch = torch.empty(n, dtype=torch.float32, device=x.device)
+            scratch = _scratch(n, torch.float32, x.device)
             lib('dwconv_bwd_weight', dy, x, dw, scratch, B, H, W, C, K, stride, pad, dil, relu_in)
         return dx, dw, None, None, None, None
 
@@ -115,7 +129,7 @@ class PwConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if lib.query('pwconv_wgrad_small_supported', P, Cout, Cin):
                 dw = torch.empty_like(w)
-                scratch = torch.empty(lib.query('pwconv_wgrad_small_scratch_elems', P, Cout, Cin), dtype=torch.float32, device=x.device)
+                scratch = _scratch(lib.query('pwconv_wgrad_small_scratch_elems', P, Cout, Cin), torch.float32, x.device)
                 lib('pwconv_wgrad_small', dy, x, dw, scratch, P, Cout, Cin, int(ctx.relu_in))
             else:
                 dw = _gemm_ex(dy, 1, Cout, x, 1, Cin, Cout, Cin, P, 2 if ctx.relu_in else 0).reshape(w.shape)
@@ -131,7 +145,7 @@ def _bn_forward(x, gamma, beta, run_mean, run_var, tracked, training, momentum, 
     y = torch.empty_like(x)
     mean = torch.empty(C, dtype=torch.float32, device=dev)
     invstd = torch.empty(C, dtype=torch.float32, device=dev)
-    scratch = torch.empty(lib.query('bn_scratch_doubles', P, C), dtype=torch.float64, device=dev)
+    scratch = _scratch(lib.query('bn_scratch_doubles', P, C), torch.float64, dev)
     lib('batchnorm_fwd', x, C, y, C, P, C, gamma, beta, run_mean, run_var, tracked if training else None, mean, invstd, scratch,
         int(training), float(momentum), float(eps))
     return y, mean, invstd
@@ -142,8 +156,8 @@ def _bn_backward(dy, x, mean, invstd, gamma, training):
     P = x.numel() // C
     dev = x.device
     dx = torch.empty_like(x)
-    sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
-    scratch = torch.empty(lib.query('bn_scratch_doubles', P, C), dtype=torch.float64, device=dev)
+    sums = _scratch(2 * C, torch.float32, dev)
+    scratch = _scratch(lib.query('bn_scratch_doubles', P, C), torch.float64, dev)
     dg = db = None
     if gamma is not None:
         dg = torch.empty(C, dtype=torch.float32, device=dev)
@@ -265,7 +279,7 @@ class MixedCombineFn(torch.autograd.Function):
             dbr.append(g)
         dw = torch.zeros(max(len(branches), 1), dtype=torch.float32, device=dev)
         dbeta = torch.empty(1, dtype=torch.float32, device=dev)
-        scratch = torch.empty(lib.query('mixed_combine_scratch_elems', B, Ho, Wo), dtype=torch.float32, device=dev)
+        scratch = _scratch(lib.query('mixed_combine_scratch_elems', B, Ho, Wo), torch.float32, dev)
         lib('mixed_combine_bwd_scalars', dout, ldd, _ptr_array(branches), len(branches), wsel, beta, x, B, Ho, Wo, C,
             ctx.reduce, dw, dbeta, scratch)
         dw = dw[:len(branches)]
@@ -376,7 +390,7 @@ class DwPwBnFn(torch.autograd.Function):
         dw_pw = dw_dw = dx = None
         if need[2]:
             dw_pw = torch.empty_like(w_pw)
-            scratch = torch.empty(lib.query('pwconv_wgrad_small_scratch_elems', P, Cout, C), dtype=torch.float32, device=dev)
+            scratch = _scratch(lib.query('pwconv_wgrad_small_scratch_elems', P, Cout, C), torch.float32, dev)
             lib('pwconv_wgrad_small', d2, y1, dw_pw, scratch, P, Cout, C, 0)
         if need[0] or need[1]:
             d1 = torch.empty_like(y1)
@@ -384,12 +398,40 @@ class DwPwBnFn(torch.autograd.Function):
             if need[1]:
                 dw_dw = torch.empty_like(w_dw)
                 n = lib.query('dwconv_bwd_weight_scratch_elems', B, H, W, C, K, stride, pad, dil)
-                scratch = torch.empty(n, dtype=torch.float32, device=dev)
+                scratch = _scratch(n, torch.float32, dev)
                 lib('dwconv_bwd_weight', d1, x, dw_dw, scratch, B, H, W, C, K, stride, pad, dil, relu_in)
             if need[0]:
                 dx = torch.empty_like(x)
                 lib('dwconv_bwd_input', d1, w_dw, x, dx, B, H, W, C, K, stride, pad, dil, relu_in)
         return (dx, dw_dw, dw_pw, dg, db) + (None,) * 10
+
+
+class PoolBnFn(torch.autograd.Function):
+    """3x3 max / avg pool -> BatchNorm2d (the pooling branches of a MixedOp, model_search.py:35-37) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, tracked, training, momentum, eps, stride, kind):
+        x = _chk(x)
+        B, H, W, C = x.shape
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        y1 = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+        lib('pool3x3_fwd', x, y1, B, H, W, C, stride, kind)
+        y2, mean, invstd = _bn_forward(y1, gamma, beta, run_mean, run_var, tracked, training, momentum, eps)
+        ctx.save_for_backward(x, y1, mean, invstd, gamma)
+        ctx.cfg = (stride, kind, int(training))
+        return y2
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y1, mean, invstd, gamma = ctx.saved_tensors
+        stride, kind, training = ctx.cfg
+        B, H, W, C = x.shape
+        d1, dg, db = _bn_backward(_chk(dy), y1, mean, invstd, gamma, training)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            lib('pool3x3_bwd', d1, x, dx, B, H, W, C, stride, kind)
+        return (dx, dg, db) + (None,) * 8
 
 
 def _is_depthwise(m):
@@ -417,6 +459,10 @@ def run_seq(seq, x):
             x = DwPwBnFn.apply(x, m.weight, mods[i].weight, *_bn_args(mods[i + 1]), m.stride[0], m.padding[0], m.dilation[0], relu)
             relu = False
             i += 2
+        elif isinstance(m, (nn.AvgPool2d, nn.MaxPool2d)) and i < len(mods) and isinstance(mods[i], nn.BatchNorm2d):
+            stride = m.stride if isinstance(m.stride, int) else m.stride[0]
+            x = PoolBnFn.apply(x, *_bn_args(mods[i]), stride, 1 if isinstance(m, nn.AvgPool2d) else 0)
+            i += 1
         elif isinstance(m, nn.Conv2d):
             if m.bias is not None:
                 raise NotImplementedError('conv bias in a DARTS op')
