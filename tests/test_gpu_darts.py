@@ -215,3 +215,28 @@ def test_derived_network_from_searched_genotype_vs_oracle(D):
         sd = net.state_dict()
         for k, v in ns.items():
             assert rel_err(sd[k], v) < 1e-4, k
+
+
+def test_search_network_step_as_hip_graph(hip_lib):
+    """The C ABI only launches on the stream it is given, so a whole forward+backward of the search network can be captured
+    into one HIP graph (lct_vqa_amd.graph.Graphed) and replayed: same gradients as the eager step, bit for bit, also after
+    the parameters and the input have been changed in place (the graph reads them at replay time)."""
+    from lct_vqa_amd.basic_vqa import config
+    from lct_vqa_amd.basic_vqa.pcdarts.model_search import Network
+    from lct_vqa_amd.graph import Graphed
+    config.DEVICE = torch.device(DEV)
+    torch.manual_seed(3)
+    net = Network(16, 512, 4).to(DEV).train()
+    x = torch.randn(2, 3, 32, 32, device=DEV)
+    params = list(net.parameters()) + net.arch_parameters()
+    step = lambda: torch.autograd.grad(net(x).sum(), params)
+    g = Graphed(step)
+    for trial in range(2):
+        got = [t.clone() for t in g.replay()]
+        ref = step()
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        with torch.no_grad():                                   # move parameters and input in place, replay again
+            for p_ in params:
+                p_.add_(0.01 * torch.randn_like(p_))
+            x.copy_(torch.randn_like(x))

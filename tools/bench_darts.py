@@ -16,6 +16,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--iters', type=int, default=3)
+    ap.add_argument('--graph', action='store_true', help='also capture the encoder forward+backward into one HIP graph and time replays')
     ap.add_argument('--vqa', action='store_true', help='also time a darts_vqa weight step and an Architect step')
     args = ap.parse_args()
     from lct_vqa_amd.basic_vqa import config
@@ -34,8 +35,36 @@ def main():
     macs = 1408.9e6 * (args.size / 224.0) ** 2
     print(f'DARTS encoder fwd+bwd B={args.batch} {args.size}x{args.size}: {dt * 1e3:.1f} ms  '
           f'({args.batch / dt:.1f} img/s, ~{3 * 2 * macs * args.batch / dt / 1e12:.2f} TFLOP/s, peak mem {torch.cuda.max_memory_allocated() / 1e9:.1f} GB)')
+    if args.graph:
+        # the same forward+backward captured once into a HIP graph and replayed: no host work per launch
+        del out, g
+        params = list(net.parameters()) + net.arch_parameters()
+        step = lambda: torch.autograd.grad(net(x).sum(), params)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            ggrads = step()
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [t.clone() for t in ggrads]
+        ref = step()
+        err = max(((a - b).abs().max() / (b.abs().max() + 1e-30)).item() for a, b in zip(got, ref))
+        t0 = time.perf_counter()
+        for _ in range(args.iters):
+            graph.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.iters
+        print(f'  as one HIP graph: {dt * 1e3:.1f} ms per replay ({args.batch / dt:.1f} img/s), gradients vs eager max rel diff {err:.1e}')
     if args.vqa:
-        del net, out, g
+        if not args.graph:
+            del out, g
+        del net
         darts_vqa_step(args)
 
 
