@@ -178,12 +178,15 @@ def main():
         ef_red = parallel.FlatGradReducer(ef_opt.flat['params'], ef_opt.flat_grad, scale_fn=parallel.hip_scale) if world > 1 else None
         w_step = step
 
-        def step():  # noqa: F811
+        def step(convs=None):  # noqa: F811
             ef_opt.zero_grad()
             # the examiner's trunk is frozen (pretrained): stage 1's forward and stage 2's generate see the same images
             # through the same weights, so its convolutional part runs once per batch (--lct-no-share: twice, as the
             # reference's two calls do)
-            conv = ef.img_encoder.conv_features(img) if args.lct_share_trunk else None
+            if convs is not None:
+                conv, conv_w = convs
+            else:
+                conv, conv_w = (ef.img_encoder.conv_features(img) if args.lct_share_trunk else None), None
             l1 = ef._loss(img, qst, lab, conv)
             l1.backward()
             if ef_red is not None:
@@ -193,7 +196,7 @@ def main():
                 pq, pa = ef.generate(img, conv)
                 pa = ops.softmax_rows(pa, 1.0)
             opt.zero_grad()
-            l2 = model._soft_loss(img, qst, lab, pq, pa)
+            l2 = model._soft_loss(img, qst, lab, pq, pa, conv_w)
             l2.backward()
             if reducer is not None:
                 reducer.finish()
@@ -296,6 +299,44 @@ def main():
             st.synchronize()
         barrier()
         dt = time.perf_counter() - t0
+    elif args.workload == 'lct' and args.lct_share_trunk and not args.no_pipeline:
+        # Both trunks of the LCT step are frozen (examiner: pretrained, W: by construction), so their convolutional parts for
+        # batch i+1 run on a second HIP stream while stage 1 / generate / stage 2 of batch i run on the main stream -- the
+        # schedule of the W workload above.  Every timed step still contains both trunk passes and all the head work.
+        main_stream = torch.cuda.current_stream()
+        trunk_stream = torch.cuda.Stream()
+
+        def launch_convs():
+            trunk_stream.wait_stream(main_stream)
+            with torch.cuda.stream(trunk_stream):
+                cs = (ef.img_encoder.conv_features(img), model.img_encoder.conv_features(img))
+                ev = torch.cuda.Event()
+                ev.record(trunk_stream)
+            for c in cs:
+                c.record_stream(main_stream)
+            return cs, ev
+
+        def run_steps(k):
+            nxt = launch_convs()
+            out = None
+            for i in range(k):
+                cs, ev = nxt
+                if i + 1 < k:
+                    nxt = launch_convs()
+                main_stream.wait_event(ev)
+                out = step(cs)
+            return out
+
+        pipelined = True
+        if args.warmup:
+            run_steps(args.warmup)
+        ops.conv_timer_start()
+        barrier()
+        t0 = time.perf_counter()
+        loss = run_steps(args.steps)
+        trunk_stream.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
     else:
         for _ in range(args.warmup):
             step()
@@ -375,7 +416,7 @@ def main():
                                                      'shared by its two forwards)' if args.lct_share_trunk else
                                                   'per call for the examiner, once for W')),
                    'global_batch': world * B, 'seq_len': 14, 'parallelism': f'dp{world}',
-                   'schedule': ('trunk(i+1) || head(i) on two HIP streams' + (', head starts after conv layer %d of trunk(i+1)' % args.head_after if args.head_after else '')) if pipelined else 'single stream'},
+                   'schedule': ('trunk(i+1) || head(i) on two HIP streams' + (', head starts after conv layer %d of trunk(i+1)' % args.head_after if args.head_after and args.workload == 'w' else '')) if pipelined else 'single stream'},
         'loss': round(float(loss.item()), 5),
         'model_flops_per_step': 39.48e9 * B if args.workload == 'w' else None,
         'model_tflops': round(39.48e9 * B / (ms * 1e-3) / 1e12, 2) if args.workload == 'w' else None,

@@ -111,11 +111,12 @@ class VqaModel(nn.Module):
         ans_out = self(images, questions)
         return ops.cross_entropy(ans_out, labels)
 
-    def _soft_loss(self, images, questions, labels, pseudo_qst, pseudo_labels):
+    def _soft_loss(self, images, questions, labels, pseudo_qst, pseudo_labels, conv_feature=None):
         """reference models.py:118-125.  Both forwards see the same images through the same frozen trunk: its
         convolutional part (deterministic, 98 % of a forward) is evaluated once; the classifier with its two live
-        dropouts and everything after it run per forward, in the reference's order (so do the mask draws)."""
-        conv = self.img_encoder.conv_features(images)
+        dropouts and everything after it run per forward, in the reference's order (so do the mask draws).  A driver that
+        has already evaluated it for this batch (on another stream, say) passes it as ``conv_feature``."""
+        conv = conv_feature if conv_feature is not None else self.img_encoder.conv_features(images)
         ans_out_1 = self(images, questions, conv_feature=conv)
         loss_1 = ops.cross_entropy(ans_out_1, labels)
         ans_out_2 = self(images, pseudo_qst, conv_feature=conv)
