@@ -46,7 +46,10 @@ def test_w_small_against_reference_goldens(pkg):
     m.eval()
     with torch.no_grad():
         sl = m._soft_loss(img, qst, lab, fx['pseudo_qst'].to(DEV), fx['pseudo_label'].to(DEV))
-    assert rel_err(sl, fx['soft_loss']) < 1e-4
+        # the same with the frozen trunk's conv features evaluated by the caller (bench.py --workload lct runs them on
+        # a second stream)
+        sl2 = m._soft_loss(img, qst, lab, fx['pseudo_qst'].to(DEV), fx['pseudo_label'].to(DEV), m.img_encoder.conv_features(img))
+    assert rel_err(sl, fx['soft_loss']) < 1e-4 and torch.equal(sl, sl2)
 
 
 def test_ef_small_against_reference_goldens(pkg):
