@@ -5,7 +5,7 @@ ResNet-152 is NOT built (the image encoder of these classes is the VGG19 trunk).
 import torch.nn as nn
 
 from .. import ops
-from .models import ImgEncoder, VqaModel
+from .models import VqaModel
 
 
 class QstEncoderGRU(nn.Module):

@@ -5,7 +5,7 @@ import types
 import pytest
 import torch
 
-from _util import load, rel_err, vgg_params_from_seed
+from _util import load, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'

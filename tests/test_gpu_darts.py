@@ -96,7 +96,7 @@ def test_pool3x3(D, stride, kind):
 def test_factorized_reduce_and_mixed_op(D, hip_lib):
     from lct_vqa_amd.basic_vqa import config
     config.DEVICE = torch.device(DEV)
-    from lct_vqa_amd.basic_vqa.pcdarts import operations as OP, model_search as MS
+    from lct_vqa_amd.basic_vqa.pcdarts import model_search as MS
     from oracle import darts_oracle as DO
     torch.manual_seed(4)
     for stride in (1, 2):

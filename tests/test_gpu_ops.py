@@ -199,7 +199,6 @@ def test_gemm_epilogue_and_autograd(ops):
 
 
 def test_lstm_embed_fwd_bwd(ops):
-    from oracle import vqa_oracle as O
     torch.manual_seed(4)
     B, T, We, H, V = 5, 7, 12, 16, 30
     lstm = torch.nn.LSTM(We, H, 1)

@@ -5,7 +5,6 @@
 import argparse
 import ctypes
 import os
-import sys
 
 import torch
 

@@ -72,7 +72,6 @@ def darts_vqa_step(args):
     """BASELINE configs[4] in fp32 on one GPU: darts_vqa VqaModel(img_encoder_type='darts') weight step
     (CE(ans) + CE(qst), clip, Adam) and the 2-level Architect.step that the driver runs beside it."""
     import types
-    from lct_vqa_amd import ops
     from lct_vqa_amd.darts_vqa import config as dconfig, factory
     from lct_vqa_amd.basic_vqa import config as bconfig
     dconfig.DEVICE = bconfig.DEVICE = torch.device('cuda')

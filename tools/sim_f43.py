@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Numerical feasibility of Winograd F(4x4,3x3) in fp32 (CPU simulation with explicit fp32 transforms): single-layer
 error against an fp64 direct convolution, for the trunk's layer shapes and activation statistics."""
-import sys
 import torch
 import torch.nn.functional as F
 torch.manual_seed(0)
