@@ -138,6 +138,13 @@ int lctvqa_lstm_seq_fwd(const float* xp, const float* w_hh, const float* b_hh, f
                         float* wpack, int T, int B, int H, void* stream);
 int lctvqa_lstm_seq_bwd(float* dgates, const float* w_hh, const float* dout, const float* gates, const float* c_all,
                         float* dc_buf, float* wpack, int T, int B, int H, void* stream);
+/* greedy question generation (models_lct.py:124-157, darts_vqa/vqa_model.py:190-222) as one call: x_0 = tanh(emb[start]),
+ * x_t = emb[pred_{t-1}]; (h,c) = LSTM step; pred_t = argmax(fc(tanh(h))).  h, c [B][H] in/out; tokens [B][L] int64 out;
+ * scratch: lctvqa_lstm_decode_scratch_elems(B,H,We,QV) floats */
+long lctvqa_lstm_decode_scratch_elems(int B, int H, int We, int QV);
+int lctvqa_lstm_decode_greedy(const float* emb, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                              const float* fc_w, const float* fc_b, float* h, float* c, long* tokens, long start_token, int L,
+                              int B, int H, int We, int QV, float* scratch, void* stream);
 /* GRU cell (nn.GRU, gates r,z,n): the "LSTM/GRU" question-encoder variant of BASELINE.json (not in the reference;
  * oracle = torch.nn.GRU).  xp/hp: [B][3H] projections incl. their biases; saved [B][4H] = r,z,n,hp_n */
 int lctvqa_gru_cell_fwd(const float* xp, const float* hp, const float* h_prev, float* saved, float* h_out, int B, int H,

@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops, vgg
+from .._lib import lib
 from . import config as _config
 from .models import VqaModel as WModel, softXEnt, _single_layer  # noqa: F401
 
@@ -89,6 +90,10 @@ class QstEncoder(nn.Module):
         dev = image_embedding.device
         h = image_embedding.reshape(B, self.hidden_size)
         c = h
+        if self.deterministic and lib.query('lstm_step_fused_supported', B, self.hidden_size):
+            # greedy decoding: the whole token loop in one C call (same kernels, identical token ids)
+            return ops.lstm_decode_greedy(self.word2vec.weight, *_single_layer(self.lstm), self.fc2.weight, self.fc2.bias,
+                                          h, c, self.max_length, start_token=2)
         start_word = torch.full((B, 1), 2, dtype=torch.long, device=dev)
         current_word = ops.embed(start_word, self.word2vec.weight, True)      # [1,B,We]
         qst_out = torch.zeros((B, self.max_length), dtype=torch.long, device=dev)

@@ -1026,6 +1026,97 @@ extern "C" int lctvqa_lstm_seq_bwd(float* dgates, const float* w_hh, const float
 }
 
 // ------------------------------------------------------------------------------------------
+// Greedy question generation (reference models_lct.py:124-157, darts_vqa/vqa_model.py:190-222): L dependent tokens,
+//   x_0 = tanh(emb[<start>]),  x_t = emb[pred_{t-1}] (no tanh);  (h,c) = LSTM(x_t, (h,c));  pred_t = argmax(fc(tanh(h)))
+// as ONE C call: W_hh is packed once, then 7 launches per token (gather, input projection, recurrent step, tanh, token-head
+// GEMM, argmax, token store) are issued back to back with no host work between them -- the Python loop it replaces spends
+// ~8 autograd/ctypes round trips (~100 us) per token on ~70 us of kernels.  Same kernels and GEMM configurations as the
+// per-token path, so the token ids are identical.
+// ------------------------------------------------------------------------------------------
+__global__ void fill_long_kernel(long* __restrict__ p, long v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void store_tokens_kernel(const long* __restrict__ idx, long* __restrict__ out, int B, int L, int t) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) out[(long)b * L + t] = idx[b];
+}
+
+extern "C" long lctvqa_gemm_workspace_bytes(int M, int N, int K);
+extern "C" int lctvqa_gemm_f32(const float* A, long a_ms, long a_ks, const float* B, long b_ns, long b_ks, float* C, long ldc, int M,
+                               int N, int K, const float* bias, const float* addend, long ld_add, int act, const uint8_t* mask,
+                               long ld_mask, float mask_scale, float* workspace, long workspace_bytes, void* stream);
+
+static long decode_ws_bytes(int B, int H, int We, int QV) {
+  const long a = lctvqa_gemm_workspace_bytes(B, 4 * H, We), b = lctvqa_gemm_workspace_bytes(B, QV, H);
+  return ((a > b ? a : b) + 15) & ~15L;
+}
+// floats of scratch for lctvqa_lstm_decode_greedy
+extern "C" long lctvqa_lstm_decode_scratch_elems(int B, int H, int We, int QV) {
+  const long BH = (long)B * H;
+  return 4L * H * H + (long)B * We + 8L * BH + 2 * BH + BH + (long)B * QV + 2L * B + 64 + decode_ws_bytes(B, H, We, QV) / 4;
+}
+
+// h, c: [B][H] in/out (initial state -> state after the last token); tokens [B][L] int64 out; emb [QV][We]; token head
+// fc_w [QV][H], fc_b [QV]; gate order and weight shapes of nn.LSTM (w_ih [4H][We], w_hh [4H][H]).
+extern "C" int lctvqa_lstm_decode_greedy(const float* emb, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                                         const float* fc_w, const float* fc_b, float* h, float* c, long* tokens, long start_token,
+                                         int L, int B, int H, int We, int QV, float* scratch, void* stream) {
+  LCT_REQUIRE(L >= 1 && B >= 1 && lctvqa_lstm_step_fused_supported(B, H), "lstm_decode_greedy: need L, B >= 1 and H %% 32 == 0 (H=%d)", H);
+  LCT_REQUIRE((((uintptr_t)scratch | (uintptr_t)h | (uintptr_t)w_hh) & 15) == 0, "lstm_decode_greedy: scratch / h / w_hh must be 16-B aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const long BH = (long)B * H;
+  float* wpack = scratch;
+  float* xcur = wpack + 4L * H * H;
+  float* xp = xcur + (((long)B * We + 3) & ~3L);
+  float* gates = xp + 4 * BH;
+  float* hn = gates + 4 * BH;
+  float* cn = hn + BH;
+  float* tout = cn + BH;
+  float* logits = tout + BH;
+  long* idx = (long*)(logits + (((long)B * QV + 3) & ~3L));
+  float* ws = (float*)(idx + B + (B & 1));
+  ws = (float*)(((uintptr_t)ws + 15) & ~(uintptr_t)15);
+  const long ws_bytes = decode_ws_bytes(B, H, We, QV);
+  const bool packed = lctvqa_lstm_seq_packed(B, H);
+  if (packed) hipLaunchKernelGGL(lstm_pack_whh_fwd_kernel, dim3(cdiv((long)H * H, 256)), dim3(256), 0, st, w_hh, wpack, H);
+  hipLaunchKernelGGL(fill_long_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, idx, start_token, B);
+  float *hc = h, *cc = c, *hx = hn, *cx = cn;
+  const dim3 sgrid(cdiv(B, 32) * (H / 16));
+  for (int t = 0; t < L; t++) {
+    int rc = lctvqa_embed_gather(idx, emb, xcur, B, 1, We, QV, t == 0 ? 1 : 0, stream);
+    if (rc) return rc;
+    rc = lctvqa_gemm_f32(xcur, We, 1, w_ih, We, 1, xp, 4L * H, B, 4 * H, We, b_ih, nullptr, 0, 0, nullptr, 0, 1.f, ws, ws_bytes, stream);
+    if (rc) return rc;
+    if (packed) {
+      switch (H) {
+        case 64: hipLaunchKernelGGL(lstm_step2_kernel<1>, sgrid, dim3(256), 0, st, xp, hc, cc, wpack, b_hh, gates, cx, hx, B); break;
+        case 128: hipLaunchKernelGGL(lstm_step2_kernel<2>, sgrid, dim3(256), 0, st, xp, hc, cc, wpack, b_hh, gates, cx, hx, B); break;
+        case 256: hipLaunchKernelGGL(lstm_step2_kernel<4>, sgrid, dim3(256), 0, st, xp, hc, cc, wpack, b_hh, gates, cx, hx, B); break;
+        default: hipLaunchKernelGGL(lstm_step2_kernel<8>, sgrid, dim3(256), 0, st, xp, hc, cc, wpack, b_hh, gates, cx, hx, B); break;
+      }
+    } else {
+      rc = lctvqa_lstm_step_fused(xp, hc, cc, w_hh, b_hh, gates, cx, hx, B, H, stream);
+      if (rc) return rc;
+    }
+    rc = lctvqa_tanh_fwd(hx, tout, BH, stream);
+    if (rc) return rc;
+    rc = lctvqa_gemm_f32(tout, H, 1, fc_w, H, 1, logits, QV, B, QV, H, fc_b, nullptr, 0, 0, nullptr, 0, 1.f, ws, ws_bytes, stream);
+    if (rc) return rc;
+    rc = lctvqa_argmax_rows(logits, QV, B, QV, idx, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(store_tokens_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, idx, tokens, B, L, t);
+    float* tp = hc; hc = hx; hx = tp;
+    tp = cc; cc = cx; cx = tp;
+  }
+  if (hc != h) {                                        // odd number of tokens: the final state sits in the scratch halves
+    hipMemcpyAsync(h, hc, BH * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(c, cc, BH * sizeof(float), hipMemcpyDeviceToDevice, st);
+  }
+  return lct_check_launch("lstm_decode_greedy");
+}
+
+// ------------------------------------------------------------------------------------------
 // Input pipeline, device side (reference basic_vqa/data_loader_v2.py:53-55,82-86: PIL fromarray -> ToTensor ->
 // Normalize(mean,std) per sample on the host): the uint8 HWC image store rows are copied to HBM as they are
 // (3 B/pixel over PCIe instead of 12) and converted here:  y[n][c][h][w] = (x[n][h][w][c]/255 - mean[c]) / std[c]

@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops, vgg
+from .._lib import lib
 from ..basic_vqa.models import VqaModel as _WModel, _single_layer
 from ..basic_vqa.pcdarts.model_search import Network
 from . import config as _config
@@ -73,6 +74,10 @@ class QstEncoderBase(nn.Module):
         dev = image_embedding.device
         h = image_embedding.reshape(B, self.hidden_size)
         c = h
+        if self.deterministic and lib.query('lstm_step_fused_supported', B, self.hidden_size):
+            # greedy decoding: the whole token loop in one C call (same kernels, identical token ids); fc1 is the token head here
+            return ops.lstm_decode_greedy(self.word2vec.weight, *_single_layer(self.lstm), self.fc1.weight, self.fc1.bias,
+                                          h, c, self.max_length, start_token=2)
         start_word = torch.full((B, 1), 2, dtype=torch.long, device=dev)
         current_word = ops.embed(start_word, self.word2vec.weight, True)
         qst_out = torch.zeros((B, self.max_length), dtype=torch.long, device=dev)

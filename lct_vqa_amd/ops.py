@@ -291,6 +291,24 @@ def lstm(x, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None):
     return LSTMFn.apply(x, w_ih, w_hh, b_ih, b_hh, h0, c0)
 
 
+def lstm_decode_greedy(emb_weight, w_ih, w_hh, b_ih, b_hh, fc_weight, fc_bias, h0, c0, length, start_token=2):
+    """Greedy question generation of the LCT examiner (reference models_lct.py:124-157) in ONE C call: returns int64 token ids
+    [B, length].  x_0 = tanh(emb[start]), x_t = emb[pred_{t-1}] (no tanh), (h, c) start at (h0, c0) [B,H]; pred_t =
+    argmax(fc(tanh(h_t))).  No autograd: token ids carry no gradient (the reference's ``generate`` output is integer too)."""
+    with torch.no_grad():
+        emb_weight, w_ih, w_hh, fc_weight = _chk(emb_weight), _chk(w_ih), _chk(w_hh), _chk(fc_weight)
+        B, H = h0.shape[-2], h0.shape[-1]
+        QV, We = emb_weight.shape
+        dev = h0.device
+        h = _chk(h0).reshape(B, H).clone()
+        c = _chk(c0).reshape(B, H).clone()
+        tokens = torch.empty((B, length), dtype=torch.long, device=dev)
+        scratch = torch.empty(lib.query('lstm_decode_scratch_elems', B, H, We, QV), dtype=torch.float32, device=dev)
+        lib('lstm_decode_greedy', emb_weight, w_ih, w_hh, b_ih, b_hh, fc_weight, fc_bias, h, c, tokens, int(start_token), int(length),
+            B, H, We, QV, scratch)
+    return tokens
+
+
 class GRUFn(torch.autograd.Function):
     """Single-layer nn.GRU over [T,B,I] (gate order r,z,n): the GRU question-encoder variant named by BASELINE.json
     (the reference itself only has nn.LSTM).  Returns (out [T,B,H], h_T [B,H])."""

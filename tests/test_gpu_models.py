@@ -275,3 +275,30 @@ def test_ragged_and_empty_batches(pkg):
             assert rel_err(m(img[:B].contiguous(), qst[:B].contiguous()), full[:B]) < 1e-5
         with pytest.raises(RuntimeError):
             m(img[:0].contiguous(), qst[:0].contiguous())
+
+
+@pytest.mark.parametrize('H,We,QV,B,L', [(512, 300, 1000, 37, 9), (32, 16, 50, 5, 14), (64, 20, 77, 33, 6)])
+def test_greedy_decode_in_c_equals_the_token_loop(pkg, H, We, QV, B, L):
+    """lctvqa_lstm_decode_greedy (one C call for the whole generate loop) against the per-token path it replaces
+    (embed -> lstm -> tanh -> token head -> argmax through the autograd wrappers): identical token ids."""
+    ops, _, models_lct, config = pkg
+    config.ARCH_TYPE = 'fixed'
+    torch.manual_seed(H + L)
+    enc = models_lct.QstEncoder(QV, We, H, 1, H).to(DEV).eval()
+    enc.max_length = L
+    feat = torch.randn(B, H, device=DEV) * 0.5
+    with torch.no_grad():
+        enc.deterministic = True
+        fast = enc.generate(feat)
+        # the loop: force the fallback branch by asking the stochastic path for its deterministic sampler
+        h = c = feat
+        word = ops.embed(torch.full((B, 1), 2, dtype=torch.long, device=DEV), enc.word2vec.weight, True)
+        params = (enc.lstm.weight_ih_l0, enc.lstm.weight_hh_l0, enc.lstm.bias_ih_l0, enc.lstm.bias_hh_l0)
+        slow = torch.zeros(B, L, dtype=torch.long, device=DEV)
+        for t in range(L):
+            out, h, c = ops.lstm(word, *params, h, c)
+            pred = ops.argmax_rows(ops.linear(ops.TanhFn.apply(out), enc.fc2.weight, enc.fc2.bias).reshape(B, -1)).reshape(B, 1)
+            word = ops.embed(pred, enc.word2vec.weight, False)
+            slow[:, t] = pred[:, 0]
+    assert fast.dtype == torch.long and tuple(fast.shape) == (B, L)
+    assert torch.equal(fast, slow)
