@@ -15,6 +15,7 @@ class Architect(object):
         cfg = _config.active()
         self.model = model
         self.optimizer = bilevel.arch_optimizer(model.arch_parameters(), cfg.ARCH_LEARNING_RATE, cfg.ARCH_WEIGHT_DECAY)
+        self.trace = None      # set to a dict to have the next step leave its intermediates there (parity tests)
 
     def step(self, img_train, qst_train, label_train, img_valid, qst_valid, label_valid, eta=None,
              network_optimizer=None, unrolled=True):
@@ -42,4 +43,6 @@ class Architect(object):
         dalpha, v = g[:len(ahead_alphas)], g[len(ahead_alphas):]
         implicit = bilevel.fd_grad(weights, v, lambda: bilevel.grads(model._loss(img_train, qst_train, label_train),
                                                                     model.arch_parameters()))
+        if self.trace is not None:
+            self.trace.update(dalpha_direct=dalpha, v=v, implicit=implicit)
         return [d - eta * i for d, i in zip(dalpha, implicit)]

@@ -27,6 +27,7 @@ class ArchitectLct(object):
         self.ef_model, self.w_model = ef_model, w_model
         self.ef_optimizer, self.w_optimizer = ef_optimizer, w_optimizer
         self.optimizer = bilevel.arch_optimizer(ef_model.arch_parameters(), cfg.ARCH_LEARNING_RATE, cfg.ARCH_WEIGHT_DECAY)
+        self.trace = None      # set to a dict to have the next step leave its intermediates there (parity tests)
 
     def step(self, img_train, qst_train, label_train, img_valid, qst_valid, label_valid, ef_lr, w_lr):
         for opt in (self.ef_optimizer, self.w_optimizer, self.optimizer):
@@ -58,6 +59,9 @@ class ArchitectLct(object):
 
         val_loss = w_ahead._loss(img_valid, qst_valid, label_valid)
         v = bilevel.grads(val_loss, w_ahead.parameters(), self.W_FROZEN)
+        if self.trace is not None:
+            self.trace.update(ef_ahead=ef_ahead, w_ahead=w_ahead, pseudo_qst=pseudo_qst, pseudo_ans=pseudo_ans.detach(),
+                              val_loss=val_loss.detach(), grad_wprime=v)
 
         def soft_loss_grad_wrt_examiner():
             q, a = self._tests(ef_ahead, img_train)                  # regenerated: the probes move W, not EF'
@@ -66,4 +70,6 @@ class ArchitectLct(object):
         kappa = bilevel.fd_grad(w_weights, v, soft_loss_grad_wrt_examiner)
         gamma = bilevel.fd_grad(ef_weights, kappa,
                                 lambda: bilevel.grads(ef._loss(img_train, qst_train, label_train), ef.arch_parameters(), 0))
+        if self.trace is not None:
+            self.trace.update(kappa=kappa, gamma=gamma)
         return gamma, val_loss

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Golden vectors of the DARTS-encoder models and of the architect steps, produced by RUNNING the reference's own
 classes on CPU.   python tests/make_golden_arch.py basic|darts
-  basic: basic_vqa models_lct.VqaModel(ARCH_TYPE='darts') forward/loss/grads + ArchitectLct.step (3-level)
+  basic: basic_vqa models_lct.VqaModel(ARCH_TYPE='darts') forward/loss/grads + ArchitectLct.step (3-level), with every
+         intermediate of the step recorded (EF' / W' parameters, the generated tests, the validation loss, grad_wprime,
+         kappa, gamma), gamma also at r = 3e-2 and from a float64 run of the same reference code (what the step computes
+         without fp32 finite-difference noise: the tolerance of the GPU test is derived from those three)
+  basic2: the 2-level basic_vqa pcdarts.architect.Architect (unrolled and first-order) on the same EF model
   darts: darts_vqa vqa_model.VqaModel('darts') forward/loss/grads + pcdarts.architect_vqa.Architect.step
 nn.Dropout is neutralised for this run by patching torch.nn.functional.dropout to the identity (the architects build
 fresh models with ``new()`` whose Dropout holders are in training mode, and the CPU Bernoulli stream cannot be replayed
@@ -47,50 +51,237 @@ def data(seed, B, QV, A):
     return img, qst, lab
 
 
+def build_pair(models, models_lct, dims, dtype=torch.float32):
+    """EF (darts encoder) and W as the fixtures define them: seeds 10 / 20, architecture parameters 0.3 * N(0,1) from
+    seed 12.  For float64 the SAME float32 initial values are cast up."""
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(10)
+    ef = models_lct.VqaModel(**dims)
+    torch.manual_seed(12)
+    for a in ef.arch_parameters():
+        a.data.copy_(torch.randn_like(a) * 0.3)
+    torch.manual_seed(20)
+    w = models.VqaModel(**dims)
+    if dtype == torch.float64:
+        torch.set_default_dtype(torch.float64)           # new() inside the architect must build float64 twins
+        ef64, w64 = models_lct.VqaModel(**dims), models.VqaModel(**dims)
+        ef64.load_state_dict(ef.state_dict()); w64.load_state_dict(w.state_dict())
+        for a, b in zip(ef64.arch_parameters(), ef.arch_parameters()):
+            a.data.copy_(b)
+        ef, w = ef64, w64
+    no_dropout(ef.train()); no_dropout(w.train())
+    ef.qst_encoder.max_length = 6
+    return ef, w
+
+
+def named_small(model, tensors):
+    return {n: t.detach().clone().float() for (n, _), t in zip(model.named_parameters(), tensors) if '.model.' not in n}
+
+
+def basic_lct(config, models, models_lct, dims):
+    from pcdarts.architect_lct import ArchitectLct
+
+    class Traced(ArchitectLct):
+        """The reference's architect with every hand-over between its stages recorded (nothing is re-implemented)."""
+        r = 1e-2
+
+        def _compute_unrolled_model(self, *a, **k):
+            m = super()._compute_unrolled_model(*a, **k)
+            self.tr['ef_ahead'] = m
+            return m
+
+        def _compute_unrolled_model_2(self, img, qst, label, pseudo_qst, pseudo_label, *a, **k):
+            self.tr['pseudo_qst'], self.tr['pseudo_ans'] = pseudo_qst.clone(), pseudo_label.detach().clone().float()
+            m = super()._compute_unrolled_model_2(img, qst, label, pseudo_qst, pseudo_label, *a, **k)
+            self.tr['w_ahead'] = m
+            inner = m._loss
+
+            def recording_loss(*aa):
+                out = inner(*aa)
+                self.tr['val_loss'] = out.detach().clone().float()
+                return out
+            m._loss = recording_loss
+            return m
+
+        def _hessian_vector_product_2(self, vector, *a, **k):
+            self.tr['grad_wprime'] = named_small(self.w_model, vector)
+            out = super()._hessian_vector_product_2(vector, *a, r=self.r, **k)
+            self.tr['kappa'] = named_small(self.ef_model, out)
+            return out
+
+        def _hessian_vector_product(self, vector, *a, **k):
+            out = super()._hessian_vector_product(vector, *a, r=self.r, **k)
+            self.tr['gamma'] = [g.detach().clone().float() for g in out]
+            return out
+
+    img, qst, lab = data(30, 2, 50, 40)
+    vimg, vqst, vlab = data(31, 2, 50, 40)
+    ef, w = build_pair(models, models_lct, dims)
+    out = {'dims': dims, 'ef_seed': 10, 'w_seed': 20, 'ef_state': small(ef.state_dict()), 'w_state': small(w.state_dict()),
+           'arch': [a.detach().clone() for a in ef.arch_parameters()], 'max_length': 6,
+           'train': (img, qst, lab), 'valid': (vimg, vqst, vlab)}
+    loss = ef._loss(img, qst, lab)
+    ps = dict(ef.named_parameters())
+    names = ['img_encoder.fc.weight', 'img_encoder.darts.stem.0.weight', 'img_encoder.darts.cells.1._ops.2._ops.6.op.1.weight',
+             'qst_encoder.fc2.weight', 'qst_encoder.lstm.weight_hh_l0', 'fc2.weight']
+    grads = torch.autograd.grad(loss, list(ef.arch_parameters()) + [ps[n] for n in names])
+    out.update(ef_loss=loss.detach(), ef_arch_grads=[g.clone() for g in grads[:4]],
+               ef_param_grads={n: g.clone() for n, g in zip(names, grads[4:])})
+    # the forward above updated the BN running statistics: record what changed (the state the architect starts from)
+    after = small(ef.state_dict())
+    out['ef_state_before_step'] = {k: v for k, v in after.items() if not torch.equal(v, out['ef_state'][k])}
+    start = {k: v.clone() for k, v in ef.state_dict().items()}
+    w_start = {k: v.clone() for k, v in w.state_dict().items()}
+
+    def run(ef, w, r, dt):
+        ef.load_state_dict(start)
+        w.load_state_dict(w_start)
+        arch = Traced(ef, w, torch.optim.Adam(ef.parameters(), lr=1e-3), torch.optim.Adam(w.parameters(), lr=1e-3))
+        arch.tr, arch.r = {}, r
+        arch.optimizer.zero_grad()
+        c = lambda t: t.to(dt) if t.is_floating_point() else t
+        arch._backward_step_unrolled(c(img), qst, lab, c(vimg), vqst, vlab, 1e-3, 1e-3)
+        return arch
+
+    arch = run(ef, w, 1e-2, torch.float32)
+    tr = arch.tr
+    ef_ahead, w_ahead = tr.pop('ef_ahead'), tr.pop('w_ahead')
+    pick = ['img_encoder.fc.weight', 'img_encoder.darts.stem.0.weight', 'qst_encoder.lstm.weight_hh_l0', 'fc2.weight']
+    out['lct'] = dict(tr, ef_ahead={n: dict(ef_ahead.named_parameters())[n].detach().clone() for n in pick},
+                      w_ahead={n: p.detach().clone() for n, p in w_ahead.named_parameters() if '.model.' not in n})
+    out['lct_arch_grads'] = [a.grad.detach().clone() for a in ef.arch_parameters()]
+    arch.optimizer.step()
+    out['lct_arch_after'] = [a.detach().clone() for a in ef.arch_parameters()]
+    # the same step with the architecture weight decay off: alpha_after - alpha_before then depends on gamma alone
+    for a, r0 in zip(ef.arch_parameters(), out['arch']):
+        a.data.copy_(r0)
+    config.ARCH_WEIGHT_DECAY = 0.0
+    arch0 = run(ef, w, 1e-2, torch.float32)
+    arch0.optimizer.step()
+    out['lct_arch_after_nowd'] = [a.detach().clone() for a in ef.arch_parameters()]
+    config.ARCH_WEIGHT_DECAY = 1e-3
+    for a, r0 in zip(ef.arch_parameters(), out['arch']):
+        a.data.copy_(r0)
+    # is the reference stable at this probe point (see basic_two_level)?  gamma at r * (1 + k * 1e-6) against r
+    spread = max(float((a - b).abs().max() / b.abs().max())
+                 for k in (-3, -1, 1, 3) for a, b in zip(run(ef, w, 1e-2 * (1 + k * 1e-6), torch.float32).tr['gamma'], tr['gamma']))
+    print('spread of the reference gamma under r * (1 +- 3e-6):', spread)
+    assert spread < 5e-4, 'unstable probe point: choose other batches'
+    out['lct_gamma_self_spread'] = spread
+    # how much of gamma is finite-difference noise: the same reference code at r = 3e-2, and in float64 at both r
+    out['lct_gamma_r3'] = run(ef, w, 3e-2, torch.float32).tr['gamma']
+    ef64, w64 = build_pair(models, models_lct, dims, torch.float64)
+    start = {k: v.double() if v.is_floating_point() else v for k, v in start.items()}
+    a64 = run(ef64, w64, 1e-2, torch.float64)
+    assert torch.equal(a64.tr['pseudo_qst'], tr['pseudo_qst'])
+    out['lct_f64'] = {k: a64.tr[k] for k in ('val_loss', 'grad_wprime', 'gamma')}
+    k64, k32 = a64.tr['kappa'], tr['kappa']
+    den = sum(float(t.double().pow(2).sum()) for t in k64.values())
+    out['lct_f64']['kappa_f32_rel_l2'] = (sum(float((k32[n].double() - t.double()).pow(2).sum()) for n, t in k64.items()) / den) ** 0.5
+    out['lct_f64']['kappa_f32_worst_tensor'] = max(float((k32[n] - t).abs().max() / t.abs().max()) for n, t in k64.items() if t.abs().max() > 0)
+    out['lct_f64']['gamma_r3'] = run(ef64, w64, 3e-2, torch.float64).tr['gamma']
+    torch.set_default_dtype(torch.float32)
+    torch.save(out, os.path.join(GOLD, 'arch_lct.pt'))
+    rel = lambda a, b: max(float((x - y).abs().max() / y.abs().max()) for x, y in zip(a, b))
+    g32, g64 = tr['gamma'], out['lct_f64']['gamma']
+    print('gamma abs max', [float(g.abs().max()) for g in g32])
+    print('gamma f32 r=1e-2 vs f64 r=1e-2 (rel to max)', rel(g32, g64))
+    print('gamma f32 r=3e-2 vs f64 r=1e-2', rel(out['lct_gamma_r3'], g64))
+    print('gamma f64 r=3e-2 vs f64 r=1e-2 (truncation)', rel(out['lct_f64']['gamma_r3'], g64))
+    print('kappa f32 vs f64: rel L2', out['lct_f64']['kappa_f32_rel_l2'], 'worst tensor', out['lct_f64']['kappa_f32_worst_tensor'])
+    print('grad_wprime f32 vs f64', max(float((tr['grad_wprime'][n] - out['lct_f64']['grad_wprime'][n]).abs().max() / out['lct_f64']['grad_wprime'][n].abs().max())
+                                        for n in tr['grad_wprime']))
+
+
+def basic_two_level(config, models, models_lct, dims):
+    """reference basic_vqa/pcdarts/architect.py:12-109 on the EF model (architect_factory.py:11-12: SKIP_STAGE2).  Its
+    _construct_model_from_theta ends in ``.cuda()`` (:92); for this CPU run nn.Module.cuda is the identity."""
+    from pcdarts.architect import Architect
+    torch.nn.Module.cuda = lambda self, device=None: self
+    ef, _ = build_pair(models, models_lct, dims)
+    start = {k: v.clone() for k, v in ef.state_dict().items()}
+    # A finite difference of a gradient of a ReLU / max-pool network is a discontinuous function of the probe point:
+    # when one decision element sits on its boundary at theta + R v, rounding decides between two answers that differ by
+    # percents (seen with the batches of seeds 30/31: the reference's own result flips with r * (1 +- 1e-6)).  A golden
+    # is only meaningful where the reference agrees with itself, so take the first pair of batches for which its
+    # Hessian-vector product is the same at r * (1 + k * 1e-6), k = -4 ... 4.
+    for seed in range(30, 60, 2):
+        img, qst, lab = data(seed, 2, 50, 40)
+        vimg, vqst, vlab = data(seed + 1, 2, 50, 40)
+        ef.load_state_dict(start)
+        ef.zero_grad()
+        probe = Architect(ef)
+        unrolled = probe._compute_unrolled_model(img, qst, lab, 1e-3, None)
+        unrolled._loss(vimg, vqst, vlab).backward()
+        vec = [p.grad.data for p in unrolled.parameters()]
+        base = probe._hessian_vector_product(vec, img, qst, lab)
+        spread = max(float((a - b).abs().max() / b.abs().max())
+                     for k in range(-4, 5) for a, b in zip(probe._hessian_vector_product(vec, img, qst, lab, r=1e-2 * (1 + k * 1e-6)), base))
+        print('data seeds', seed, seed + 1, 'spread of the reference HVP under r * (1 +- 4e-6):', spread)
+        if spread < 5e-4:
+            break
+    else:
+        raise SystemExit('no stable probe point found')
+    ef.load_state_dict(start)
+    # the EF model is arch_lct.pt's (same seeds): its initial state is pinned there, not stored twice
+    out = {'dims': dims, 'ef_seed': 10, 'arch': [a.detach().clone() for a in ef.arch_parameters()], 'data_seeds': (seed, seed + 1),
+           'hvp_self_spread': spread, 'train': (img, qst, lab), 'valid': (vimg, vqst, vlab)}
+    pick = ('img_encoder.fc.weight', 'img_encoder.darts.stem.0.weight', 'img_encoder.darts.cells.1._ops.2._ops.6.op.1.weight',
+            'img_encoder.darts.cells.3._ops.13._ops.4.op.5.weight', 'qst_encoder.fc2.weight', 'qst_encoder.lstm.weight_hh_l0', 'fc2.weight')
+
+    class Traced(Architect):
+        def _hessian_vector_product(self, vector, *a, **k):
+            self.tr['v'] = {n: t for n, t in named_small(self.model, vector).items() if n in pick}
+            self.tr['dalpha_direct'] = [p.grad.detach().clone() for p in self.unrolled.arch_parameters()]
+            out = super()._hessian_vector_product(vector, *a, **k)
+            self.tr['implicit'] = [g.detach().clone() for g in out]
+            return out
+
+        def _compute_unrolled_model(self, *a, **k):
+            self.unrolled = super()._compute_unrolled_model(*a, **k)
+            return self.unrolled
+
+    for unrolled in (True, False):
+        ef.load_state_dict(start)
+        for a, r0 in zip(ef.arch_parameters(), out['arch']):
+            a.data.copy_(r0)
+            a.grad = None
+        ef.zero_grad()
+        arch = Traced(ef)
+        arch.tr = {}
+        arch.optimizer.zero_grad()
+        if unrolled:
+            arch._backward_step_unrolled(img, qst, lab, vimg, vqst, vlab, 1e-3, None)
+        else:
+            arch._backward_step(vimg, vqst, vlab)
+        key = 'unrolled' if unrolled else 'first_order'
+        out[key] = dict(arch.tr, arch_grads=[a.grad.detach().clone() for a in ef.arch_parameters()])
+        arch.optimizer.step()
+        out[key]['arch_after'] = [a.detach().clone() for a in ef.arch_parameters()]
+        print(key, 'arch grads abs max', [float(g.abs().max()) for g in out[key]['arch_grads']])
+    # fp32 noise of the finite-difference term: the same reference code in float64 from the same initial values
+    ef64, _ = build_pair(models, models_lct, dims, torch.float64)
+    ef64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in start.items()})
+    arch = Traced(ef64)
+    arch.tr = {}
+    arch._backward_step_unrolled(img.double(), qst, lab, vimg.double(), vqst, vlab, 1e-3, None)
+    torch.set_default_dtype(torch.float32)
+    out['unrolled']['implicit_f64'] = [g.float() for g in arch.tr['implicit']]
+    print('implicit f32 vs f64 (rel to max)', [float((a - b.float()).abs().max() / b.abs().max()) for a, b in zip(out['unrolled']['implicit'], arch.tr['implicit'])])
+    torch.save(out, os.path.join(GOLD, 'arch_two_level.pt'))
+
+
 def main(mode):
     stub_tv()
     torch.nn.functional.dropout = lambda input, p=0.5, training=True, inplace=False: input
     dims = dict(embed_size=32, qst_vocab_size=50, ans_vocab_size=40, word_embed_size=16, num_layers=1, hidden_size=32)
-    if mode == 'basic':
+    if mode in ('basic', 'basic2'):
         sys.path.insert(0, '/root/reference/basic_vqa')
         import config
         config.DEVICE = 'cpu'
         config.ARCH_TYPE = 'darts'
         import models, models_lct
-        from pcdarts.architect_lct import ArchitectLct
-        torch.manual_seed(10)
-        ef = models_lct.VqaModel(**dims)
-        torch.manual_seed(12)
-        for a in ef.arch_parameters():
-            a.data.copy_(torch.randn_like(a) * 0.3)
-        torch.manual_seed(20)
-        w = models.VqaModel(**dims)
-        no_dropout(ef.train()); no_dropout(w.train())
-        ef.qst_encoder.max_length = 6
-        img, qst, lab = data(30, 2, 50, 40)
-        vimg, vqst, vlab = data(31, 2, 50, 40)
-        out = {'dims': dims, 'ef_seed': 10, 'w_seed': 20, 'ef_state': small(ef.state_dict()), 'w_state': small(w.state_dict()),
-               'arch': [a.detach().clone() for a in ef.arch_parameters()], 'max_length': 6,
-               'train': (img, qst, lab), 'valid': (vimg, vqst, vlab)}
-        loss = ef._loss(img, qst, lab)
-        ps = dict(ef.named_parameters())
-        names = ['img_encoder.fc.weight', 'img_encoder.darts.stem.0.weight', 'img_encoder.darts.cells.1._ops.2._ops.6.op.1.weight',
-                 'qst_encoder.fc2.weight', 'qst_encoder.lstm.weight_hh_l0', 'fc2.weight']
-        grads = torch.autograd.grad(loss, list(ef.arch_parameters()) + [ps[n] for n in names])
-        out.update(ef_loss=loss.detach(), ef_arch_grads=[g.clone() for g in grads[:4]],
-                   ef_param_grads={n: g.clone() for n, g in zip(names, grads[4:])})
-        # the forward above updated the BN running statistics: record the state the architect starts from
-        out['ef_state_before_step'] = small(ef.state_dict())
-        ef_opt = torch.optim.Adam(ef.parameters(), lr=1e-3)
-        w_opt = torch.optim.Adam(w.parameters(), lr=1e-3)
-        arch = ArchitectLct(ef, w, ef_opt, w_opt)
-        arch.optimizer.zero_grad()
-        arch._backward_step_unrolled(img, qst, lab, vimg, vqst, vlab, 1e-3, 1e-3)
-        out['lct_arch_grads'] = [a.grad.detach().clone() for a in ef.arch_parameters()]
-        arch.optimizer.step()
-        out['lct_arch_after'] = [a.detach().clone() for a in ef.arch_parameters()]
-        torch.save(out, os.path.join(GOLD, 'arch_lct.pt'))
-        print('arch grads abs max', [float(g.abs().max()) for g in out['lct_arch_grads']])
+        (basic_lct if mode == 'basic' else basic_two_level)(config, models, models_lct, dims)
     else:
         sys.path.insert(0, '/root/reference/darts_vqa')
         import config
