@@ -10,6 +10,9 @@ barrier + synchronize; MAX over ranks; rank 0 prints ONE JSON line.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 256]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(``torch.distributed.run`` as a child process, before this process has touched the GPU) and relays rank 0's JSON line.
 """
 import argparse
 import json
@@ -84,6 +87,16 @@ def host_threads():
     return min(n, 64) if n > 64 else n
 
 
+def conv_source_stamp():
+    """Hash of the trunk-convolution kernel sources: a committed PMC profile is only quoted for the kernels it measured."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('conv3x3.hip', 'conv3x3_wino.hip', 'conv3x3_wino4.hip', 'common.h'):
+        with open(os.path.join(ROOT, 'lct_vqa_amd', 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_model_name():
     try:
         for line in open('/proc/cpuinfo'):
@@ -127,8 +140,24 @@ def cpu_baseline(steps):
                       + f' (torch {torch.__version__} CPU, {ncores} threads)'}
 
 
+def self_launch(args):
+    """N > 1 without a launcher: run ``torch.distributed.run`` as a CHILD of this process (which has not initialised HIP:
+    importing torch does not) with the same arguments; the ranks inherit stdout, so rank 0's JSON line is this command's."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args))
     from lct_vqa_amd import ops, parallel
     from lct_vqa_amd._lib import lib
     from lct_vqa_amd.basic_vqa import models, config
@@ -368,27 +397,38 @@ def main():
     tot_exec = sum(r['flops'] / (4.0 if r['name'].startswith('wino4') else 2.25 if r['name'].startswith('wino') else 1.0) for r in conv)
     tot_ms = sum(r['ms'] for r in conv)
     nlaunch = max(1, len(conv))
-    achieved = tot_flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    direct_equiv = tot_flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     executed = tot_exec / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     nwino = sum(1 for r in conv if r['name'].startswith('wino'))
     nw4 = sum(1 for r in conv if r['name'].startswith('wino4'))
+    # achieved / frac: the multiply-adds the kernels' ALGORITHM performs on the MFMA pipe (Winograd F(4x4,3x3): 36 per
+    # 4x4 output tile and channel pair = 1/4 of direct convolution's 144; F(2x2,3x3): 1/2.25) over the live HIP-event
+    # time of those launches, against the dense fp32 MFMA peak: a utilisation, <= 1.  What Winograd buys on top is
+    # `algorithmic_speedup`; `direct_equivalent_tflops` = the direct-convolution FLOP count per second.
     roofline = {'bound': 'mfma',
                 'kernel': ('conv3x3_wino4_kernel (Winograd F(4x4,3x3), %d launches) + conv3x3_wino2/3_kernel (F(2x2,3x3), %d) + '
                            'conv3x3_mfma_kernel (direct, %d): fp32 MFMA' % (nw4, nwino - nw4, nlaunch - nwino)) if nwino else
                           'conv3x3_mfma_kernel (direct implicit GEMM, 15 VGG19 layers/step)',
-                'algorithm': algo, 'achieved': round(achieved, 2),
-                'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                'mfma_executed_tflops': round(executed, 2), 'mfma_executed_frac': round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
-                'note': ('achieved counts the ALGORITHMIC (direct-convolution) FLOPs per launch; the fp32 Winograd kernels execute 4x '
-                         '(F(4x4,3x3)) / 2.25x (F(2x2,3x3)) fewer on the MFMA pipe, so frac can exceed 1; mfma_executed_frac is the '
-                         "pipe's real utilisation against the same peak") if nwino else None,
+                'algorithm': algo, 'achieved': round(executed, 2),
+                'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
+                'algorithmic_speedup': round(tot_flops / tot_exec, 3) if tot_exec else None,
+                'direct_equivalent_tflops': round(direct_equiv, 2),
                 'traffic': None, 'launches': nlaunch, 'avg_launch_ms': round(tot_ms / nlaunch, 4),
-                'flops_per_launch': tot_flops / nlaunch, 'conv_ms_per_step': round(tot_ms / args.steps, 3)}
-    try:      # HBM bytes per launch of the same kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
-        pfile = 'r01_pmc_conv_wino.json' if nwino else 'r01_pmc_conv_gemm.json'
-        pm = json.load(open(os.path.join(ROOT, 'profiles', pfile)))['conv3x3_family']
-        roofline['traffic'] = pm['hbm_bytes_per_launch']
-        roofline['traffic_source'] = f'profiles/{pfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per launch)'
+                'flops_per_launch': tot_exec / nlaunch, 'direct_flops_per_launch': tot_flops / nlaunch,
+                'algorithmic_bytes_per_launch': sum(r.get('bytes', 0) for r in conv) / nlaunch or None,
+                'conv_ms_per_step': round(tot_ms / args.steps, 3)}
+    # HBM bytes per launch of the same kernel family from the committed rocprofv3 --pmc passes of this command (FETCH_SIZE,
+    # WRITE_SIZE: tools/pmc_profile.py); used only while the kernels are the ones that were profiled (source stamp)
+    try:
+        pfile = 'r02_pmc_conv_wino.json' if nwino else 'r01_pmc_conv_gemm.json'
+        pm = json.load(open(os.path.join(ROOT, 'profiles', pfile)))
+        if pm.get('csrc_stamp') in (None, conv_source_stamp()):
+            roofline['traffic'] = pm['conv3x3_family']['hbm_bytes_per_launch']
+            roofline['traffic_source'] = f'profiles/{pfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per launch)'
+            if roofline['algorithmic_bytes_per_launch']:
+                roofline['traffic_ratio'] = round(roofline['traffic'] / roofline['algorithmic_bytes_per_launch'], 3)
+        else:
+            roofline['traffic_source'] = f'profiles/{pfile} is of other kernel sources (stamp mismatch): not reported'
     except Exception:
         pass
     if args.layer_report:

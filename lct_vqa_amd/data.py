@@ -13,7 +13,12 @@ Here the same on-disk arrays are consumed in their own dtype:
   * batches are gathered as uint8 into PINNED host buffers (double buffered), copied with non_blocking H2D on a
     side stream (150 KB per 224x224 image instead of 602 KB) and normalised to fp32 NCHW on the GPU
     (lctvqa_image_u8_nhwc_to_f32_nchw);
-  * the answer label is drawn like the reference (`np.random.choice(valid_answers)`, `<unk>` when none).
+  * the answer label is drawn like the reference (`np.random.choice(valid_answers)`, `<unk>` when none);
+  * `answer_multi_choice` (the valid answer ids of a sample, padded with -1 to MAX_NUM_ANS = 10,
+    data_loader_v2.py:66-67) travels as ONE int64 [10, B] device tensor -- the stacked form of the list of 10 [B] tensors
+    the reference's collate produces; `misc.num_correct` / `ops.eval_multi_choice` take either -- and `enc_ans` [B, A],
+    `image_name` (host strings, for BLEU bookkeeping) are yielded too, so a batch can drive the reference's train / val
+    loops (experiment.py:197,309) and the device-side accuracy counters.
 """
 import numpy as np
 import torch
@@ -22,6 +27,7 @@ from ._lib import lib
 
 MEAN = (0.485, 0.456, 0.406)
 STD = (0.229, 0.224, 0.225)
+MAX_NUM_ANS = 10              # reference basic_vqa/config.py:12; data_loader_v2.py:66 hard-codes the same 10
 
 
 class ShardedSampler:
@@ -51,10 +57,13 @@ class ShardedSampler:
 
 class DeviceBatcher:
     """Iterate device-resident batches {'image' fp32 [B,3,S,S], 'question' int64 [B,T], 'answer_label' int64 [B],
-    'qst_len', 'image_id'} from array-like stores with the reference's HDF5 layout."""
+    'answer_multi_choice' int64 [10,B] (-1 padded), 'enc_ans' [B,A], 'qst_len', 'image_id'} + host-side 'image_name',
+    'image_path' (lists of str) from array-like stores with the reference's HDF5 layout (the keys of
+    data_loader_v2.py:69-73)."""
 
     def __init__(self, images, coco_ids, enc_qst, qst_len, enc_ans, img_id, batch_size, device, rank=0, world=1, seed=10,
-                 unk_idx=0, shuffle=True, drop_last=False):
+                 unk_idx=0, shuffle=True, drop_last=False, split='train'):
+        self.split = split
         self.images, self.enc_qst, self.qst_len, self.enc_ans, self.img_id = images, enc_qst, qst_len, enc_ans, img_id
         self.id_to_row = {int(v): i for i, v in enumerate(np.asarray(coco_ids))}       # data_loader_v2.py:38-43
         self.B, self.device, self.unk_idx, self.drop_last = batch_size, torch.device(device), unk_idx, drop_last
@@ -67,7 +76,9 @@ class DeviceBatcher:
                           qst=torch.empty((batch_size, self.T), dtype=torch.int64).pin_memory(),
                           lab=torch.empty((batch_size,), dtype=torch.int64).pin_memory(),
                           qlen=torch.empty((batch_size,), dtype=torch.int64).pin_memory(),
-                          iid=torch.empty((batch_size,), dtype=torch.int64).pin_memory()) for _ in range(2)]
+                          iid=torch.empty((batch_size,), dtype=torch.int64).pin_memory(),
+                          choice=torch.empty((MAX_NUM_ANS, batch_size), dtype=torch.int64).pin_memory(),
+                          ans=torch.empty((batch_size, enc_ans.shape[1]), dtype=torch.int64).pin_memory()) for _ in range(2)]
 
     def __len__(self):
         n = len(self.sampler)
@@ -84,6 +95,12 @@ class DeviceBatcher:
             ans = np.asarray(self.enc_ans[i])
             valid = ans.nonzero()[0]
             h['lab'][k] = int(self.rng.choice(valid)) if valid.size > 0 else self.unk_idx
+            # the reference's list is `[-1] * 10` overwritten from the front; more than 10 valid answers would make its
+            # default collate fail on ragged lists, so the first 10 are kept
+            row = np.full(MAX_NUM_ANS, -1, dtype=np.int64)
+            row[:min(valid.size, MAX_NUM_ANS)] = valid[:MAX_NUM_ANS]
+            h['choice'][:, k] = torch.from_numpy(row)
+            h['ans'][k].copy_(torch.from_numpy(ans.astype(np.int64)))
             h['qlen'][k] = int(self.qst_len[i])
             h['iid'][k] = iid
         return len(idx)
@@ -96,13 +113,18 @@ class DeviceBatcher:
             batch = {'question': h['qst'][:n].to(self.device, non_blocking=True),
                      'answer_label': h['lab'][:n].to(self.device, non_blocking=True),
                      'qst_len': h['qlen'][:n].to(self.device, non_blocking=True),
-                     'image_id': h['iid'][:n].to(self.device, non_blocking=True)}
+                     'image_id': h['iid'][:n].to(self.device, non_blocking=True),
+                     'answer_multi_choice': h['choice'][:, :n].to(self.device, non_blocking=True),
+                     'enc_ans': h['ans'][:n].to(self.device, non_blocking=True)}
             image = torch.empty((n, 3, self.S, self.S), dtype=torch.float32, device=self.device)
             lib('image_u8_nhwc_to_f32_nchw', img8, image, n, self.S, self.S, *MEAN, *STD,
                 torch.cuda.current_stream().cuda_stream)
             batch['image'] = image
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
+        ids = h['iid'][:n].tolist()
+        batch['image_name'] = [f'COCO_{self.split}2014_{i:012}' for i in ids]
+        batch['image_path'] = [f'{self.split}/images/{i}' for i in ids]
         return batch, ev
 
     def __iter__(self):
@@ -124,5 +146,6 @@ class DeviceBatcher:
             done_ev[b & 1] = ev
             main.wait_event(ev)
             for t in batch.values():
-                t.record_stream(main)
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)
             yield batch

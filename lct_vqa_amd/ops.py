@@ -6,6 +6,7 @@ ROCm device and the library must be built, otherwise these functions raise.
 """
 import contextlib
 import os
+import weakref
 import threading
 
 import torch
@@ -606,11 +607,11 @@ def conv_timer_start():
 
 
 def conv_timer_stop():
-    """-> list of dicts {name, ms, flops} (synchronises)."""
+    """-> list of dicts {name, ms, flops (direct-convolution count), bytes (input + output once)} (synchronises)."""
     global _conv_timer
     rec, _conv_timer = _conv_timer or [], None
     torch.cuda.synchronize()
-    return [dict(name=n, ms=a.elapsed_time(b), flops=f) for (n, a, b, f) in rec]
+    return [dict(name=n, ms=a.elapsed_time(b), flops=f, bytes=by) for (n, a, b, f, by) in rec]
 
 
 # ----------------------------------------------------------------------------- VGG19 trunk
@@ -646,7 +647,7 @@ def get_conv_algo():
     return _conv_algo
 
 
-def _timed(name, flops, fn):
+def _timed(name, flops, nbytes, fn):
     if _conv_timer is None:
         fn()
         return
@@ -654,7 +655,7 @@ def _timed(name, flops, fn):
     e0.record()
     fn()
     e1.record()
-    _conv_timer.append((name, e0, e1, flops))
+    _conv_timer.append((name, e0, e1, flops, nbytes))
 
 
 # Packed (kernel-layout) copies of the conv weights.  By default they are re-made on every call: parameters change behind
@@ -663,8 +664,9 @@ def _timed(name, flops, fn):
 # CONSTRUCTION (the W model's VGG19, reference basic_vqa/models.py:35-36: run under no_grad, held by no optimizer) can
 # opt in to a cache (`vgg.VGG.cache_packed_weights = True`, set by bench.py): one packed copy per (parameter, stream),
 # re-made when the tensor's version counter moves (load_state_dict / copy_ / any in-place op on the parameter itself)
-# or the storage changes (device move).  In-place writes through `.data` do not move the counter: do not opt in for
-# parameters that receive them.
+# or the storage changes (device move).  An entry belongs to the tensor OBJECT it was made from (weak reference): another
+# model's parameter that the caching allocator later places at the same address never inherits it.  In-place writes
+# through `.data` do not move the counter: do not opt in for parameters that receive them.
 _pack_cache = {}
 
 
@@ -675,12 +677,15 @@ def _packed_weights(w, kind, numel, pack, cache=False):
         return dst
     key = (kind, w.data_ptr(), tuple(w.shape), torch.cuda.current_stream(w.device).cuda_stream)
     ent = _pack_cache.get(key)
+    if ent is not None and ent[2]() is not w:                 # same address, other (or dead) tensor: not this one's copy
+        ent = None
     if ent is None or ent[0] != w._version:
         dst = ent[1] if ent is not None else torch.empty(numel, dtype=torch.float32, device=w.device)
         pack(dst)
         if len(_pack_cache) > 512:                            # entries of parameters that no longer exist
-            _pack_cache.clear()
-        _pack_cache[key] = (w._version, dst)
+            for k in [k for k, e in _pack_cache.items() if e[2]() is None]:
+                del _pack_cache[k]
+        _pack_cache[key] = (w._version, dst, weakref.ref(w))
         return dst
     return ent[1]
 
@@ -700,6 +705,7 @@ def _conv_block(cur, w, b, B, H, W, pool, cache=False):
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
         _timed(f'{wv}_{H}x{W}_{Cin}->{Cout}{"+pool" if pool else ""}', 2.0 * B * H * W * Cout * Cin * 9,
+               4.0 * B * (H * W * Cin + Ho * Wo * Cout),
                lambda: lib(f'conv3x3_{wv}_nhwc', cur, up, b, out, B, H, W, Cin, Cout, 1, pool))
         return out
     mfma = lib.query('conv3x3_uses_mfma', B, H, W, Cin, Cout, pool)
@@ -710,15 +716,12 @@ def _conv_block(cur, w, b, B, H, W, pool, cache=False):
         tmp = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
-    if _conv_timer is not None and mfma:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        lib('conv3x3_nhwc', cur, w, wp, b, out, tmp, B, H, W, Cin, Cout, 1, pool)
-        e1.record()
-        _conv_timer.append((f'conv{H}x{W}_{Cin}->{Cout}{"+pool" if pool else ""}', e0, e1,
-                            2.0 * B * H * W * Cout * Cin * 9))
+    launch = lambda: lib('conv3x3_nhwc', cur, w, wp, b, out, tmp, B, H, W, Cin, Cout, 1, pool)
+    if mfma:
+        _timed(f'conv{H}x{W}_{Cin}->{Cout}{"+pool" if pool else ""}', 2.0 * B * H * W * Cout * Cin * 9,
+               4.0 * B * (H * W * Cin + Ho * Wo * Cout), launch)
     else:
-        lib('conv3x3_nhwc', cur, w, wp, b, out, tmp, B, H, W, Cin, Cout, 1, pool)
+        launch()
     return out
 
 

@@ -17,26 +17,34 @@ import torch.distributed as dist
 
 class FlatGradReducer:
     def __init__(self, params, flat_grad, process_group=None, bucket_bytes=32 << 20, scale_fn=None):
-        """params: the parameters whose .grad are consecutive views into flat_grad (arena order)."""
+        """params: parameters whose .grad are views into ``flat_grad`` in ascending order (optim.FusedAdam(flatten=True)'s
+        arena, which pads every parameter to a 16-byte boundary, or ``make_flat_grad``).  A bucket is a contiguous range of
+        the buffer (padding included: it is zero on every rank)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.flat = flat_grad
         self.scale_fn = scale_fn
         self.buckets = []          # [start, end, n_params_pending, n_params]
         self.param_bucket = {}
-        per = max(1, bucket_bytes // 4)
-        o, start, cnt, ids = 0, 0, 0, []
+        per = max(1, bucket_bytes // flat_grad.element_size())
+        base, size = flat_grad.data_ptr(), flat_grad.element_size()
+        start, ids, prev_end = 0, [], 0
         for p in params:
-            k = p.numel()
+            if p.grad is None:
+                raise ValueError('FlatGradReducer: a parameter has no .grad view into the flat buffer')
+            o = (p.grad.data_ptr() - base) // size
+            if o < prev_end or o + p.numel() > flat_grad.numel():
+                raise ValueError('FlatGradReducer: parameter gradients must be ascending, disjoint views of flat_grad')
+            prev_end = o + p.numel()
             ids.append(p)
-            cnt += 1
-            o += k
-            if o - start >= per:
-                self._close(start, o, ids)
-                start, cnt, ids = o, 0, []
-        if ids:
-            self._close(start, o, ids)
-        assert o == flat_grad.numel()
+            if prev_end - start >= per:
+                self._close(start, prev_end, ids)
+                start, ids = prev_end, []
+        if ids or start < flat_grad.numel():
+            if ids:
+                self._close(start, flat_grad.numel(), ids)
+            else:                                                  # trailing padding joins the last bucket
+                self.buckets[-1][1] = flat_grad.numel()
         self.handles = []
         self._hooks = []
         if self.world > 1:

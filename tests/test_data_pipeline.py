@@ -37,8 +37,34 @@ def test_device_batcher_matches_reference_transform(hip_lib, tmp_path):
     enc_ans[0] = 0                                                                     # no valid answer -> <unk>
     img_id = coco_ids[rs.randint(0, nimg, (nq,))]
     db = DeviceBatcher(images, coco_ids, enc_qst, qst_len, enc_ans, img_id, 8, 'cuda', unk_idx=1, shuffle=True)
+    from lct_vqa_amd.basic_vqa import misc
+    from lct_vqa_amd import ops
     seen = []
+    hits = total = 0
     for batch in db:
+        # the multiple-choice table: every valid answer id of the sample from the front, -1 padded, 10 rows
+        # (data_loader_v2.py:63-67), and it feeds the accuracy counters of the train / val loops directly
+        ch = batch['answer_multi_choice']
+        assert ch.shape == (10, len(batch['image_id'])) and ch.dtype == torch.int64
+        ans = batch['enc_ans'].cpu().numpy()
+        for k in range(ch.shape[1]):
+            valid = ans[k].nonzero()[0]
+            exp = np.full(10, -1)
+            exp[:min(10, valid.size)] = valid[:10]
+            assert np.array_equal(ch[:, k].cpu().numpy(), exp)
+        pred = batch['answer_label'].clone()
+        pred[::2] = A + 5                                                       # half of the predictions are wrong on purpose
+        ref_hits = sum(int(pred[k].item() in set(ans[k].nonzero()[0][:10].tolist())) for k in range(len(pred)))
+        assert misc.num_correct(pred, ch) == ref_hits                            # reference formula misc.py:42-45
+        assert misc.num_correct(pred, list(ch)) == ref_hits                      # ... and in the collate's list-of-10 form
+        counts = torch.zeros(2, dtype=torch.int64, device='cuda')
+        logits = torch.full((len(pred), A + 6), -1.0, device='cuda')
+        logits[torch.arange(len(pred)), pred] = 1.0
+        ops.eval_multi_choice(logits, ch, 1, counts)
+        assert counts[0].item() == ref_hits
+        hits += ref_hits
+        total += len(pred)
+        assert batch['image_name'][0] == 'COCO_train2014_%012d' % int(batch['image_id'][0]) and len(batch['image_name']) == len(pred)
         iid = batch['image_id'].cpu().numpy()
         for k in range(len(iid)):
             raw = np.asarray(images[int(iid[k]) - 100]).astype(np.float32) / 255.0     # ToTensor
@@ -49,5 +75,6 @@ def test_device_batcher_matches_reference_transform(hip_lib, tmp_path):
         seen.append(batch['question'].cpu().numpy())
         lab = batch['answer_label'].cpu().numpy()
         assert ((lab >= 0) & (lab < A)).all()
+    assert 0 < hits < total
     seen = np.concatenate(seen)
     assert len(seen) == nq and sorted(map(tuple, seen.tolist())) == sorted(map(tuple, enc_qst.astype(np.int64).tolist()))

@@ -59,6 +59,63 @@ def test_dp2_matches_single_process(tmp_path):
     assert torch.allclose(got, ref, rtol=1e-5, atol=1e-7)
 
 
+def _arena_worker(rank, world, port, out):
+    """The objects bench.py uses: optim.FusedAdam(flatten=True)'s padded arena + FlatGradReducer on its flat gradient (CPU
+    tensors here, so only the optimizer STEP -- a HIP kernel -- is left out)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lct_vqa_amd import parallel
+    from lct_vqa_amd.optim import FusedAdam
+    m = _model()
+    opt = FusedAdam(m.parameters(), lr=1e-3, flatten=True)
+    assert all(o % 4 == 0 for o in opt.flat['offsets']) and opt.flat_grad.numel() % 4 == 0
+    assert opt.flat_grad.numel() > sum(p.numel() for p in m.parameters())          # 17000*300, 7: padding exists
+    red = parallel.FlatGradReducer(opt.flat['params'], opt.flat_grad, bucket_bytes=1 << 20)
+    assert len(red.buckets) >= 2 and red.buckets[0][0] == 0 and red.buckets[-1][1] == opt.flat_grad.numel()
+    assert all(a[1] == b[0] for a, b in zip(red.buckets, red.buckets[1:]))           # the buckets tile the arena
+    torch.manual_seed(11)
+    x = torch.randn(8, 20)
+    y = torch.randint(7, (8,))
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    for it in range(2):
+        opt.zero_grad()
+        nn.functional.cross_entropy(m(xs), ys).backward()
+        red.finish()
+    assert opt.flat['touched'] == set(range(len(opt.flat['params'])))
+    if rank == 0:
+        torch.save([p.grad.clone() for p in m.parameters()], out)
+    dist.destroy_process_group()
+
+
+def test_dp2_on_the_optimizer_arena(tmp_path):
+    out = str(tmp_path / 'g.pt')
+    mp.spawn(_arena_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    m = _model()
+    torch.manual_seed(11)
+    x = torch.randn(8, 20)
+    y = torch.randint(7, (8,))
+    nn.functional.cross_entropy(m(x), y).backward()
+    for g, p in zip(got, m.parameters()):
+        assert torch.allclose(g, p.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_arena_skips_parameters_backward_did_not_reach():
+    """torch.optim.Adam leaves grad-None parameters alone; the arena records which parameters backward reached."""
+    from lct_vqa_amd.optim import FusedAdam
+    a, b, c = nn.Linear(3, 5), nn.Linear(5, 7), nn.Linear(7, 2)
+    opt = FusedAdam(list(a.parameters()) + list(b.parameters()) + list(c.parameters()), flatten=True)
+    opt.zero_grad()
+    c(torch.randn(2, 7)).sum().backward()                      # only the last module
+    assert opt.flat['touched'] == {4, 5}
+    assert opt._runs() == [[4, 5, 1]]
+    opt.flat['touched'].clear()
+    a(torch.randn(2, 3)).sum().backward()
+    c(torch.randn(2, 7)).sum().backward()
+    assert opt._runs() == [[0, 1, 1], [4, 5, 2]]             # per-parameter step counts, like torch's state['step']
+    assert float(opt.state[c.weight]['step']) == 2.0 and float(opt.state[b.weight]['step']) == 0.0
+
+
 def test_single_process_reducer_is_noop():
     from lct_vqa_amd import parallel
     m = _model()

@@ -240,3 +240,30 @@ def test_search_network_step_as_hip_graph(hip_lib):
             for p_ in params:
                 p_.add_(0.01 * torch.randn_like(p_))
             x.copy_(torch.randn_like(x))
+
+
+def test_graphed_refuses_a_step_that_would_crash_the_capture(hip_lib):
+    """The capture crash on record (gpurun_out/graph_fault.log) was preceded by torch's AccumulateGrad stream-mismatch
+    warning: a ``backward()`` into ``.grad`` whose AccumulateGrad nodes belong to an older graph on the default stream.
+    ``Graphed`` must see that during its warm-up and raise instead of starting a capture; the same step is fine once the old
+    graph is gone, and a ``backward()`` step whose nodes are made during warm-up captures and replays correctly."""
+    from lct_vqa_amd.graph import Graphed, GraphCaptureError
+    w = torch.randn(64, 64, device=DEV, requires_grad=True)
+    x = torch.randn(8, 64, device=DEV)
+    old_loss = (x @ w).sum()                       # an eager iteration whose graph (and AccumulateGrad node of w) stays alive
+    old_loss.backward(retain_graph=True)
+
+    def step():
+        (x @ w).pow(2).sum().backward()
+        return w.grad
+
+    with pytest.raises(GraphCaptureError):
+        Graphed(step)
+    del old_loss
+    w.grad = None
+    g = Graphed(step)
+    w.grad.zero_()
+    out = g.replay()
+    w2 = w.detach().clone().requires_grad_()
+    (x @ w2).pow(2).sum().backward()
+    assert torch.allclose(out, w2.grad, rtol=1e-5, atol=1e-5)

@@ -1,0 +1,71 @@
+"""The data-parallel path on the GPU box (one MI355X): RCCL itself at world size 1 on the real arena, and the
+self-launching ``bench.py --gpus 2`` rehearsed with both ranks on the one device (gloo transport; RCCL refuses two ranks on
+one GPU).  Each case runs in child processes so that process groups never leak into the test session."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', **extra)
+    env.pop('WORLD_SIZE', None)
+    return env
+
+
+def test_rccl_world_size_one_on_the_arena(hip_lib, tmp_path):
+    """backend 'nccl' (= RCCL) initialises on this box and all-reduces the optimizer's flat gradient arena in place;
+    FlatGradReducer + hip_scale + the fused clip+Adam step run on top of it."""
+    script = tmp_path / 'rccl1.py'
+    script.write_text(textwrap.dedent('''
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_PORT='29541')
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        from lct_vqa_amd import parallel
+        from lct_vqa_amd.optim import FusedAdam
+        from lct_vqa_amd._lib import lib
+        lib.load()
+        torch.manual_seed(0)
+        m = torch.nn.Sequential(torch.nn.Linear(33, 77), torch.nn.Tanh(), torch.nn.Linear(77, 5)).cuda()
+        opt = FusedAdam(m.parameters(), lr=1e-3, flatten=True)
+        red = parallel.FlatGradReducer(opt.flat['params'], opt.flat_grad, scale_fn=parallel.hip_scale)
+        opt.zero_grad()
+        m(torch.randn(8, 33, device='cuda')).sum().backward()
+        before = opt.flat_grad.clone()
+        h = dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM, async_op=True)      # what FlatGradReducer._launch issues
+        h.wait()
+        parallel.hip_scale(1.0, opt.flat_grad)
+        red.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(before, opt.flat_grad) and before.abs().sum() > 0
+        p0 = opt.flat_param.clone()
+        opt.step(max_grad_norm=5)
+        assert not torch.equal(p0, opt.flat_param)
+        dist.barrier()
+        dist.destroy_process_group()
+        print('RCCL_OK', torch.cuda.nccl.version())
+    ''' % ROOT))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=_env())
+    assert r.returncode == 0 and 'RCCL_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_bench_launches_its_own_ranks(hip_lib):
+    """``python bench.py --gpus 2`` with no launcher around it starts its two ranks (torch.distributed.run as a child) and
+    prints ONE JSON line with n_gpus = 2 and the whole-job rate."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--batch', '32', '--no-cpu-baseline'], capture_output=True, text=True, timeout=600,
+                       env=_env(LCTVQA_REHEARSE_ONE_GPU='1'), cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-4000:])
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 64 and out['scaling'] == 'weak'
+    assert out['value'] > 0 and abs(out['value'] - 64 / (out['ms_per_step'] * 1e-3)) < 1e-2 * out['value']
+    assert 0 < out['roofline']['frac'] <= 1.0

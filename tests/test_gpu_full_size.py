@@ -9,7 +9,7 @@ from _util import rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
-DIMS = dict(embed_size=1024, qst_vocab_size=17858, ans_vocab_size=3129, word_embed_size=300, num_layers=1, hidden_size=512)
+from bench import DIMS          # BASELINE configs[1] exactly as bench.py measures it (embed 512, hidden 512, QV 17858, A 3129)
 
 
 @pytest.fixture(scope='module')
