@@ -237,6 +237,26 @@ int lctvqa_mixed_combine_bwd_scalars(const float* dout, long ldd, const float* c
                                      const float* beta, const float* x, int B, int Ho, int Wo, int C, int reduce, float* dw,
                                      float* dbeta, float* scratch, void* stream);
 
+/* One PC-DARTS MixedOp edge as fused tile kernels (model_search.py:22-55 + the seven live primitives of operations.py:4-20
+ * on x[..., :C/4], their BatchNorms, the alpha-weighted sum, bypass, channel shuffle and the beta-weighted accumulation
+ * into the node's sum, model_search.py:87): csrc/mixed_edge.hip.  w = 14 device pointers: depthwise weights [Cq][K][K] of
+ * sep3.a, sep5.a, dil3, dil5, sep3.b, sep5.b; their 1x1 weights [Cq][Cq]; FactorizedReduce conv_1 / conv_2 [Cq/2][Cq] (stride-2
+ * edges, else NULL).  bn = 27 pointers: running_mean[9], running_var[9], num_batches_tracked[9] by slot (0 max-pool, 1 avg-pool,
+ * 2 skip, 3 sep3.a, 4 sep5.a, 5 dil3, 6 dil5, 7 sep3.b, 8 sep5.b; NULL = none).  pre [9][P][Cq] receives every pre-BatchNorm
+ * tensor (saved for the backward), mean / invstd [9][Cq] the statistics used; part = fp64 scratch, grid*7*Cq*2 doubles.
+ * wsel [7] = softmax(alpha) of the live primitives, beta [1].  Backward: dx [B,H,W,C], dwsel [7], dbeta [1], wgrad = flat
+ * weight gradients in the order of w. */
+int lctvqa_mixed_edge_supported(int B, int H, int W, int C, int stride);
+int lctvqa_mixed_edge_grid(int B, int H, int W, int C, int stride);
+int lctvqa_mixed_edge_wgrad_elems(int C);
+long lctvqa_mixed_edge_bwd_scratch_floats(int B, int H, int W, int C, int stride);
+int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride, const void* const* w, void* const* bn,
+                          float* pre, float* mean, float* invstd, double* part, const float* wsel, const float* beta,
+                          float* out, long ldo, int accumulate, int training, float momentum, float eps, void* stream);
+int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, int H, int W, int C, int stride, const void* const* w,
+                          const float* pre, const float* mean, const float* invstd, const float* wsel, const float* beta, float* dx,
+                          float* dwsel, float* dbeta, float* wgrad, float* scratch, int training, void* stream);
+
 /* ---- input pipeline, device side (data_loader_v2.py:53-55,82-86: ToTensor + Normalize done per sample on the host):
  *      uint8 HWC rows of the image store -> fp32 NCHW, y = (x/255 - mean[c]) / std[c] ---------------------------- */
 int lctvqa_image_u8_nhwc_to_f32_nchw(const uint8_t* x, float* y, int B, int H, int W, float m0, float m1, float m2,

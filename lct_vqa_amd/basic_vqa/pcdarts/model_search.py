@@ -79,15 +79,39 @@ class MixedOp(nn.Module):
                 outs.append(op(part))
         return outs, self._live
 
+    def _fused_plan(self):
+        """(BatchNorm holder per slot, weight tensors in the fused kernels' order) when this MixedOp is the PRIMITIVES table
+        the fused edge kernels implement (csrc/mixed_edge.hip), else None."""
+        plan = self.__dict__.get('_plan')
+        if plan is None:
+            plan = False
+            if list(PRIMITIVES) == ['none', 'max_pool_3x3', 'avg_pool_3x3', 'skip_connect', 'sep_conv_3x3', 'sep_conv_5x5',
+                                    'dil_conv_3x3', 'dil_conv_5x5']:
+                mx, av, skip, s3, s5, d3, d5 = (self._ops[i] for i in range(1, 8))
+                convs = [s3.op[1], s5.op[1], d3.op[1], d5.op[1], s3.op[5], s5.op[5]]
+                points = [s3.op[2], s5.op[2], d3.op[2], d5.op[2], s3.op[6], s5.op[6]]
+                bns = [mx[1], av[1], skip.bn if self.stride == 2 else None, s3.op[3], s5.op[3], d3.op[3], d5.op[3], s3.op[7], s5.op[7]]
+                if all(not b.affine and b.momentum is not None for b in bns if b is not None):
+                    plan = (bns, convs + points + ([skip.conv_1, skip.conv_2] if self.stride == 2 else []))
+            self.__dict__['_plan'] = plan
+        return plan or None
+
     def forward(self, x, weights, state=None, beta=None):
         """``state (+)= beta * shuffle(cat(sum_k w_k op_k(x[:C/4]), bypass(x[C/4:])))``; with the defaults this is the
         reference's ``MixedOp.forward(x, weights)``."""
-        outs, live = self.branches(x)
         idx = self._live_index.get(weights.device)
         if idx is None:
-            idx = self._live_index[weights.device] = torch.as_tensor(live, device=weights.device)
+            idx = self._live_index[weights.device] = torch.as_tensor(self._live, device=weights.device)
         if beta is None:
             beta = torch.ones(1, dtype=torch.float32, device=x.device)
+        plan = self._fused_plan() if D.FUSED_EDGE else None
+        if plan is not None and D.lib.query('mixed_edge_supported', *x.shape, self.stride):
+            bns, mods = plan
+            modes = {b.training or not b.track_running_stats for b in bns if b is not None}
+            if len(modes) == 1:                                   # one kernel, one mode: every BatchNorm of the edge agrees
+                return D.MixedEdgeFn.apply(state, x, weights[idx], beta.reshape(1), self.stride, bns, modes.pop(),
+                                           *[m.weight for m in mods])
+        outs, _ = self.branches(x)
         return D.MixedCombineFn.apply(state, x, weights[idx], beta.reshape(1), self.stride == 2, *outs)
 
 

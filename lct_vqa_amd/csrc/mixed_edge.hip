@@ -1,0 +1,1223 @@
+// One PC-DARTS MixedOp edge (reference basic_vqa/pcdarts/model_search.py:22-55, operations.py:4-104) as a handful of
+// tile kernels instead of one launch and one HBM tensor per primitive and per BatchNorm pass.
+//
+//   x [B,H,W,C] NHWC, Cq = C/4, x1 = x[..., :Cq]; stride s (2 on the input edges of a reduction cell); P = B*Ho*Wo
+//   slot  branch                                 pre-BN tensor (all [P,Cq], batch-statistics BatchNorm, affine=False)
+//    0    max_pool_3x3(s)                         u0
+//    1    avg_pool_3x3(s), count_include_pad=0    u1
+//    2    skip_connect: s=1 identity (no BN); s=2 FactorizedReduce = relu -> two 1x1 stride-2 convs (even / odd) -> cat   u2
+//    3    sep_conv_3x3 stage a: relu -> dw3(s) -> 1x1                        t3     7  stage b: bn -> relu -> dw3(1) -> 1x1   u3
+//    4    sep_conv_5x5 stage a: relu -> dw5(s) -> 1x1                        t4     8  stage b: bn -> relu -> dw5(1) -> 1x1   u4
+//    5    dil_conv_3x3: relu -> dw3(s, dilation 2) -> 1x1                    u5
+//    6    dil_conv_5x5: relu -> dw5(s, dilation 2) -> 1x1                    u6
+//   mix = sum_k w_k bn_k(u_k);  out (+)= beta * channel_shuffle(cat(mix, bypass(x[..., Cq:])), 4)
+//
+// Forward = three tile kernels separated by the two batch-statistics reductions BatchNorm needs:
+//   edge_fwd_a   x1 halo tile in LDS (read once for all seven branches) -> slots 0..6 + per-workgroup partial (sum, sum^2)
+//   edge_fwd_b   t3 / t4 halo tiles, normalised + ReLU'd on load -> slots 7, 8 + partials
+//   edge_fwd_c   normalise the seven final slots, alpha-weighted sum, bypass (2x2 max-pooled on reduction edges),
+//                channel shuffle, beta-accumulate into the node's running sum
+// with edge_stats_finish (fixed-order fp64 finish, running statistics, num_batches_tracked) after a and b.
+// Thread = one output pixel with ALL Cq channels in registers (the 1x1 convolutions never leave the thread); LDS tiles are
+// planar per channel quad ([quad][position] of float4) so neighbouring pixels read neighbouring 16-byte words.
+// Roofline: HBM (Cq = 4..16 cannot feed an MFMA tile); algorithmic bytes per edge forward = (1 + 9 + 2 + 7 + 3 + 4 + 4) T
+// with T = 4*P*Cq bytes.
+#include "common.h"
+
+namespace {
+
+constexpr int NSLOT = 9;
+struct EdgeW {
+  const float* dw[6];   // depthwise weights [Cq][K][K]:  0 sep3a 1 sep5a 2 dil3 3 dil5 4 sep3b 5 sep5b
+  const float* pw[6];   // 1x1 weights [Cq][Cq] (out, in), same order
+  const float* fr[2];   // FactorizedReduce conv_1 / conv_2 [Cq/2][Cq] (stride-2 edges)
+};
+struct EdgeBN {         // per slot: running statistics + batch counter (null when untracked / identity)
+  float* run_mean[NSLOT];
+  float* run_var[NSLOT];
+  long* tracked[NSLOT];
+};
+
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+}
+
+// Zero-padded halo tile of NQ channel quads: tile[q * th*tw + ly*tw + lx] = src[n, y0+ly, x0+lx, 4q..4q+3] (row stride ld
+// floats); ACT 0: as stored, 1: ReLU'd, 2: normalised + ReLU'd ((v - mean) * invstd, then max 0: the input of a sep_conv's
+// second stage).
+template <int NQ, int ACT>
+__device__ __forceinline__ void load_tile(f32x4* __restrict__ tile, const float* __restrict__ src, long ld, int n, int H, int W,
+                                          int y0, int x0, int th, int tw, const float* __restrict__ mean,
+                                          const float* __restrict__ invstd) {
+  const int npos = th * tw;
+  for (int idx = threadIdx.x; idx < npos * NQ; idx += blockDim.x) {
+    const int q = idx % NQ, pos = idx / NQ;
+    const int ly = pos / tw, lx = pos - ly * tw;
+    const int y = y0 + ly, x = x0 + lx;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      v = *(const f32x4*)(src + (((long)n * H + y) * W + x) * ld + 4 * q);
+      if (ACT == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = fmaxf((v[e] - mean[4 * q + e]) * invstd[4 * q + e], 0.f);
+      } else if (ACT == 1) {
+        v = relu4(v);
+      }
+    }
+    tile[q * npos + pos] = v;
+  }
+}
+
+// depthwise K x K at one output pixel: taps at (cy + DIL*j, cx + DIL*i) of the tile (cy, cx = top-left tap), ReLU'd on read
+template <int CQ, int K, int DIL, bool RELU>
+__device__ __forceinline__ void dw_at(const f32x4* __restrict__ tile, int npos, int tw, int cy, int cx,
+                                      const float* __restrict__ wl /* LDS [CQ][K*K] */, float* __restrict__ out) {
+#pragma unroll
+  for (int q = 0; q < CQ / 4; q++) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < K; j++)
+#pragma unroll
+      for (int i = 0; i < K; i++) {
+        f32x4 v = tile[q * npos + (cy + DIL * j) * tw + cx + DIL * i];
+        if (RELU) v = relu4(v);
+#pragma unroll
+        for (int e = 0; e < 4; e++) a[e] = fmaf(wl[(4 * q + e) * K * K + j * K + i], v[e], a[e]);
+      }
+#pragma unroll
+    for (int e = 0; e < 4; e++) out[4 * q + e] = a[e];
+  }
+}
+
+// out[oc] = sum_c w[oc][c] * in[c]  (w in LDS, uniform address across the wave: broadcast reads)
+template <int NO, int NI>
+__device__ __forceinline__ void pw_at(const float* __restrict__ wl, const float* __restrict__ in, float* __restrict__ out) {
+#pragma unroll
+  for (int oc = 0; oc < NO; oc++) {
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < NI; c++) a = fmaf(wl[oc * NI + c], in[c], a);
+    out[oc] = a;
+  }
+}
+
+__device__ __forceinline__ void stage_weights(float* __restrict__ dst, const float* __restrict__ src, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+
+// Per-workgroup (sum, sum of squares) of the NS x CQ values every thread holds for ITS pixel (u[k][c], zeros when the thread
+// is not live): per channel quad the 4*NS columns go through LDS (red[col][thread]), 8 row segments per column are summed
+// by one thread each, then one thread per column adds the 8 segment sums -- in a fixed order -- into the workgroup's fp64
+// accumulators acc[(slot_base + k) * CQ + c] (sums) and acc[NSTAT * CQ + ...] (sums of squares).
+template <int CQ, int NS, int NSTAT, int TPB>
+__device__ __forceinline__ void phase_stats(const float (*u)[CQ], bool live, float* __restrict__ red, float* __restrict__ seg,
+                                            double* __restrict__ acc, int slot_base) {
+  constexpr int NC = 4 * NS;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < CQ / 4; q++) {
+    __syncthreads();                                           // red[] of the previous round consumed
+#pragma unroll
+    for (int k = 0; k < NS; k++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) red[(k * 4 + e) * (TPB + 1) + t] = live ? u[k][4 * q + e] : 0.f;
+    __syncthreads();
+    if (t < NC * 8) {
+      const int col = t % NC, prt = t / NC;
+      const float* r = red + col * (TPB + 1) + prt * (TPB / 8);
+      float a = 0.f, b = 0.f;
+#pragma unroll 8
+      for (int i = 0; i < TPB / 8; i++) { const float v = r[i]; a += v; b = fmaf(v, v, b); }
+      seg[col * 8 + prt] = a;
+      seg[(NC + col) * 8 + prt] = b;
+    }
+    __syncthreads();
+    if (t < NC) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int p = 0; p < 8; p++) { a += (double)seg[t * 8 + p]; b += (double)seg[(NC + t) * 8 + p]; }
+      const int k = t / 4, e = t % 4;
+      acc[(slot_base + k) * CQ + 4 * q + e] += a;
+      acc[(NSTAT + slot_base + k) * CQ + 4 * q + e] += b;
+    }
+  }
+}
+
+template <int CQ>
+__device__ __forceinline__ void store_row(float* __restrict__ dst, const float* __restrict__ v) {
+#pragma unroll
+  for (int q = 0; q < CQ / 4; q++) *(f32x4*)(dst + 4 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// edge_fwd_a: slots 0..6 from one x1 halo tile.  Tile = TH x TW output pixels (TH*TW threads), persistent over tiles.
+// Input tile origin (S*ty0 - 4, S*tx0 - 4): halo 4 = the reach of dil_conv_5x5 (padding 4, dilation 2).
+// ------------------------------------------------------------------------------------------------------------------
+template <int CQ, int S, int TH, int TW>
+__global__ __launch_bounds__(TH * TW) void edge_fwd_a_kernel(const float* __restrict__ x, int B, int H, int W, EdgeW wts,
+                                                             float* __restrict__ pre /* [9][P][CQ] */,
+                                                             double* __restrict__ part /* [grid][7*CQ][2] */) {
+  constexpr int TPB = TH * TW, NQ = CQ / 4, C = 4 * CQ;
+  constexpr int IH = S * (TH - 1) + 9, IW = S * (TW - 1) + 9, NPOS = IH * IW;
+  extern __shared__ __align__(16) unsigned char smem[];
+  f32x4* tile = (f32x4*)smem;                                   // [NQ][NPOS]
+  float* wl = (float*)(tile + NQ * NPOS);                      // weights
+  float* w_dw3a = wl, *w_dw5a = w_dw3a + CQ * 9, *w_dd3 = w_dw5a + CQ * 25, *w_dd5 = w_dd3 + CQ * 9;
+  float* w_pw = w_dd5 + CQ * 25;                               // [4][CQ*CQ]: sep3a sep5a dil3 dil5
+  float* w_fr = w_pw + 4 * CQ * CQ;                            // [2][CQ/2*CQ]
+  float* red = w_fr + CQ * CQ;                                 // [12][TPB+1]
+  float* seg = red + 12 * (TPB + 1);                           // [2][12][8]
+  double* acc = (double*)(seg + 2 * 12 * 8);                   // [2][7*CQ] (an even number of floats precedes it)
+  stage_weights(w_dw3a, wts.dw[0], CQ * 9);
+  stage_weights(w_dw5a, wts.dw[1], CQ * 25);
+  stage_weights(w_dd3, wts.dw[2], CQ * 9);
+  stage_weights(w_dd5, wts.dw[3], CQ * 25);
+  for (int k = 0; k < 4; k++) stage_weights(w_pw + k * CQ * CQ, wts.pw[k], CQ * CQ);
+  if (S == 2) { stage_weights(w_fr, wts.fr[0], CQ / 2 * CQ); stage_weights(w_fr + CQ / 2 * CQ, wts.fr[1], CQ / 2 * CQ); }
+  for (int i = threadIdx.x; i < 2 * 7 * CQ; i += TPB) acc[i] = 0.0;
+  const int Ho = H / S, Wo = W / S;
+  const int tiles_y = (Ho + TH - 1) / TH, tiles_x = (Wo + TW - 1) / TW;
+  const long ntiles = (long)B * tiles_y * tiles_x;
+  const long P = (long)B * Ho * Wo;
+  const int ly = threadIdx.x / TW, lx = threadIdx.x % TW;
+  for (long tidx = blockIdx.x; tidx < ntiles; tidx += gridDim.x) {
+    const int n = (int)(tidx / (tiles_y * tiles_x));
+    const int tr = (int)(tidx % (tiles_y * tiles_x));
+    const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+    __syncthreads();                                           // previous tile's readers are done (also orders the weight staging)
+    load_tile<NQ, 0>(tile, x, C, n, H, W, S * ty0 - 4, S * tx0 - 4, IH, IW, nullptr, nullptr);
+    __syncthreads();
+    const int oy = ty0 + ly, ox = tx0 + lx;
+    const bool live = oy < Ho && ox < Wo;
+    const int cy = S * ly + 4, cx = S * lx + 4;                  // tile position of input pixel (S*oy, S*ox)
+    const long qo = ((long)n * Ho + oy) * Wo + ox;
+    // The three groups of branches are computed, stored and reduced one after the other so that only one group's values are
+    // live in registers at a time.
+    {   // ---- pools (raw x1; validity by image coordinates) and, on a stride-2 edge, FactorizedReduce ----
+      float u[3][CQ];
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        f32x4 mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sm = {0.f, 0.f, 0.f, 0.f};
+        int cnt = 0;
+#pragma unroll
+        for (int j = -1; j <= 1; j++)
+#pragma unroll
+          for (int i = -1; i <= 1; i++) {
+            const int iy = S * oy + j, ix = S * ox + i;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+              const f32x4 v = tile[q * NPOS + (cy + j) * IW + cx + i];
+#pragma unroll
+              for (int e = 0; e < 4; e++) { mx[e] = fmaxf(mx[e], v[e]); sm[e] += v[e]; }
+              cnt++;
+            }
+          }
+        const float inv = 1.f / (float)max(cnt, 1);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { u[0][4 * q + e] = live ? mx[e] : 0.f; u[1][4 * q + e] = sm[e] * inv; }
+      }
+      if (S == 2) {
+        float r0[CQ], r1[CQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const f32x4 a = relu4(tile[q * NPOS + cy * IW + cx]), b = relu4(tile[q * NPOS + (cy + 1) * IW + cx + 1]);
+#pragma unroll
+          for (int e = 0; e < 4; e++) { r0[4 * q + e] = a[e]; r1[4 * q + e] = b[e]; }
+        }
+        pw_at<CQ / 2, CQ>(w_fr, r0, &u[2][0]);
+        pw_at<CQ / 2, CQ>(w_fr + CQ / 2 * CQ, r1, &u[2][CQ / 2]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < CQ; c++) u[2][c] = 0.f;
+      }
+      if (live) {
+        store_row<CQ>(pre + (0 * P + qo) * CQ, u[0]);
+        store_row<CQ>(pre + (1 * P + qo) * CQ, u[1]);
+        if (S == 2) store_row<CQ>(pre + (2 * P + qo) * CQ, u[2]);
+      }
+      phase_stats<CQ, 3, 7, TPB>(u, live, red, seg, acc, 0);
+    }
+    {   // ---- first stages of sep_conv_3x3 / sep_conv_5x5: relu -> depthwise (stride S) -> 1x1 ----
+      float u[2][CQ], d[CQ];
+      dw_at<CQ, 3, 1, true>(tile, NPOS, IW, cy - 1, cx - 1, w_dw3a, d);
+      pw_at<CQ, CQ>(w_pw, d, u[0]);
+      dw_at<CQ, 5, 1, true>(tile, NPOS, IW, cy - 2, cx - 2, w_dw5a, d);
+      pw_at<CQ, CQ>(w_pw + CQ * CQ, d, u[1]);
+      if (live) { store_row<CQ>(pre + (3 * P + qo) * CQ, u[0]); store_row<CQ>(pre + (4 * P + qo) * CQ, u[1]); }
+      phase_stats<CQ, 2, 7, TPB>(u, live, red, seg, acc, 3);
+    }
+    {   // ---- dil_conv_3x3 / dil_conv_5x5: relu -> depthwise (stride S, dilation 2) -> 1x1 ----
+      float u[2][CQ], d[CQ];
+      dw_at<CQ, 3, 2, true>(tile, NPOS, IW, cy - 2, cx - 2, w_dd3, d);
+      pw_at<CQ, CQ>(w_pw + 2 * CQ * CQ, d, u[0]);
+      dw_at<CQ, 5, 2, true>(tile, NPOS, IW, cy - 4, cx - 4, w_dd5, d);
+      pw_at<CQ, CQ>(w_pw + 3 * CQ * CQ, d, u[1]);
+      if (live) { store_row<CQ>(pre + (5 * P + qo) * CQ, u[0]); store_row<CQ>(pre + (6 * P + qo) * CQ, u[1]); }
+      phase_stats<CQ, 2, 7, TPB>(u, live, red, seg, acc, 5);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 7 * CQ; i += TPB) {
+    part[((long)blockIdx.x * 7 * CQ + i) * 2 + 0] = acc[i];
+    part[((long)blockIdx.x * 7 * CQ + i) * 2 + 1] = acc[7 * CQ + i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// edge_fwd_b: second stage of sep_conv_3x3 / sep_conv_5x5: bn_a -> relu (on load) -> depthwise (stride 1) -> 1x1
+// ------------------------------------------------------------------------------------------------------------------
+template <int CQ, int TH, int TW>
+__global__ __launch_bounds__(TH * TW) void edge_fwd_b_kernel(int B, int Ho, int Wo, EdgeW wts, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, float* __restrict__ pre,
+                                                             double* __restrict__ part /* [grid][2*CQ][2] */) {
+  constexpr int TPB = TH * TW, NQ = CQ / 4;
+  constexpr int IH = TH + 4, IW = TW + 4, NPOS = IH * IW;
+  extern __shared__ __align__(16) unsigned char smem[];
+  f32x4* tile3 = (f32x4*)smem;
+  f32x4* tile5 = tile3 + NQ * NPOS;
+  float* w_dw3 = (float*)(tile5 + NQ * NPOS), *w_dw5 = w_dw3 + CQ * 9, *w_pw = w_dw5 + CQ * 25;   // pw [2][CQ*CQ]
+  float* ms = w_pw + 2 * CQ * CQ;                               // mean/invstd of slots 3, 4: [2][2][CQ]
+  float* red = ms + 4 * CQ;                                    // [8][TPB+1]
+  float* seg = red + 8 * (TPB + 1);                            // [2][8][8]
+  double* acc = (double*)(seg + 128);                          // [2][2*CQ]
+  stage_weights(w_dw3, wts.dw[4], CQ * 9);
+  stage_weights(w_dw5, wts.dw[5], CQ * 25);
+  stage_weights(w_pw, wts.pw[4], CQ * CQ);
+  stage_weights(w_pw + CQ * CQ, wts.pw[5], CQ * CQ);
+  for (int i = threadIdx.x; i < 2 * CQ; i += TPB) {
+    ms[i] = mean[3 * CQ + i];                                  // slots 3 and 4 are consecutive
+    ms[2 * CQ + i] = invstd[3 * CQ + i];
+  }
+  for (int i = threadIdx.x; i < 4 * CQ; i += TPB) acc[i] = 0.0;
+  const int tiles_y = (Ho + TH - 1) / TH, tiles_x = (Wo + TW - 1) / TW;
+  const long ntiles = (long)B * tiles_y * tiles_x;
+  const long P = (long)B * Ho * Wo;
+  const int ly = threadIdx.x / TW, lx = threadIdx.x % TW;
+  for (long tidx = blockIdx.x; tidx < ntiles; tidx += gridDim.x) {
+    const int n = (int)(tidx / (tiles_y * tiles_x));
+    const int tr = (int)(tidx % (tiles_y * tiles_x));
+    const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+    __syncthreads();
+    load_tile<NQ, 2>(tile3, pre + 3 * P * CQ, CQ, n, Ho, Wo, ty0 - 2, tx0 - 2, IH, IW, ms, ms + 2 * CQ);
+    load_tile<NQ, 2>(tile5, pre + 4 * P * CQ, CQ, n, Ho, Wo, ty0 - 2, tx0 - 2, IH, IW, ms + CQ, ms + 3 * CQ);
+    __syncthreads();
+    const int oy = ty0 + ly, ox = tx0 + lx;
+    const bool live = oy < Ho && ox < Wo;
+    float u[2][CQ], d[CQ];
+    dw_at<CQ, 3, 1, false>(tile3, NPOS, IW, ly + 1, lx + 1, w_dw3, d);
+    pw_at<CQ, CQ>(w_pw, d, u[0]);
+    dw_at<CQ, 5, 1, false>(tile5, NPOS, IW, ly, lx, w_dw5, d);
+    pw_at<CQ, CQ>(w_pw + CQ * CQ, d, u[1]);
+    const long qo = ((long)n * Ho + oy) * Wo + ox;
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+          *(f32x4*)(pre + ((long)(7 + k) * P + qo) * CQ + 4 * q) = f32x4{u[k][4 * q], u[k][4 * q + 1], u[k][4 * q + 2], u[k][4 * q + 3]};
+    }
+    phase_stats<CQ, 2, 2, TPB>(u, live, red, seg, acc, 0);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * CQ; i += TPB) {
+    part[((long)blockIdx.x * 2 * CQ + i) * 2 + 0] = acc[i];
+    part[((long)blockIdx.x * 2 * CQ + i) * 2 + 1] = acc[2 * CQ + i];
+  }
+}
+
+// mean / invstd of `nslot` consecutive slots starting at slot0 from the per-workgroup fp64 partials (fixed order), plus the
+// running-statistics update of nn.BatchNorm2d (momentum m, unbiased variance) and its batch counter.  In eval mode
+// (training = 0) the statistics are the running ones and nothing is updated.  One wave per (slot, channel).
+__global__ __launch_bounds__(64) void edge_stats_finish_kernel(const double* __restrict__ part, int nblk, int nslot, int slot0, int CQ,
+                                                               long P, float eps, float momentum, int training, EdgeBN bn,
+                                                               int skip_slot, float* __restrict__ mean, float* __restrict__ invstd) {
+  const int col = blockIdx.x;                                  // local slot * CQ + c
+  const int slot = slot0 + col / CQ, c = col % CQ;
+  if (slot == skip_slot) {                                     // identity skip: no BatchNorm
+    if (threadIdx.x == 0) { mean[slot * CQ + c] = 0.f; invstd[slot * CQ + c] = 1.f; }
+    return;
+  }
+  if (!training) {
+    if (threadIdx.x == 0) {
+      mean[slot * CQ + c] = bn.run_mean[slot][c];
+      invstd[slot * CQ + c] = 1.f / sqrtf(bn.run_var[slot][c] + eps);
+    }
+    return;
+  }
+  double a = 0.0, b = 0.0;
+  for (int k = threadIdx.x; k < nblk; k += 64) { a += part[((long)k * nslot * CQ + col) * 2]; b += part[((long)k * nslot * CQ + col) * 2 + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+  if (threadIdx.x != 0) return;
+  const double m = a / (double)P;
+  double var = b / (double)P - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[slot * CQ + c] = (float)m;
+  invstd[slot * CQ + c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (bn.run_mean[slot]) {
+    const double unb = P > 1 ? var * (double)P / (double)(P - 1) : var;
+    bn.run_mean[slot][c] = (float)((1.0 - momentum) * bn.run_mean[slot][c] + momentum * m);
+    bn.run_var[slot][c] = (float)((1.0 - momentum) * bn.run_var[slot][c] + momentum * unb);
+  }
+  if (c == 0 && bn.tracked[slot]) bn.tracked[slot][0] += 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// edge_fwd_c: out[q][4i] (+)= beta * sum_k w_k bn_k(u_k[q][i]);  out[q][4i+g] (+)= beta * bypass[q][g*Cq+i]
+// thread = (output pixel, channel quad i..i+3) -> the 16 contiguous output channels 4i .. 4i+15
+// ------------------------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void edge_fwd_c_kernel(const float* __restrict__ x, const float* __restrict__ pre, const float* __restrict__ mean,
+                                  const float* __restrict__ invstd, const float* __restrict__ wsel /* [7] */,
+                                  const float* __restrict__ beta, int B, int Ho, int Wo, int CQ, float* __restrict__ out, long ldo,
+                                  int accumulate) {
+  const int NQ = CQ / 4, C = 4 * CQ;
+  const long P = (long)B * Ho * Wo;
+  const float bt = beta[0];
+  float wk[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) wk[k] = wsel[k];
+  const int slot_of[7] = {0, 1, 2, 7, 8, 5, 6};                // live branch k -> slot of its final pre-BN tensor
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < P * NQ; o += (long)gridDim.x * blockDim.x) {
+    const int q4 = (int)(o % NQ);
+    const long q = o / NQ;
+    f32x4 mix = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      if (S == 1 && k == 2) continue;
+      const int sl = slot_of[k];
+      const f32x4 v = *(const f32x4*)(pre + ((long)sl * P + q) * CQ + 4 * q4);
+      const f32x4 m = *(const f32x4*)(mean + sl * CQ + 4 * q4), is = *(const f32x4*)(invstd + sl * CQ + 4 * q4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) mix[e] = fmaf(wk[k], (v[e] - m[e]) * is[e], mix[e]);
+    }
+    f32x4 byp[3];
+    if (S == 1) {
+      const float* xp = x + q * C + 4 * q4;
+      const f32x4 x1v = *(const f32x4*)xp;
+#pragma unroll
+      for (int e = 0; e < 4; e++) mix[e] = fmaf(wk[2], x1v[e], mix[e]);
+#pragma unroll
+      for (int g = 1; g < 4; g++) byp[g - 1] = *(const f32x4*)(xp + g * CQ);
+    } else {
+      const int ox = (int)(q % Wo), oy = (int)((q / Wo) % Ho), n = (int)(q / ((long)Wo * Ho));
+      const int W = 2 * Wo, H = 2 * Ho;
+      const float* b0 = x + (((long)n * H + 2 * oy) * W + 2 * ox) * C + 4 * q4;
+      const long rs = (long)W * C;
+#pragma unroll
+      for (int g = 1; g < 4; g++) {
+        const f32x4 a = *(const f32x4*)(b0 + g * CQ), b = *(const f32x4*)(b0 + C + g * CQ);
+        const f32x4 c = *(const f32x4*)(b0 + rs + g * CQ), d = *(const f32x4*)(b0 + rs + C + g * CQ);
+#pragma unroll
+        for (int e = 0; e < 4; e++) byp[g - 1][e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
+      }
+    }
+    float* dst = out + q * ldo + 16 * q4;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      f32x4 v = {mix[e] * bt, byp[0][e] * bt, byp[1][e] * bt, byp[2][e] * bt};
+      if (accumulate) {
+        const f32x4 old = *(const f32x4*)(dst + 4 * e);
+        v += old;
+      }
+      *(f32x4*)(dst + 4 * e) = v;
+    }
+  }
+}
+
+
+// ==================================================================================================================
+// Backward.  dOut = gradient of the node's running sum (row stride ldd).  With a_k = beta * w_k the gradient entering
+// BatchNorm k is a_k * dY (dY[q][i] = dOut[q][4i]) for EVERY branch, so one pass over the pixels yields all the sums its
+// backward needs -- S0[i] = sum_q dY, S_k[i] = sum_q dY * xhat_k -- and with them the architecture gradients
+// dw_k = beta * sum_i S_k[i], dbeta = sum_k w_k sum_i S_k[i] + <dOut_bypass, bypass>.  Then
+//   g_k = d/d(u_k) = A_k (dY - c1_k - xhat_k c2_k),  A_k = a_k invstd_k, c1_k = S0 / P, c2_k = S_k / P      (training)
+// flows through the 1x1 / depthwise / pooling stencils of each branch back to x1.
+//   edge_bwd_sums    dY compact, the sums above (per-workgroup partials), the bypass part of dx
+//   edge_bwd_coef    finish: coefficients A, c1, c2 per slot; dw, dbeta
+//   edge_bwd_pools   max / avg pool, skip (identity or FactorizedReduce): dx1 =
+//   edge_bwd_conv    one (relu ->) depthwise -> 1x1 stage: dx1 += (or the gradient entering a sep_conv's first BatchNorm
+//                    + its sums), per-workgroup partial weight gradients; launched for dil3, dil5, sep3b, sep5b, then
+//                    (after edge_bwd_coef_a) sep3a, sep5a
+//   edge_wgrad_finish  fixed-order fp64 column sums of the partial weight gradients
+// ==================================================================================================================
+constexpr int COEF = 3 * 16;                                   // per slot: A[16], c1[16], c2[16]
+
+template <int S>
+__global__ __launch_bounds__(256) void edge_bwd_sums_kernel(const float* __restrict__ dout, long ldd, const float* __restrict__ x,
+                                                            const float* __restrict__ pre, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ beta,
+                                                            int B, int Ho, int Wo, int CQ, float* __restrict__ dY,
+                                                            float* __restrict__ dx, float* __restrict__ part /* [grid][8*CQ+1] */) {
+  __shared__ float red[4][33];
+  const int NQ = CQ / 4, C = 4 * CQ;
+  const long P = (long)B * Ho * Wo;
+  const float bt = beta[0];
+  const int slot_of[7] = {0, 1, 2, 7, 8, 5, 6};
+  f32x4 acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float sb = 0.f;
+  for (long o = blockIdx.x * 256L + threadIdx.x; o < P * NQ; o += gridDim.x * 256L) {
+    const int q4 = (int)(o % NQ);
+    const long q = o / NQ;
+    f32x4 D[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) D[e] = *(const f32x4*)(dout + q * ldd + 16 * q4 + 4 * e);
+    const f32x4 dy = {D[0][0], D[1][0], D[2][0], D[3][0]};
+    *(f32x4*)(dY + q * CQ + 4 * q4) = dy;
+    acc[7] += dy;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      if (S == 1 && k == 2) continue;
+      const int sl = slot_of[k];
+      const f32x4 v = *(const f32x4*)(pre + ((long)sl * P + q) * CQ + 4 * q4);
+      const f32x4 m = *(const f32x4*)(mean + sl * CQ + 4 * q4), is = *(const f32x4*)(invstd + sl * CQ + 4 * q4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc[k][e] = fmaf(dy[e], (v[e] - m[e]) * is[e], acc[k][e]);
+    }
+    if (S == 1) {
+      const float* xp = x + q * C + 4 * q4;
+      const f32x4 x1v = *(const f32x4*)xp;
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc[2][e] = fmaf(dy[e], x1v[e], acc[2][e]);
+#pragma unroll
+      for (int g = 1; g < 4; g++) {
+        const f32x4 bv = *(const f32x4*)(xp + g * CQ);
+        f32x4 gv = {D[0][g], D[1][g], D[2][g], D[3][g]};
+#pragma unroll
+        for (int e = 0; e < 4; e++) sb = fmaf(gv[e], bv[e], sb);
+        *(f32x4*)(dx + q * C + g * CQ + 4 * q4) = gv * bt;
+      }
+    } else {
+      const int ox = (int)(q % Wo), oy = (int)((q / Wo) % Ho), n = (int)(q / ((long)Wo * Ho));
+      const int W = 2 * Wo, H = 2 * Ho;
+      const long base = (((long)n * H + 2 * oy) * W + 2 * ox) * C + 4 * q4;
+      const long rs = (long)W * C;
+#pragma unroll
+      for (int g = 1; g < 4; g++) {
+        const f32x4 a = *(const f32x4*)(x + base + g * CQ), b = *(const f32x4*)(x + base + C + g * CQ);
+        const f32x4 c = *(const f32x4*)(x + base + rs + g * CQ), d = *(const f32x4*)(x + base + rs + C + g * CQ);
+        f32x4 ga = {0.f, 0.f, 0.f, 0.f}, gb = ga, gc = ga, gd = ga;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          // first maximum in scan order (a, b, c, d), like MaxPool2d(2, 2)
+          int best = 0; float bv = a[e];
+          if (b[e] > bv) { bv = b[e]; best = 1; }
+          if (c[e] > bv) { bv = c[e]; best = 2; }
+          if (d[e] > bv) { bv = d[e]; best = 3; }
+          const float gr = D[e][g];
+          sb = fmaf(gr, bv, sb);
+          const float v = gr * bt;
+          ga[e] = best == 0 ? v : 0.f; gb[e] = best == 1 ? v : 0.f; gc[e] = best == 2 ? v : 0.f; gd[e] = best == 3 ? v : 0.f;
+        }
+        *(f32x4*)(dx + base + g * CQ) = ga; *(f32x4*)(dx + base + C + g * CQ) = gb;
+        *(f32x4*)(dx + base + rs + g * CQ) = gc; *(f32x4*)(dx + base + rs + C + g * CQ) = gd;
+      }
+    }
+  }
+  // lanes with equal (lane % NQ) hold the same channel quad: fold those lanes, then the four waves
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float vals[33];
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) vals[k * 4 + e] = acc[k][e];
+  vals[32] = sb;
+#pragma unroll
+  for (int i = 0; i < 33; i++) {
+    float v = vals[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+      if (o >= NQ || i == 32) v += __shfl_xor(v, o, 64);
+    vals[i] = v;
+  }
+  float* out = part + (long)blockIdx.x * (8 * CQ + 1);
+  for (int qd = 0; qd < NQ; qd++) {
+    __syncthreads();
+    if (lane == qd) {
+#pragma unroll
+      for (int i = 0; i < 32; i++) red[wv][i] = vals[i];
+      if (qd == 0) red[wv][32] = vals[32];
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      const int k = threadIdx.x / 4, e = threadIdx.x % 4;
+      out[k * CQ + 4 * qd + e] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    }
+    if (qd == 0 && threadIdx.x == 32) out[8 * CQ] = red[0][32] + red[1][32] + red[2][32] + red[3][32];
+  }
+}
+
+// one workgroup: sums of the partials (fixed order, fp64) -> coefficients of the seven final slots, dw[7], dbeta
+__global__ __launch_bounds__(256) void edge_bwd_coef_kernel(const float* __restrict__ part, int nblk, int CQ, long P, int S, int training,
+                                                            const float* __restrict__ wsel, const float* __restrict__ beta,
+                                                            const float* __restrict__ invstd, float* __restrict__ coef,
+                                                            float* __restrict__ dw, float* __restrict__ dbeta) {
+  __shared__ double tot[8 * 16 + 1];
+  const int ncol = 8 * CQ + 1;
+  for (int col = threadIdx.x; col < ncol; col += 256) {
+    double a = 0.0;
+    for (int b = 0; b < nblk; b++) a += (double)part[(long)b * ncol + col];
+    tot[col] = a;
+  }
+  __syncthreads();
+  const int slot_of[7] = {0, 1, 2, 7, 8, 5, 6};
+  const float bt = beta[0];
+  if (threadIdx.x < 7 * CQ) {
+    const int k = threadIdx.x / CQ, c = threadIdx.x % CQ, sl = slot_of[k];
+    const bool ident = (S == 1 && k == 2);
+    float* cf = coef + sl * COEF;
+    cf[c] = bt * wsel[k] * (ident ? 1.f : invstd[sl * CQ + c]);
+    cf[16 + c] = (training && !ident) ? (float)(tot[7 * CQ + c] / (double)P) : 0.f;
+    cf[32 + c] = (training && !ident) ? (float)(tot[k * CQ + c] / (double)P) : 0.f;
+  }
+  if (threadIdx.x == 0) {
+    double db = tot[8 * CQ];
+    for (int k = 0; k < 7; k++) {
+      double sk = 0.0;
+      for (int c = 0; c < CQ; c++) sk += tot[k * CQ + c];
+      dw[k] = (float)(bt * sk);
+      db += (double)wsel[k] * sk;
+    }
+    dbeta[0] = (float)db;
+  }
+}
+
+// coefficients of a sep_conv's FIRST BatchNorm (slots 3, 4) from the partial sums its second stage's backward left:
+// A = invstd, c1 = sum dBN / P, c2 = sum dBN * xhat / P
+__global__ __launch_bounds__(64) void edge_bwd_coef_a_kernel(const double* __restrict__ part /* [2][grid][2*CQ][2] */, int nblk, int CQ,
+                                                             long P, int training, const float* __restrict__ invstd,
+                                                             float* __restrict__ coef) {
+  const int which = blockIdx.x / CQ, c = blockIdx.x % CQ;       // which: 0 sep3 (slot 3), 1 sep5 (slot 4)
+  const double* pp = part + (long)which * nblk * 2 * CQ * 2;
+  double a = 0.0, b = 0.0;
+  for (int k = threadIdx.x; k < nblk; k += 64) { a += pp[((long)k * 2 * CQ + c) * 2]; b += pp[((long)k * 2 * CQ + CQ + c) * 2]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+  if (threadIdx.x != 0) return;
+  float* cf = coef + (3 + which) * COEF;
+  cf[c] = invstd[(3 + which) * CQ + c];
+  cf[16 + c] = training ? (float)(a / (double)P) : 0.f;
+  cf[32 + c] = training ? (float)(b / (double)P) : 0.f;
+}
+
+// g[oc] = A (dY - c1 - xhat c2) for one pixel, all CQ channels (rows of dY / u read from memory)
+template <int CQ>
+__device__ __forceinline__ void grad_row(const float* __restrict__ dyr, const float* __restrict__ ur, const float* __restrict__ ms /* LDS: mean[CQ], invstd[CQ] */,
+                                         const float* __restrict__ cf /* LDS: A[16], c1[16], c2[16] */, float* __restrict__ g) {
+#pragma unroll
+  for (int q = 0; q < CQ / 4; q++) {
+    const f32x4 d = *(const f32x4*)(dyr + 4 * q), u = *(const f32x4*)(ur + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int c = 4 * q + e;
+      const float xh = (u[e] - ms[c]) * ms[CQ + c];
+      g[c] = cf[c] * (d[e] - cf[16 + c] - xh * cf[32 + c]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// edge_bwd_pools: dx1 = backward of max_pool (slot 0), avg_pool (slot 1) and skip_connect (slot 2).  Tile = TH x TW INPUT
+// pixels (one thread each, all Cq channels); gradient tiles g0, g1 of the covering output pixels and an x1 tile with halo 2
+// (the windows of the neighbouring outputs) in LDS.  FactorizedReduce weight gradients: per-workgroup partials.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CQ, int S, int TH, int TW>
+__global__ __launch_bounds__(TH * TW) void edge_bwd_pools_kernel(const float* __restrict__ x, const float* __restrict__ dY,
+                                                                 const float* __restrict__ pre, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                                 int B, int H, int W, EdgeW wts, float* __restrict__ dx,
+                                                                 float* __restrict__ wpart, int wtot, int fr_off) {
+  constexpr int TPB = TH * TW, NQ = CQ / 4, C = 4 * CQ;
+  constexpr int XH = TH + 4, XW = TW + 4, XN = XH * XW;         // x1 tile, halo 2
+  constexpr int GH = TH / S + 2, GW = TW / S + 2, GN = GH * GW;   // gradient tiles: outputs (ty0/S - 1) .. (ty0/S + TH/S)
+  extern __shared__ __align__(16) unsigned char smem[];
+  f32x4* xt = (f32x4*)smem;                                     // [NQ][XN]
+  f32x4* g0t = xt + NQ * XN;                                    // [NQ][GN]
+  f32x4* g1t = g0t + NQ * GN;
+  float* ms = (float*)(g1t + NQ * GN);                         // mean/invstd of slots 0,1,2: [3][2][CQ]
+  float* cf = ms + 6 * CQ;                                     // coef of slots 0,1,2: [3][48]
+  float* w_fr = cf + 3 * COEF;                                 // [2][CQ/2][CQ]
+  float* Gs = w_fr + CQ * CQ;                                  // S == 2: g2 rows of the tile's outputs [TPB/4][CQ]
+  float* R0 = Gs + (TPB / 4) * CQ;                             //         relu(x1) at the even / odd taps [TPB/4][CQ] each
+  float* R1 = R0 + (TPB / 4) * CQ;
+  const int Ho = H / S, Wo = W / S;
+  const long P = (long)B * Ho * Wo;
+  for (int i = threadIdx.x; i < 3 * CQ; i += TPB) {
+    const int k = i / CQ, c = i % CQ;
+    ms[k * 2 * CQ + c] = mean[k * CQ + c];
+    ms[k * 2 * CQ + CQ + c] = invstd[k * CQ + c];
+  }
+  for (int i = threadIdx.x; i < 3 * COEF; i += TPB) cf[i] = coef[i];
+  if (S == 2) { stage_weights(w_fr, wts.fr[0], CQ / 2 * CQ); stage_weights(w_fr + CQ / 2 * CQ, wts.fr[1], CQ / 2 * CQ); }
+  float acc_fr = 0.f;                                          // thread (oc, c) of the two FactorizedReduce weight gradients
+  const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
+  const long ntiles = (long)B * tiles_y * tiles_x;
+  const int ly = threadIdx.x / TW, lx = threadIdx.x % TW;
+  for (long tidx = blockIdx.x; tidx < ntiles; tidx += gridDim.x) {
+    const int n = (int)(tidx / (tiles_y * tiles_x));
+    const int tr = (int)(tidx % (tiles_y * tiles_x));
+    const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+    const int gy0 = ty0 / S - 1, gx0 = tx0 / S - 1;             // first output row / column of the gradient tiles
+    __syncthreads();
+    load_tile<NQ, 0>(xt, x, C, n, H, W, ty0 - 2, tx0 - 2, XH, XW, nullptr, nullptr);
+    for (int idx = threadIdx.x; idx < GN; idx += TPB) {
+      const int gy = gy0 + idx / GW, gx = gx0 + idx % GW;
+      float a[CQ], b[CQ];
+      if (gy >= 0 && gy < Ho && gx >= 0 && gx < Wo) {
+        const long q = ((long)n * Ho + gy) * Wo + gx;
+        grad_row<CQ>(dY + q * CQ, pre + (0 * P + q) * CQ, ms, cf, a);
+        grad_row<CQ>(dY + q * CQ, pre + (1 * P + q) * CQ, ms + 2 * CQ, cf + COEF, b);
+      } else {
+#pragma unroll
+        for (int c = 0; c < CQ; c++) { a[c] = 0.f; b[c] = 0.f; }
+      }
+#pragma unroll
+      for (int q4 = 0; q4 < NQ; q4++) {
+        g0t[q4 * GN + idx] = f32x4{a[4 * q4], a[4 * q4 + 1], a[4 * q4 + 2], a[4 * q4 + 3]};
+        g1t[q4 * GN + idx] = f32x4{b[4 * q4], b[4 * q4 + 1], b[4 * q4 + 2], b[4 * q4 + 3]};
+      }
+    }
+    __syncthreads();
+    const int iy = ty0 + ly, ix = tx0 + lx;
+    const bool live = iy < H && ix < W;
+    float dxv[CQ];
+    // ---- pools: every output window (oy, ox) that contains (iy, ix) ----
+    const int oy_lo = (iy - 1 + S - 1) / S, oy_hi = min((iy + 1) / S, Ho - 1);    // ceil((iy-1)/S) .. floor((iy+1)/S)
+    const int ox_lo = (ix - 1 + S - 1) / S, ox_hi = min((ix + 1) / S, Wo - 1);
+#pragma unroll
+    for (int q4 = 0; q4 < NQ; q4++) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      if (live) {
+        const f32x4 xp = xt[q4 * XN + (ly + 2) * XW + lx + 2];
+        for (int oy = max(oy_lo, 0); oy <= oy_hi; oy++)
+          for (int ox = max(ox_lo, 0); ox <= ox_hi; ox++) {
+            const int gi = (oy - gy0) * GW + (ox - gx0);
+            const f32x4 gmax = g0t[q4 * GN + gi], gavg = g1t[q4 * GN + gi];
+            // window of (oy, ox): rows S*oy-1 .. S*oy+1 clipped to the image
+            const int wy0 = max(S * oy - 1, 0), wy1 = min(S * oy + 1, H - 1), wx0 = max(S * ox - 1, 0), wx1 = min(S * ox + 1, W - 1);
+            const float inv = 1.f / (float)((wy1 - wy0 + 1) * (wx1 - wx0 + 1));
+            // (iy, ix) is the window's FIRST maximum iff nothing before it (scan order) is >= and nothing after it is >
+            bool first[4] = {true, true, true, true};
+            for (int yy = wy0; yy <= wy1; yy++)
+              for (int xx = wx0; xx <= wx1; xx++) {
+                const f32x4 v = xt[q4 * XN + (yy - ty0 + 2) * XW + (xx - tx0 + 2)];
+                const bool before = (yy < iy) || (yy == iy && xx < ix);
+#pragma unroll
+                for (int e = 0; e < 4; e++) first[e] = first[e] && (before ? (v[e] < xp[e]) : (v[e] <= xp[e]));
+              }
+#pragma unroll
+            for (int e = 0; e < 4; e++) a[e] += (first[e] ? gmax[e] : 0.f) + gavg[e] * inv;
+          }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) dxv[4 * q4 + e] = a[e];
+    }
+    // ---- skip_connect ----
+    if (S == 1) {
+      if (live) {
+        const long q = ((long)n * H + iy) * W + ix;
+#pragma unroll
+        for (int q4 = 0; q4 < NQ; q4++) {
+          const f32x4 d = *(const f32x4*)(dY + q * CQ + 4 * q4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) dxv[4 * q4 + e] = fmaf(cf[2 * COEF + 4 * q4 + e], d[e], dxv[4 * q4 + e]);
+        }
+      }
+    } else {
+      // FactorizedReduce: output (iy/2, ix/2) reads relu(x1) at (even, even) through conv_1 and at (odd, odd) through conv_2
+      const bool even = !(iy & 1) && !(ix & 1), odd = (iy & 1) && (ix & 1);
+      float g2[CQ];
+      const int oy = iy >> 1, ox = ix >> 1;
+      if (live && (even || odd)) {
+        const long q = ((long)n * Ho + oy) * Wo + ox;
+        grad_row<CQ>(dY + q * CQ, pre + (2 * P + q) * CQ, ms + 4 * CQ, cf + 2 * COEF, g2);
+        const float* wf = w_fr + (odd ? CQ / 2 * CQ : 0);
+        const int o0 = odd ? CQ / 2 : 0;
+#pragma unroll
+        for (int q4 = 0; q4 < NQ; q4++) {
+          const f32x4 xp = xt[q4 * XN + (ly + 2) * XW + lx + 2];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int c = 4 * q4 + e;
+            float a = 0.f;
+#pragma unroll
+            for (int oc = 0; oc < CQ / 2; oc++) a = fmaf(wf[oc * CQ + c], g2[o0 + oc], a);
+            if (xp[e] > 0.f) dxv[c] += a;
+          }
+        }
+      }
+      // weight gradients: stage g2 and the two relu'd taps of every output of this tile, then thread (oc, c) sums over them
+      __syncthreads();
+      {
+        const int lo = (ly >> 1) * (TW / 2) + (lx >> 1);          // local output index of this thread's 2x2 cell
+        if (even) {
+#pragma unroll
+          for (int c = 0; c < CQ; c++) Gs[lo * CQ + c] = live ? g2[c] : 0.f;
+        }
+        if (even || odd) {
+          float* R = even ? R0 : R1;
+#pragma unroll
+          for (int q4 = 0; q4 < NQ; q4++) {
+            const f32x4 v = relu4(xt[q4 * XN + (ly + 2) * XW + lx + 2]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) R[lo * CQ + 4 * q4 + e] = live ? v[e] : 0.f;
+          }
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x < CQ * CQ) {
+        const int oc = threadIdx.x / CQ, c = threadIdx.x % CQ;
+        const float* R = oc < CQ / 2 ? R0 : R1;
+        float a = 0.f;
+        for (int o = 0; o < TPB / 4; o++) a = fmaf(Gs[o * CQ + oc], R[o * CQ + c], a);
+        acc_fr += a;
+      }
+    }
+    if (live) store_row<CQ>(dx + (((long)n * H + iy) * W + ix) * C, dxv);
+  }
+  if (S == 2 && threadIdx.x < CQ * CQ) wpart[(long)blockIdx.x * wtot + fr_off + threadIdx.x] = acc_fr;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// edge_bwd_conv: backward of one (relu ->) depthwise K x K (stride S, dilation DIL) -> 1x1 stage.
+//   MODE 0  input relu(x1) (row stride C); output gradient from (dY, u, coef);  dx1 +=
+//   MODE 1  input relu(bn_a(t)) (second stage of a sep_conv, S = 1);  writes dBN = d/d(bn_a(t)) and its BatchNorm-backward sums
+//   MODE 2  input relu(x1); output gradient from (dBN, t, coef_a) (first stage of a sep_conv);  dx1 +=
+// Tile = TH x TW OUTPUT pixels.  LDS: the activated input tile (forward halo), the tile of dd = Wpw^T g over the outputs that
+// reach the owned input pixels (backward halo), and the per-pixel rows g, d (depthwise output) for the 1x1 weight gradient.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CQ, int K, int DIL, int S, int MODE, int TH, int TW>
+__global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __restrict__ in, long ldin, const float* __restrict__ gsrc /* dY or dBN */,
+                                                                const float* __restrict__ usrc /* u or t: pre-BN output of this stage */,
+                                                                const float* __restrict__ mean_o, const float* __restrict__ invstd_o,
+                                                                const float* __restrict__ coef_o, const float* __restrict__ mean_i,
+                                                                const float* __restrict__ invstd_i, const float* __restrict__ w_dw,
+                                                                const float* __restrict__ w_pw, int B, int H, int W,
+                                                                float* __restrict__ dst /* dx (MODE 0, 2) or dBN [P][CQ] (MODE 1) */,
+                                                                double* __restrict__ spart /* MODE 1: [grid][2*CQ][2] */,
+                                                                float* __restrict__ wpart, int wtot, int dw_off, int pw_off) {
+  constexpr int TPB = TH * TW, NQ = CQ / 4, KK = K * K, PAD = DIL * (K - 1) / 2, HB = (PAD + S - 1) / S;
+  constexpr int IH = S * (TH - 1) + 2 * PAD + 1, IW = S * (TW - 1) + 2 * PAD + 1, IN = IH * IW;
+  constexpr int DH = TH + 2 * HB, DW = TW + 2 * HB, DN = DH * DW;
+  constexpr int NDW = (CQ * KK + TPB - 1) / TPB;                // depthwise weight-gradient entries per thread
+  constexpr int SL = TPB >= CQ * CQ ? TPB / (CQ * CQ) : 1;      // pixel slices of the 1x1 weight gradient
+  constexpr int NPW = TPB >= CQ * CQ ? 1 : CQ * CQ / TPB;       // its entries per thread (narrow tiles at Cq = 16: 2)
+  extern __shared__ __align__(16) unsigned char smem[];
+  f32x4* rt = (f32x4*)smem;                                     // [NQ][IN] activated input
+  f32x4* ddt = rt + NQ * IN;                                    // [NQ][DN]
+  float* Gs = (float*)(ddt + NQ * DN);                         // [TPB][CQ]
+  float* Ds = Gs + TPB * CQ;                                   // [TPB][CQ]
+  float* wdl = Ds + TPB * CQ;                                  // [CQ][KK]
+  float* wpl = wdl + CQ * KK;                                  // [CQ][CQ]
+  float* mso = wpl + CQ * CQ;                                  // mean/invstd of the stage's output BN [2][CQ]
+  float* cfo = mso + 2 * CQ;                                   // its coefficients [48]
+  float* msi = cfo + COEF;                                     // MODE 1: mean/invstd of the input BN [2][CQ]
+  float* red = msi + 2 * CQ;                                   // MODE 1: [8][TPB+1]
+  float* seg = red + (MODE == 1 ? 8 * (TPB + 1) : 0);          // MODE 1: [2][8][8]
+  double* acc = (double*)(seg + (MODE == 1 ? 128 : 0));        // MODE 1: [2][2*CQ]
+  stage_weights(wdl, w_dw, CQ * KK);
+  stage_weights(wpl, w_pw, CQ * CQ);
+  for (int i = threadIdx.x; i < CQ; i += TPB) {
+    mso[i] = mean_o[i]; mso[CQ + i] = invstd_o[i];
+    if (MODE == 1) { msi[i] = mean_i[i]; msi[CQ + i] = invstd_i[i]; }
+  }
+  for (int i = threadIdx.x; i < COEF; i += TPB) cfo[i] = coef_o[i];
+  if (MODE == 1)
+    for (int i = threadIdx.x; i < 4 * CQ; i += TPB) acc[i] = 0.0;
+  const int Ho = H / S, Wo = W / S;
+  const int tiles_y = (Ho + TH - 1) / TH, tiles_x = (Wo + TW - 1) / TW;
+  const long ntiles = (long)B * tiles_y * tiles_x;
+  const int ly = threadIdx.x / TW, lx = threadIdx.x % TW;
+  float acc_dw[NDW];
+#pragma unroll
+  for (int i = 0; i < NDW; i++) acc_dw[i] = 0.f;
+  float acc_pw[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; i++) acc_pw[i] = 0.f;
+  for (long tidx = blockIdx.x; tidx < ntiles; tidx += gridDim.x) {
+    const int n = (int)(tidx / (tiles_y * tiles_x));
+    const int tr = (int)(tidx % (tiles_y * tiles_x));
+    const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+    __syncthreads();
+    // activated input tile
+    load_tile<NQ, MODE == 1 ? 2 : 1>(rt, in, ldin, n, H, W, S * ty0 - PAD, S * tx0 - PAD, IH, IW, msi, msi + CQ);
+    // dd = Wpw^T g over the outputs (ty0 - HB .. ty0 + TH - 1 + HB)
+    for (int idx = threadIdx.x; idx < DN; idx += TPB) {
+      const int oy = ty0 - HB + idx / DW, ox = tx0 - HB + idx % DW;
+      float dd[CQ];
+      if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) {
+        const long q = ((long)n * Ho + oy) * Wo + ox;
+        float g[CQ];
+        grad_row<CQ>(gsrc + q * CQ, usrc + q * CQ, mso, cfo, g);
+#pragma unroll
+        for (int c = 0; c < CQ; c++) {
+          float a = 0.f;
+#pragma unroll
+          for (int oc = 0; oc < CQ; oc++) a = fmaf(wpl[oc * CQ + c], g[oc], a);
+          dd[c] = a;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CQ; c++) dd[c] = 0.f;
+      }
+#pragma unroll
+      for (int q4 = 0; q4 < NQ; q4++) ddt[q4 * DN + idx] = f32x4{dd[4 * q4], dd[4 * q4 + 1], dd[4 * q4 + 2], dd[4 * q4 + 3]};
+    }
+    __syncthreads();
+    const int oy = ty0 + ly, ox = tx0 + lx;
+    const bool live = oy < Ho && ox < Wo;
+    // ---- own output pixel: g and the recomputed depthwise output d, staged for the 1x1 weight gradient ----
+    {
+      float g[CQ], d[CQ];
+      if (live) {
+        const long q = ((long)n * Ho + oy) * Wo + ox;
+        grad_row<CQ>(gsrc + q * CQ, usrc + q * CQ, mso, cfo, g);
+        dw_at<CQ, K, DIL, false>(rt, IN, IW, S * ly, S * lx, wdl, d);
+      } else {
+#pragma unroll
+        for (int c = 0; c < CQ; c++) { g[c] = 0.f; d[c] = 0.f; }
+      }
+#pragma unroll
+      for (int c = 0; c < CQ; c++) { Gs[threadIdx.x * CQ + c] = g[c]; Ds[threadIdx.x * CQ + c] = d[c]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NPW; i++) {
+      const int t = threadIdx.x + i * TPB;
+      if (t < SL * CQ * CQ) {
+        const int e = t % (CQ * CQ), sl = t / (CQ * CQ);
+        const int oc = e / CQ, c = e % CQ;
+        float a = 0.f;
+        for (int p = sl; p < TPB; p += SL) a = fmaf(Gs[p * CQ + oc], Ds[p * CQ + c], a);
+        acc_pw[i] += a;
+      }
+    }
+    // ---- depthwise weight gradient: entry (c, tap) sums dd[o][c] * r[S*o - PAD + DIL*tap][c] over the tile's outputs ----
+#pragma unroll
+    for (int i = 0; i < NDW; i++) {
+      const int ent = threadIdx.x + i * TPB;
+      if (ent < CQ * KK) {
+        const int c = ent / KK, tap = ent % KK, tj = tap / K, ti = tap % K;
+        const float* rp = (const float*)(rt + (c >> 2) * IN) + (c & 3);
+        const float* dp = (const float*)(ddt + (c >> 2) * DN) + (c & 3);
+        float a = 0.f;
+        for (int py = 0; py < TH; py++)
+          for (int px = 0; px < TW; px++)
+            a = fmaf(dp[((py + HB) * DW + px + HB) * 4], rp[((S * py + DIL * tj) * IW + S * px + DIL * ti) * 4], a);
+        acc_dw[i] += a;
+      }
+    }
+    // ---- input gradient at the owned input pixels (S*oy + a, S*ox + b): gather over the taps ----
+    float stat[2][CQ];
+#pragma unroll
+    for (int a = 0; a < S; a++)
+#pragma unroll
+      for (int b = 0; b < S; b++) {
+        const int iy = S * oy + a, ix = S * ox + b;
+        float din[CQ];
+#pragma unroll
+        for (int q4 = 0; q4 < NQ; q4++) {
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            const int ty = a + PAD - DIL * j;
+            if (ty % S != 0) continue;
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+              const int tx = b + PAD - DIL * i;
+              if (tx % S != 0) continue;
+              const f32x4 v = ddt[q4 * DN + (ly + HB + ty / S) * DW + lx + HB + tx / S];
+#pragma unroll
+              for (int e = 0; e < 4; e++) sacc[e] = fmaf(wdl[(4 * q4 + e) * KK + j * K + i], v[e], sacc[e]);
+            }
+          }
+          const f32x4 r = rt[q4 * IN + (S * ly + a + PAD) * IW + S * lx + b + PAD];
+#pragma unroll
+          for (int e = 0; e < 4; e++) din[4 * q4 + e] = r[e] > 0.f ? sacc[e] : 0.f;
+          if (MODE == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { stat[0][4 * q4 + e] = din[4 * q4 + e]; stat[1][4 * q4 + e] = din[4 * q4 + e] * r[e]; }
+          }
+        }
+        if (live && iy < H && ix < W) {
+          if (MODE == 1) store_row<CQ>(dst + (((long)n * H + iy) * W + ix) * CQ, din);
+          else {
+            float* dp = dst + (((long)n * H + iy) * W + ix) * ldin;
+#pragma unroll
+            for (int q4 = 0; q4 < NQ; q4++) {
+              f32x4 o = *(const f32x4*)(dp + 4 * q4);
+              o += f32x4{din[4 * q4], din[4 * q4 + 1], din[4 * q4 + 2], din[4 * q4 + 3]};
+              *(f32x4*)(dp + 4 * q4) = o;
+            }
+          }
+        }
+      }
+    if (MODE == 1) phase_stats<CQ, 2, 2, TPB>(stat, live, red, seg, acc, 0);
+  }
+  // ---- per-workgroup partial weight gradients ----
+  __syncthreads();
+  float* wrow = wpart + (long)blockIdx.x * wtot;
+#pragma unroll
+  for (int i = 0; i < NDW; i++) {
+    const int ent = threadIdx.x + i * TPB;
+    if (ent < CQ * KK) wrow[dw_off + ent] = acc_dw[i];
+  }
+  if (SL > 1) {
+    Gs[threadIdx.x] = acc_pw[0];
+    __syncthreads();
+    if (threadIdx.x < CQ * CQ) {
+      float a = 0.f;
+      for (int sl = 0; sl < SL; sl++) a += Gs[sl * CQ * CQ + threadIdx.x];
+      wrow[pw_off + threadIdx.x] = a;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NPW; i++)
+      if (threadIdx.x + i * TPB < CQ * CQ) wrow[pw_off + threadIdx.x + i * TPB] = acc_pw[i];
+  }
+  if (MODE == 1) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * CQ; i += TPB) {
+      spart[((long)blockIdx.x * 2 * CQ + i) * 2 + 0] = acc[i];
+      spart[((long)blockIdx.x * 2 * CQ + i) * 2 + 1] = acc[2 * CQ + i];
+    }
+  }
+}
+
+// out[col] = sum over the workgroups' partial rows (fixed order, fp64); columns lo..hi-1 only
+__global__ __launch_bounds__(64) void edge_wgrad_finish_kernel(const float* __restrict__ part, int nblk, int wtot, int lo,
+                                                               float* __restrict__ out) {
+  const int col = lo + blockIdx.x;
+  double a = 0.0;
+  for (int k = threadIdx.x; k < nblk; k += 64) a += (double)part[(long)k * wtot + col];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (threadIdx.x == 0) out[col] = (float)a;
+}
+
+template <int CQ, int S, int TH, int TW>
+size_t bwd_pools_lds() {
+  constexpr int TPB = TH * TW, NQ = CQ / 4, XN = (TH + 4) * (TW + 4), GN = (TH / S + 2) * (TW / S + 2);
+  size_t floats = (size_t)NQ * XN * 4 + 2 * NQ * GN * 4 + 6 * CQ + 3 * COEF + CQ * CQ + 3 * (TPB / 4) * CQ;
+  return floats * 4 + 16;
+}
+template <int CQ, int K, int DIL, int S, int MODE, int TH, int TW>
+size_t bwd_conv_lds() {
+  constexpr int TPB = TH * TW, NQ = CQ / 4, KK = K * K, PAD = DIL * (K - 1) / 2, HB = (PAD + S - 1) / S;
+  constexpr int IN = (S * (TH - 1) + 2 * PAD + 1) * (S * (TW - 1) + 2 * PAD + 1), DN = (TH + 2 * HB) * (TW + 2 * HB);
+  size_t floats = (size_t)NQ * IN * 4 + NQ * DN * 4 + 2 * TPB * CQ + CQ * KK + CQ * CQ + 2 * CQ + COEF + 2 * CQ;
+  if (MODE == 1) floats += 8 * (TPB + 1) + 128 + 1;
+  return floats * 4 + (MODE == 1 ? 4 * CQ * 8 : 0) + 16;
+}
+
+template <int CQ, int S, int TH, int TW>
+size_t fwd_a_lds() {
+  constexpr int TPB = TH * TW, NQ = CQ / 4, IH = S * (TH - 1) + 9, IW = S * (TW - 1) + 9;
+  size_t floats = (size_t)NQ * IH * IW * 4 + CQ * 68 + 4 * CQ * CQ + CQ * CQ + 12 * (TPB + 1) + 2 * 12 * 8;
+  return floats * 4 + 2 * 7 * CQ * 8 + 16;
+}
+template <int CQ, int TH, int TW>
+size_t fwd_b_lds() {
+  constexpr int TPB = TH * TW, NQ = CQ / 4, IH = TH + 4, IW = TW + 4;
+  size_t floats = (size_t)2 * NQ * IH * IW * 4 + CQ * 34 + 2 * CQ * CQ + 4 * CQ + 8 * (TPB + 1) + 128;
+  return floats * 4 + 4 * CQ * 8 + 16;
+}
+
+int persistent_grid(long ntiles, int per_cu) {
+  long g = 256L * per_cu;
+  if (g > ntiles) g = ntiles;
+  return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" {
+
+// 1 when the fused edge kernels take this shape (Cq in {4, 8, 16}; stride-2 edges need even H, W), else 0
+int lctvqa_mixed_edge_supported(int B, int H, int W, int C, int stride) {
+  const int CQ = C / 4;
+  if (C % 16 != 0 || (CQ != 4 && CQ != 8 && CQ != 16)) return 0;
+  if (stride == 2) return (H % 2 == 0 && W % 2 == 0 && H >= 2 && W >= 2) ? 1 : 0;
+  return stride == 1 ? 1 : 0;
+}
+// number of workgroups every tile kernel of an edge is launched with (= rows of the partial-sum buffers): enough for the
+// larger of its two tile grids (output pixels; input pixels in the pooling backward), at most four per CU
+int lctvqa_mixed_edge_grid(int B, int H, int W, int C, int stride) {
+  const int Ho = H / stride, Wo = W / stride, CQ = C / 4;
+  const int TH = 8, TW = (stride == 2 && CQ == 16) ? 16 : 32;
+  const long t_out = (long)B * ((Ho + TH - 1) / TH) * ((Wo + TW - 1) / TW);
+  const long t_in = (long)B * ((H + 7) / 8) * ((W + 31) / 32);
+  return persistent_grid(t_out > t_in ? t_out : t_in, 4);
+}
+// floats of the flat weight-gradient vector: dw[6] (9, 25, 9, 25, 9, 25 taps x Cq), pw[6] (Cq x Cq), fr[2] (Cq/2 x Cq)
+int lctvqa_mixed_edge_wgrad_elems(int C) {
+  const int CQ = C / 4;
+  return 102 * CQ + 7 * CQ * CQ;
+}
+long lctvqa_mixed_edge_bwd_scratch_floats(int B, int H, int W, int C, int stride) {
+  const int CQ = C / 4;
+  const long P = (long)B * (H / stride) * (W / stride);
+  const long G = lctvqa_mixed_edge_grid(B, H, W, C, stride);
+  return 3 * P * CQ + 1024L * (8 * CQ + 1) + 9 * COEF + G * lctvqa_mixed_edge_wgrad_elems(C) + 2 * (2 * G * 2 * CQ * 2) + 8;
+}
+
+// Forward of one edge.  w: 14 pointers = dw[6], pw[6], fr[2] (fr null on stride-1 edges); bn: 27 pointers = run_mean[9],
+// run_var[9], tracked[9] (null for the identity skip); pre [9][P][Cq]; stats mean/invstd [9][Cq]; part: fp64 scratch of
+// grid * 7*Cq * 2 doubles; wsel [7] live architecture weights (PRIMITIVES order without 'none'); beta [1]; out row stride ldo.
+int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride, const void* const* w, void* const* bn,
+                          float* pre, float* mean, float* invstd, double* part, const float* wsel, const float* beta,
+                          float* out, long ldo, int accumulate, int training, float momentum, float eps, void* stream) {
+  LCT_REQUIRE(lctvqa_mixed_edge_supported(B, H, W, C, stride), "mixed_edge_fwd: unsupported shape B=%d H=%d W=%d C=%d s=%d", B, H, W, C, stride);
+  LCT_REQUIRE((((uintptr_t)x | (uintptr_t)pre | (uintptr_t)out | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0 && (ldo & 3) == 0,
+              "mixed_edge_fwd: tensors must be 16-B aligned");
+  hipStream_t st = (hipStream_t)stream;
+  EdgeW ew;
+  EdgeBN eb;
+  for (int i = 0; i < 6; i++) { ew.dw[i] = (const float*)w[i]; ew.pw[i] = (const float*)w[6 + i]; }
+  ew.fr[0] = (const float*)w[12]; ew.fr[1] = (const float*)w[13];
+  for (int i = 0; i < NSLOT; i++) { eb.run_mean[i] = (float*)bn[i]; eb.run_var[i] = (float*)bn[9 + i]; eb.tracked[i] = (long*)bn[18 + i]; }
+  const int CQ = C / 4, Ho = H / stride, Wo = W / stride;
+  const long P = (long)B * Ho * Wo;
+  const int grid = lctvqa_mixed_edge_grid(B, H, W, C, stride);
+  const int skip_slot = stride == 1 ? 2 : -1;
+#define EDGE_A(CQv, Sv, THv, TWv)                                                                                          \
+  {                                                                                                                        \
+    static bool attr = false;                                                                                              \
+    const size_t lds = fwd_a_lds<CQv, Sv, THv, TWv>();                                                                     \
+    if (!attr) { hipFuncSetAttribute((const void*)edge_fwd_a_kernel<CQv, Sv, THv, TWv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
+    hipLaunchKernelGGL((edge_fwd_a_kernel<CQv, Sv, THv, TWv>), dim3(grid), dim3(THv * TWv), lds, st, x, B, H, W, ew, pre, part); \
+  }
+#define EDGE_B(CQv, THv, TWv)                                                                                              \
+  {                                                                                                                        \
+    static bool attr = false;                                                                                              \
+    const size_t lds = fwd_b_lds<CQv, THv, TWv>();                                                                         \
+    if (!attr) { hipFuncSetAttribute((const void*)edge_fwd_b_kernel<CQv, THv, TWv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
+    hipLaunchKernelGGL((edge_fwd_b_kernel<CQv, THv, TWv>), dim3(grid), dim3(THv * TWv), lds, st, B, Ho, Wo, ew, mean, invstd, pre, part); \
+  }
+  if (CQ == 4 && stride == 1) EDGE_A(4, 1, 8, 32)
+  else if (CQ == 4) EDGE_A(4, 2, 8, 32)
+  else if (CQ == 8 && stride == 1) EDGE_A(8, 1, 8, 32)
+  else if (CQ == 8) EDGE_A(8, 2, 8, 32)
+  else if (stride == 1) EDGE_A(16, 1, 8, 32)
+  else EDGE_A(16, 2, 8, 16)
+  int rc = lct_check_launch("edge_fwd_a");
+  if (rc) return rc;
+  hipLaunchKernelGGL(edge_stats_finish_kernel, dim3(7 * CQ), dim3(64), 0, st, part, grid, 7, 0, CQ, P, eps, momentum, training, eb,
+                     skip_slot, mean, invstd);
+  if ((rc = lct_check_launch("edge_stats_finish(a)"))) return rc;
+  const bool narrow = (stride == 2 && CQ == 16);
+  if (CQ == 4) EDGE_B(4, 8, 32)
+  else if (CQ == 8) EDGE_B(8, 8, 32)
+  else if (!narrow) EDGE_B(16, 8, 32)
+  else EDGE_B(16, 8, 16)
+  if ((rc = lct_check_launch("edge_fwd_b"))) return rc;
+  hipLaunchKernelGGL(edge_stats_finish_kernel, dim3(2 * CQ), dim3(64), 0, st, part, grid, 2, 7, CQ, P, eps, momentum, training, eb, -1,
+                     mean, invstd);
+  if ((rc = lct_check_launch("edge_stats_finish(b)"))) return rc;
+  long nb = (P * (CQ / 4) + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (stride == 1)
+    hipLaunchKernelGGL(edge_fwd_c_kernel<1>, dim3((int)nb), dim3(256), 0, st, x, pre, mean, invstd, wsel, beta, B, Ho, Wo, CQ, out, ldo, accumulate);
+  else
+    hipLaunchKernelGGL(edge_fwd_c_kernel<2>, dim3((int)nb), dim3(256), 0, st, x, pre, mean, invstd, wsel, beta, B, Ho, Wo, CQ, out, ldo, accumulate);
+  return lct_check_launch("edge_fwd_c");
+#undef EDGE_A
+#undef EDGE_B
+}
+
+// Backward of one edge (see the block comment above edge_bwd_sums_kernel).  dx [B,H,W,C] is written completely; dwsel [7],
+// dbeta [1]; wgrad = flat weight gradients (lctvqa_mixed_edge_wgrad_elems, order dw[6], pw[6], fr[2]); scratch >=
+// lctvqa_mixed_edge_bwd_scratch_floats floats, 16-byte aligned.
+int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, int H, int W, int C, int stride, const void* const* w,
+                          const float* pre, const float* mean, const float* invstd, const float* wsel, const float* beta, float* dx,
+                          float* dwsel, float* dbeta, float* wgrad, float* scratch, int training, void* stream) {
+  LCT_REQUIRE(lctvqa_mixed_edge_supported(B, H, W, C, stride), "mixed_edge_bwd: unsupported shape B=%d H=%d W=%d C=%d s=%d", B, H, W, C, stride);
+  LCT_REQUIRE((((uintptr_t)dout | (uintptr_t)x | (uintptr_t)pre | (uintptr_t)dx | (uintptr_t)scratch | (uintptr_t)wgrad) & 15) == 0 && (ldd & 3) == 0,
+              "mixed_edge_bwd: tensors must be 16-B aligned");
+  hipStream_t st = (hipStream_t)stream;
+  EdgeW ew;
+  for (int i = 0; i < 6; i++) { ew.dw[i] = (const float*)w[i]; ew.pw[i] = (const float*)w[6 + i]; }
+  ew.fr[0] = (const float*)w[12]; ew.fr[1] = (const float*)w[13];
+  const int CQ = C / 4, Ho = H / stride, Wo = W / stride;
+  const long P = (long)B * Ho * Wo;
+  const int G = lctvqa_mixed_edge_grid(B, H, W, C, stride);
+  const int wtot = lctvqa_mixed_edge_wgrad_elems(C);
+  int dw_off[6], pw_off[6];
+  { const int taps[6] = {9, 25, 9, 25, 9, 25}; int o = 0; for (int i = 0; i < 6; i++) { dw_off[i] = o; o += taps[i] * CQ; } for (int i = 0; i < 6; i++) pw_off[i] = o + i * CQ * CQ; }
+  const int fr_off = 102 * CQ + 6 * CQ * CQ;
+  float* dY = scratch;
+  float* dBN = dY + P * CQ;                                    // [2][P][CQ]
+  float* part1 = dBN + 2 * P * CQ;                             // [<=1024][8*CQ+1]
+  float* coef = part1 + 1024L * (8 * CQ + 1);
+  coef += (4 - ((coef - scratch) & 3)) & 3;
+  float* wpart = coef + 9 * COEF;                              // [G][wtot]
+  float* sp = wpart + (long)G * wtot;
+  sp += ((uintptr_t)sp & 7) ? 1 : 0;
+  double* spart = (double*)sp;                                 // [2][G][2*CQ][2]
+  int rc;
+  {
+    long nb = (P * (CQ / 4) + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    if (stride == 1)
+      hipLaunchKernelGGL(edge_bwd_sums_kernel<1>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, dx, part1);
+    else
+      hipLaunchKernelGGL(edge_bwd_sums_kernel<2>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, dx, part1);
+    if ((rc = lct_check_launch("edge_bwd_sums"))) return rc;
+    hipLaunchKernelGGL(edge_bwd_coef_kernel, dim3(1), dim3(256), 0, st, part1, (int)nb, CQ, P, stride, training, wsel, beta, invstd, coef, dwsel, dbeta);
+    if ((rc = lct_check_launch("edge_bwd_coef"))) return rc;
+  }
+#define EDGE_LAUNCH(KERN, LDS, ...)                                                                                        \
+  {                                                                                                                        \
+    static bool attr = false;                                                                                              \
+    const size_t lds = LDS;                                                                                                \
+    if (!attr) { hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
+    hipLaunchKernelGGL(KERN, __VA_ARGS__);                                                                                 \
+  }
+#define POOLS(CQv, Sv)                                                                                                     \
+  EDGE_LAUNCH((edge_bwd_pools_kernel<CQv, Sv, 8, 32>), (bwd_pools_lds<CQv, Sv, 8, 32>()), dim3(G), dim3(256), lds, st, x, dY, pre, mean, invstd, coef, \
+              B, H, W, ew, dx, wpart, wtot, fr_off)
+  if (CQ == 4 && stride == 1) POOLS(4, 1) else if (CQ == 4) POOLS(4, 2)
+  else if (CQ == 8 && stride == 1) POOLS(8, 1) else if (CQ == 8) POOLS(8, 2)
+  else if (stride == 1) POOLS(16, 1) else POOLS(16, 2)
+  if ((rc = lct_check_launch("edge_bwd_pools"))) return rc;
+  // CONV(CQ, K, DIL, S, MODE, TH, TW, conv index, slot of its output BN, input tensor, ldin, H, W, gradient source, dst, spart)
+#define CONV(CQv, Kv, DILv, Sv, MODEv, THv, TWv, ci, slot, inp, ldv, Hv, Wv, gs, dstp, spp)                                 \
+  EDGE_LAUNCH((edge_bwd_conv_kernel<CQv, Kv, DILv, Sv, MODEv, THv, TWv>), (bwd_conv_lds<CQv, Kv, DILv, Sv, MODEv, THv, TWv>()), dim3(G), dim3(THv * TWv), \
+              lds, st, inp, (long)(ldv), gs, pre + (long)(slot) * P * CQ, mean + (slot) * CQ, invstd + (slot) * CQ, coef + (slot) * COEF,         \
+              mean + ((slot) - 4) * CQ, invstd + ((slot) - 4) * CQ, ew.dw[ci], ew.pw[ci], B, Hv, Wv, dstp, spp, wpart, wtot, dw_off[ci], pw_off[ci])
+  // second stages of the sep_convs and the dil_convs (any order: they add into different things / dx1 sequentially)
+#define STAGE_FINAL(CQv, Sv, THv, TWv)                                                                                     \
+  {                                                                                                                        \
+    CONV(CQv, 3, 2, Sv, 0, THv, TWv, 2, 5, x, C, H, W, dY, dx, (double*)nullptr)                                           \
+    if ((rc = lct_check_launch("edge_bwd_conv(dil3)"))) return rc;                                                         \
+    CONV(CQv, 5, 2, Sv, 0, THv, TWv, 3, 6, x, C, H, W, dY, dx, (double*)nullptr)                                           \
+    if ((rc = lct_check_launch("edge_bwd_conv(dil5)"))) return rc;                                                         \
+    CONV(CQv, 3, 1, 1, 1, 8, 32, 4, 7, pre + 3L * P * CQv, CQv, Ho, Wo, dY, dBN, spart)                                    \
+    if ((rc = lct_check_launch("edge_bwd_conv(sep3b)"))) return rc;                                                        \
+    CONV(CQv, 5, 1, 1, 1, 8, 32, 5, 8, pre + 4L * P * CQv, CQv, Ho, Wo, dY, dBN + P * CQv, spart + (long)G * 2 * CQv * 2)  \
+    if ((rc = lct_check_launch("edge_bwd_conv(sep5b)"))) return rc;                                                        \
+    hipLaunchKernelGGL(edge_bwd_coef_a_kernel, dim3(2 * CQv), dim3(64), 0, st, spart, G, CQv, P, training, invstd, coef);  \
+    if ((rc = lct_check_launch("edge_bwd_coef_a"))) return rc;                                                             \
+    CONV(CQv, 3, 1, Sv, 2, THv, TWv, 0, 3, x, C, H, W, dBN, dx, (double*)nullptr)                                          \
+    if ((rc = lct_check_launch("edge_bwd_conv(sep3a)"))) return rc;                                                        \
+    CONV(CQv, 5, 1, Sv, 2, THv, TWv, 1, 4, x, C, H, W, dBN + P * CQv, dx, (double*)nullptr)                                \
+    if ((rc = lct_check_launch("edge_bwd_conv(sep5a)"))) return rc;                                                        \
+  }
+  if (CQ == 4 && stride == 1) STAGE_FINAL(4, 1, 8, 32)
+  else if (CQ == 4) STAGE_FINAL(4, 2, 8, 32)
+  else if (CQ == 8 && stride == 1) STAGE_FINAL(8, 1, 8, 32)
+  else if (CQ == 8) STAGE_FINAL(8, 2, 8, 32)
+  else if (stride == 1) STAGE_FINAL(16, 1, 8, 32)
+  else STAGE_FINAL(16, 2, 8, 16)
+  const int ncols = stride == 2 ? wtot : fr_off;               // stride-1 edges have no FactorizedReduce
+  hipLaunchKernelGGL(edge_wgrad_finish_kernel, dim3(ncols), dim3(64), 0, st, wpart, G, wtot, 0, wgrad);
+  return lct_check_launch("edge_wgrad_finish");
+#undef STAGE_FINAL
+#undef CONV
+#undef POOLS
+#undef EDGE_LAUNCH
+}
+
+}  // extern "C"

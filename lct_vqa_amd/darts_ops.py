@@ -3,6 +3,7 @@
 modules (ReLU / Conv2d / BatchNorm2d / AvgPool2d / MaxPool2d used purely as parameter+buffer holders,
 so state_dict keys equal the reference's) through those Functions."""
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -330,6 +331,81 @@ class AvgPool7FlattenFn(torch.autograd.Function):
         lib('adaptive_avgpool7_flatten_bwd', _chk(dy), dx, B, H, W, C)
         return dx
 
+
+
+# ------------------------------------------------------------------------------------------ fused MixedOp edge
+FUSED_EDGE = os.environ.get('LCTVQA_FUSED_EDGE', '1') != '0'     # A/B switch: 0 = one launch per primitive (the round-1 path)
+
+
+def set_fused_edge(on):
+    """Use the fused edge kernels (csrc/mixed_edge.hip) where the shape allows (default) or the per-primitive kernels.
+    Returns the previous setting."""
+    global FUSED_EDGE
+    prev, FUSED_EDGE = FUSED_EDGE, bool(on)
+    return prev
+
+
+class MixedEdgeFn(torch.autograd.Function):
+    """One MixedOp + its edge accumulation as ONE autograd node on the fused tile kernels:
+    ``state (+)= beta * shuffle(cat(sum_k w_k bn_k(op_k(x[..., :C/4])), bypass(x[..., C/4:])))`` (model_search.py:41-55,87).
+    Inputs after the fixed ones: the 12 (stride 1) or 14 (stride 2) weight tensors in the C ABI's order -- depthwise sep3.a,
+    sep5.a, dil3, dil5, sep3.b, sep5.b; 1x1 of the same six; FactorizedReduce conv_1, conv_2 -- whose gradients come back as
+    views of one flat buffer.  ``bns``: the BatchNorm2d holder per slot (None for the identity skip)."""
+
+    @staticmethod
+    def forward(ctx, prev, x, wsel, beta, stride, bns, training, *weights):
+        x, wsel, beta = _chk(x), _chk(wsel), _chk(beta)
+        weights = [_chk(w) for w in weights]
+        B, H, W, C = x.shape
+        Cq = C // 4
+        Ho, Wo = H // stride, W // stride
+        P, dev = B * Ho * Wo, x.device
+        if prev is None:
+            out = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=dev)
+            acc = 0
+        else:
+            out, acc = prev, 1
+            ctx.mark_dirty(prev)
+        pre = torch.empty((9, P, Cq), dtype=torch.float32, device=dev)
+        stats = torch.empty((2, 9, Cq), dtype=torch.float32, device=dev)          # mean, invstd per slot
+        grid = lib.query('mixed_edge_grid', B, H, W, C, stride)
+        part = _scratch(grid * 7 * Cq * 2, torch.float64, dev)
+        wptr = (ctypes.c_void_p * 14)(*([w.data_ptr() for w in weights] + [None] * (14 - len(weights))))
+        bnp = [None] * 27
+        momentum, eps = 0.1, 1e-5
+        for slot, bn in enumerate(bns):
+            if bn is None:
+                continue
+            momentum, eps = bn.momentum, bn.eps
+            if bn.track_running_stats:
+                bnp[slot], bnp[9 + slot], bnp[18 + slot] = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()
+        lib('mixed_edge_fwd', x, B, H, W, C, stride, wptr, (ctypes.c_void_p * 27)(*bnp), pre, stats[0], stats[1], part, wsel, beta,
+            out, out.stride(2), acc, int(training), float(momentum), float(eps))
+        ctx.save_for_backward(x, wsel, beta, pre, stats, *weights)
+        ctx.cfg = (stride, int(training), prev is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wsel, beta, pre, stats = ctx.saved_tensors[:5]
+        weights = list(ctx.saved_tensors[5:])
+        stride, training, has_prev = ctx.cfg
+        dout = _chk(dout)
+        B, H, W, C = x.shape
+        Cq, dev = C // 4, x.device
+        dx = torch.empty_like(x)
+        dw = torch.empty(7, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(1, dtype=torch.float32, device=dev)
+        wgrad = torch.empty(lib.query('mixed_edge_wgrad_elems', C), dtype=torch.float32, device=dev)
+        scratch = _scratch(lib.query('mixed_edge_bwd_scratch_floats', B, H, W, C, stride), torch.float32, dev)
+        wptr = (ctypes.c_void_p * 14)(*([w.data_ptr() for w in weights] + [None] * (14 - len(weights))))
+        lib('mixed_edge_bwd', dout, dout.stride(2), x, B, H, W, C, stride, wptr, pre, stats[0], stats[1], wsel, beta, dx, dw, dbeta,
+            wgrad, scratch, training)
+        grads, o = [], 0
+        for w in weights:
+            grads.append(wgrad[o:o + w.numel()].view_as(w))
+            o += w.numel()
+        return (dout if has_prev else None, dx, dw, dbeta, None, None, None) + tuple(grads)
 
 # ------------------------------------------------------------------------------------------ interpreter
 def _bn_args(bn):
