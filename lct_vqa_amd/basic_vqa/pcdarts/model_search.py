@@ -99,9 +99,13 @@ class MixedOp(nn.Module):
     def forward(self, x, weights, state=None, beta=None):
         """``state (+)= beta * shuffle(cat(sum_k w_k op_k(x[:C/4]), bypass(x[C/4:])))``; with the defaults this is the
         reference's ``MixedOp.forward(x, weights)``."""
-        idx = self._live_index.get(weights.device)
-        if idx is None:
-            idx = self._live_index[weights.device] = torch.as_tensor(self._live, device=weights.device)
+        if self._live == list(range(self._live[0], self._live[-1] + 1)):
+            wsel = weights[self._live[0]:self._live[-1] + 1]        # a view: no gather / scatter kernels around the edge
+        else:
+            idx = self._live_index.get(weights.device)
+            if idx is None:
+                idx = self._live_index[weights.device] = torch.as_tensor(self._live, device=weights.device)
+            wsel = weights[idx]
         if beta is None:
             beta = torch.ones(1, dtype=torch.float32, device=x.device)
         plan = self._fused_plan() if D.FUSED_EDGE else None
@@ -109,10 +113,9 @@ class MixedOp(nn.Module):
             bns, mods = plan
             modes = {b.training or not b.track_running_stats for b in bns if b is not None}
             if len(modes) == 1:                                   # one kernel, one mode: every BatchNorm of the edge agrees
-                return D.MixedEdgeFn.apply(state, x, weights[idx], beta.reshape(1), self.stride, bns, modes.pop(),
-                                           *[m.weight for m in mods])
+                return D.MixedEdgeFn.apply(state, x, wsel, beta.reshape(1), self.stride, bns, modes.pop(), *[m.weight for m in mods])
         outs, _ = self.branches(x)
-        return D.MixedCombineFn.apply(state, x, weights[idx], beta.reshape(1), self.stride == 2, *outs)
+        return D.MixedCombineFn.apply(state, x, wsel, beta.reshape(1), self.stride == 2, *outs)
 
 
 class Cell(nn.Module):

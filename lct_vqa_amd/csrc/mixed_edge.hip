@@ -24,6 +24,9 @@
 // with T = 4*P*Cq bytes.
 #include "common.h"
 
+#include <mutex>
+#include <unordered_map>
+
 namespace {
 
 constexpr int NSLOT = 9;
@@ -433,10 +436,10 @@ __global__ __launch_bounds__(256) void edge_fwd_c_kernel(const float* __restrict
 // dw_k = beta * sum_i S_k[i], dbeta = sum_k w_k sum_i S_k[i] + <dOut_bypass, bypass>.  Then
 //   g_k = d/d(u_k) = A_k (dY - c1_k - xhat_k c2_k),  A_k = a_k invstd_k, c1_k = S0 / P, c2_k = S_k / P      (training)
 // flows through the 1x1 / depthwise / pooling stencils of each branch back to x1.
-//   edge_bwd_sums    dY compact, the sums above (per-workgroup partials), the bypass part of dx
+//   edge_bwd_sums    dY compact, the sums above (per-workgroup partials)
 //   edge_bwd_coef    finish: coefficients A, c1, c2 per slot; dw, dbeta
-//   edge_bwd_pools   max / avg pool, skip (identity or FactorizedReduce): dx1 =
-//   edge_bwd_conv    one (relu ->) depthwise -> 1x1 stage: dx1 += (or the gradient entering a sep_conv's first BatchNorm
+//   edge_bwd_pools   LAST: max / avg pool, skip (identity or FactorizedReduce) + the conv stages' dx1c + the bypass -> dx, whole rows
+//   edge_bwd_conv    one (relu ->) depthwise -> 1x1 stage: dx1c (dense [B,H,W,Cq]) = / += (or the gradient entering a sep_conv's first BatchNorm
 //                    + its sums), per-workgroup partial weight gradients; launched for dil3, dil5, sep3b, sep5b, then
 //                    (after edge_bwd_coef_a) sep3a, sep5a
 //   edge_wgrad_finish  fixed-order fp64 column sums of the partial weight gradients
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(256) void edge_bwd_sums_kernel(const float* __restr
                                                             const float* __restrict__ pre, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ beta,
                                                             int B, int Ho, int Wo, int CQ, float* __restrict__ dY,
-                                                            float* __restrict__ dx, float* __restrict__ part /* [grid][8*CQ+1] */) {
+                                                            float* __restrict__ part /* [grid][8*CQ+1] */) {
   __shared__ float red[4][33];
   const int NQ = CQ / 4, C = 4 * CQ;
   const long P = (long)B * Ho * Wo;
@@ -484,10 +487,8 @@ __global__ __launch_bounds__(256) void edge_bwd_sums_kernel(const float* __restr
 #pragma unroll
       for (int g = 1; g < 4; g++) {
         const f32x4 bv = *(const f32x4*)(xp + g * CQ);
-        f32x4 gv = {D[0][g], D[1][g], D[2][g], D[3][g]};
 #pragma unroll
-        for (int e = 0; e < 4; e++) sb = fmaf(gv[e], bv[e], sb);
-        *(f32x4*)(dx + q * C + g * CQ + 4 * q4) = gv * bt;
+        for (int e = 0; e < 4; e++) sb = fmaf(D[e][g], bv[e], sb);
       }
     } else {
       const int ox = (int)(q % Wo), oy = (int)((q / Wo) % Ho), n = (int)(q / ((long)Wo * Ho));
@@ -498,21 +499,8 @@ __global__ __launch_bounds__(256) void edge_bwd_sums_kernel(const float* __restr
       for (int g = 1; g < 4; g++) {
         const f32x4 a = *(const f32x4*)(x + base + g * CQ), b = *(const f32x4*)(x + base + C + g * CQ);
         const f32x4 c = *(const f32x4*)(x + base + rs + g * CQ), d = *(const f32x4*)(x + base + rs + C + g * CQ);
-        f32x4 ga = {0.f, 0.f, 0.f, 0.f}, gb = ga, gc = ga, gd = ga;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          // first maximum in scan order (a, b, c, d), like MaxPool2d(2, 2)
-          int best = 0; float bv = a[e];
-          if (b[e] > bv) { bv = b[e]; best = 1; }
-          if (c[e] > bv) { bv = c[e]; best = 2; }
-          if (d[e] > bv) { bv = d[e]; best = 3; }
-          const float gr = D[e][g];
-          sb = fmaf(gr, bv, sb);
-          const float v = gr * bt;
-          ga[e] = best == 0 ? v : 0.f; gb[e] = best == 1 ? v : 0.f; gc[e] = best == 2 ? v : 0.f; gd[e] = best == 3 ? v : 0.f;
-        }
-        *(f32x4*)(dx + base + g * CQ) = ga; *(f32x4*)(dx + base + C + g * CQ) = gb;
-        *(f32x4*)(dx + base + rs + g * CQ) = gc; *(f32x4*)(dx + base + rs + C + g * CQ) = gd;
+        for (int e = 0; e < 4; e++) sb = fmaf(D[e][g], fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e])), sb);
       }
     }
   }
@@ -549,17 +537,21 @@ __global__ __launch_bounds__(256) void edge_bwd_sums_kernel(const float* __restr
   }
 }
 
-// one workgroup: sums of the partials (fixed order, fp64) -> coefficients of the seven final slots, dw[7], dbeta
+// one workgroup: sums of the partials (fixed order, fp64; one wave per column at a time) -> coefficients of the seven final
+// slots, dw[7], dbeta
 __global__ __launch_bounds__(256) void edge_bwd_coef_kernel(const float* __restrict__ part, int nblk, int CQ, long P, int S, int training,
                                                             const float* __restrict__ wsel, const float* __restrict__ beta,
                                                             const float* __restrict__ invstd, float* __restrict__ coef,
                                                             float* __restrict__ dw, float* __restrict__ dbeta) {
   __shared__ double tot[8 * 16 + 1];
   const int ncol = 8 * CQ + 1;
-  for (int col = threadIdx.x; col < ncol; col += 256) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int col = wv; col < ncol; col += 4) {
     double a = 0.0;
-    for (int b = 0; b < nblk; b++) a += (double)part[(long)b * ncol + col];
-    tot[col] = a;
+    for (int b = lane; b < nblk; b += 64) a += (double)part[(long)b * ncol + col];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) tot[col] = a;
   }
   __syncthreads();
   const int slot_of[7] = {0, 1, 2, 7, 8, 5, 6};
@@ -586,11 +578,12 @@ __global__ __launch_bounds__(256) void edge_bwd_coef_kernel(const float* __restr
 
 // coefficients of a sep_conv's FIRST BatchNorm (slots 3, 4) from the partial sums its second stage's backward left:
 // A = invstd, c1 = sum dBN / P, c2 = sum dBN * xhat / P
-__global__ __launch_bounds__(64) void edge_bwd_coef_a_kernel(const double* __restrict__ part /* [2][grid][2*CQ][2] */, int nblk, int CQ,
-                                                             long P, int training, const float* __restrict__ invstd,
+__global__ __launch_bounds__(64) void edge_bwd_coef_a_kernel(const double* __restrict__ part /* [2][G][2*CQ][2] */, int G, int nblk3, int nblk5,
+                                                             int CQ, long P, int training, const float* __restrict__ invstd,
                                                              float* __restrict__ coef) {
   const int which = blockIdx.x / CQ, c = blockIdx.x % CQ;       // which: 0 sep3 (slot 3), 1 sep5 (slot 4)
-  const double* pp = part + (long)which * nblk * 2 * CQ * 2;
+  const double* pp = part + (long)which * G * 2 * CQ * 2;
+  const int nblk = which ? nblk5 : nblk3;
   double a = 0.0, b = 0.0;
   for (int k = threadIdx.x; k < nblk; k += 64) { a += pp[((long)k * 2 * CQ + c) * 2]; b += pp[((long)k * 2 * CQ + CQ + c) * 2]; }
 #pragma unroll
@@ -619,24 +612,32 @@ __device__ __forceinline__ void grad_row(const float* __restrict__ dyr, const fl
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// edge_bwd_pools: dx1 = backward of max_pool (slot 0), avg_pool (slot 1) and skip_connect (slot 2).  Tile = TH x TW INPUT
-// pixels (one thread each, all Cq channels); gradient tiles g0, g1 of the covering output pixels and an x1 tile with halo 2
-// (the windows of the neighbouring outputs) in LDS.  FactorizedReduce weight gradients: per-workgroup partials.
+// edge_bwd_pools: the LAST backward kernel of an edge; writes every channel of dx exactly once, in whole rows:
+//   dx[..., :Cq]  = backward of max_pool (slot 0), avg_pool (slot 1), skip_connect (slot 2) + dx1c (what the conv stages
+//                   accumulated, dense [B,H,W,Cq])
+//   dx[..., Cq:]  = the bypass: beta * dOut[q][4i+g], routed to the first maximum of its 2x2 window on a reduction edge
+// Tile = TH x TW INPUT pixels (one thread each, all Cq channels).  LDS: x1 tile with halo 2, and per covering OUTPUT pixel
+// its max-pool gradient, its avg-pool gradient / window size, and the position (0..8) of its window's FIRST maximum per
+// channel (computed once per output, not once per (input, output) pair).  FactorizedReduce weight gradients: partials.
 // ------------------------------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 template <int CQ, int S, int TH, int TW>
 __global__ __launch_bounds__(TH * TW) void edge_bwd_pools_kernel(const float* __restrict__ x, const float* __restrict__ dY,
+                                                                 const float* __restrict__ dout, long ldd, const float* __restrict__ beta,
                                                                  const float* __restrict__ pre, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ coef,
-                                                                 int B, int H, int W, EdgeW wts, float* __restrict__ dx,
-                                                                 float* __restrict__ wpart, int wtot, int fr_off) {
+                                                                 const float* __restrict__ dx1c, int B, int H, int W, EdgeW wts,
+                                                                 float* __restrict__ dx, float* __restrict__ wpart, int wtot, int fr_off) {
   constexpr int TPB = TH * TW, NQ = CQ / 4, C = 4 * CQ;
   constexpr int XH = TH + 4, XW = TW + 4, XN = XH * XW;         // x1 tile, halo 2
   constexpr int GH = TH / S + 2, GW = TW / S + 2, GN = GH * GW;   // gradient tiles: outputs (ty0/S - 1) .. (ty0/S + TH/S)
   extern __shared__ __align__(16) unsigned char smem[];
   f32x4* xt = (f32x4*)smem;                                     // [NQ][XN]
-  f32x4* g0t = xt + NQ * XN;                                    // [NQ][GN]
-  f32x4* g1t = g0t + NQ * GN;
-  float* ms = (float*)(g1t + NQ * GN);                         // mean/invstd of slots 0,1,2: [3][2][CQ]
+  f32x4* g0t = xt + NQ * XN;                                    // [NQ][GN] max-pool gradient of the output
+  f32x4* g1t = g0t + NQ * GN;                                   // [NQ][GN] avg-pool gradient / window size
+  i32x4* apt = (i32x4*)(g1t + NQ * GN);                         // [NQ][GN] window position of the first maximum
+  float* ms = (float*)(apt + NQ * GN);                         // mean/invstd of slots 0,1,2: [3][2][CQ]
   float* cf = ms + 6 * CQ;                                     // coef of slots 0,1,2: [3][48]
   float* w_fr = cf + 3 * COEF;                                 // [2][CQ/2][CQ]
   float* Gs = w_fr + CQ * CQ;                                  // S == 2: g2 rows of the tile's outputs [TPB/4][CQ]
@@ -644,6 +645,7 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_pools_kernel(const float* __
   float* R1 = R0 + (TPB / 4) * CQ;
   const int Ho = H / S, Wo = W / S;
   const long P = (long)B * Ho * Wo;
+  const float bt = beta[0];
   for (int i = threadIdx.x; i < 3 * CQ; i += TPB) {
     const int k = i / CQ, c = i % CQ;
     ms[k * 2 * CQ + c] = mean[k * CQ + c];
@@ -662,21 +664,39 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_pools_kernel(const float* __
     const int gy0 = ty0 / S - 1, gx0 = tx0 / S - 1;             // first output row / column of the gradient tiles
     __syncthreads();
     load_tile<NQ, 0>(xt, x, C, n, H, W, ty0 - 2, tx0 - 2, XH, XW, nullptr, nullptr);
+    __syncthreads();
     for (int idx = threadIdx.x; idx < GN; idx += TPB) {
       const int gy = gy0 + idx / GW, gx = gx0 + idx % GW;
+      const bool in = gy >= 0 && gy < Ho && gx >= 0 && gx < Wo;
       float a[CQ], b[CQ];
-      if (gy >= 0 && gy < Ho && gx >= 0 && gx < Wo) {
+      float inv = 0.f;
+      int wy0 = 0, wy1 = -1, wx0 = 0, wx1 = -1;
+      if (in) {
         const long q = ((long)n * Ho + gy) * Wo + gx;
         grad_row<CQ>(dY + q * CQ, pre + (0 * P + q) * CQ, ms, cf, a);
         grad_row<CQ>(dY + q * CQ, pre + (1 * P + q) * CQ, ms + 2 * CQ, cf + COEF, b);
+        wy0 = max(S * gy - 1, 0); wy1 = min(S * gy + 1, H - 1); wx0 = max(S * gx - 1, 0); wx1 = min(S * gx + 1, W - 1);
+        inv = 1.f / (float)((wy1 - wy0 + 1) * (wx1 - wx0 + 1));
       } else {
 #pragma unroll
         for (int c = 0; c < CQ; c++) { a[c] = 0.f; b[c] = 0.f; }
       }
 #pragma unroll
       for (int q4 = 0; q4 < NQ; q4++) {
+        // first maximum of the window in scan order (strict >), as a window position (ky * 3 + kx relative to S*g - 1)
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        i32x4 pos = {-1, -1, -1, -1};
+        for (int yy = wy0; yy <= wy1; yy++)
+          for (int xx = wx0; xx <= wx1; xx++) {
+            const f32x4 v = xt[q4 * XN + (yy - ty0 + 2) * XW + (xx - tx0 + 2)];
+            const int code = (yy - (S * gy - 1)) * 3 + (xx - (S * gx - 1));
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+              if (v[e] > best[e]) { best[e] = v[e]; pos[e] = code; }
+          }
         g0t[q4 * GN + idx] = f32x4{a[4 * q4], a[4 * q4 + 1], a[4 * q4 + 2], a[4 * q4 + 3]};
-        g1t[q4 * GN + idx] = f32x4{b[4 * q4], b[4 * q4 + 1], b[4 * q4 + 2], b[4 * q4 + 3]};
+        g1t[q4 * GN + idx] = f32x4{b[4 * q4] * inv, b[4 * q4 + 1] * inv, b[4 * q4 + 2] * inv, b[4 * q4 + 3] * inv};
+        apt[q4 * GN + idx] = pos;
       }
     }
     __syncthreads();
@@ -684,32 +704,23 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_pools_kernel(const float* __
     const bool live = iy < H && ix < W;
     float dxv[CQ];
     // ---- pools: every output window (oy, ox) that contains (iy, ix) ----
-    const int oy_lo = (iy - 1 + S - 1) / S, oy_hi = min((iy + 1) / S, Ho - 1);    // ceil((iy-1)/S) .. floor((iy+1)/S)
-    const int ox_lo = (ix - 1 + S - 1) / S, ox_hi = min((ix + 1) / S, Wo - 1);
+    const int oy_lo = max((iy - 1 + S - 1) / S, 0), oy_hi = min((iy + 1) / S, Ho - 1);    // ceil((iy-1)/S) .. floor((iy+1)/S)
+    const int ox_lo = max((ix - 1 + S - 1) / S, 0), ox_hi = min((ix + 1) / S, Wo - 1);
 #pragma unroll
     for (int q4 = 0; q4 < NQ; q4++) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
       if (live) {
-        const f32x4 xp = xt[q4 * XN + (ly + 2) * XW + lx + 2];
-        for (int oy = max(oy_lo, 0); oy <= oy_hi; oy++)
-          for (int ox = max(ox_lo, 0); ox <= ox_hi; ox++) {
+        for (int oy = oy_lo; oy <= oy_hi; oy++)
+          for (int ox = ox_lo; ox <= ox_hi; ox++) {
             const int gi = (oy - gy0) * GW + (ox - gx0);
             const f32x4 gmax = g0t[q4 * GN + gi], gavg = g1t[q4 * GN + gi];
-            // window of (oy, ox): rows S*oy-1 .. S*oy+1 clipped to the image
-            const int wy0 = max(S * oy - 1, 0), wy1 = min(S * oy + 1, H - 1), wx0 = max(S * ox - 1, 0), wx1 = min(S * ox + 1, W - 1);
-            const float inv = 1.f / (float)((wy1 - wy0 + 1) * (wx1 - wx0 + 1));
-            // (iy, ix) is the window's FIRST maximum iff nothing before it (scan order) is >= and nothing after it is >
-            bool first[4] = {true, true, true, true};
-            for (int yy = wy0; yy <= wy1; yy++)
-              for (int xx = wx0; xx <= wx1; xx++) {
-                const f32x4 v = xt[q4 * XN + (yy - ty0 + 2) * XW + (xx - tx0 + 2)];
-                const bool before = (yy < iy) || (yy == iy && xx < ix);
+            const i32x4 pos = apt[q4 * GN + gi];
+            const int code = (iy - (S * oy - 1)) * 3 + (ix - (S * ox - 1));
 #pragma unroll
-                for (int e = 0; e < 4; e++) first[e] = first[e] && (before ? (v[e] < xp[e]) : (v[e] <= xp[e]));
-              }
-#pragma unroll
-            for (int e = 0; e < 4; e++) a[e] += (first[e] ? gmax[e] : 0.f) + gavg[e] * inv;
+            for (int e = 0; e < 4; e++) a[e] += (pos[e] == code ? gmax[e] : 0.f) + gavg[e];
           }
+        const f32x4 c1 = *(const f32x4*)(dx1c + (((long)n * H + iy) * W + ix) * CQ + 4 * q4);   // the conv stages' share
+        a += c1;
       }
 #pragma unroll
       for (int e = 0; e < 4; e++) dxv[4 * q4 + e] = a[e];
@@ -775,7 +786,37 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_pools_kernel(const float* __
         acc_fr += a;
       }
     }
-    if (live) store_row<CQ>(dx + (((long)n * H + iy) * W + ix) * C, dxv);
+    if (live) {
+      float* drow = dx + (((long)n * H + iy) * W + ix) * C;
+      store_row<CQ>(drow, dxv);
+      // ---- bypass channels g*Cq + i <- beta * dOut[q][4i + g] ----
+      const long q = ((long)n * Ho + iy / S) * Wo + ix / S;
+      const float* xr = x + (((long)n * H + (iy & ~(S - 1))) * W + (ix & ~(S - 1))) * C;   // top-left of the 2x2 window (S = 2)
+      const int me = (iy & 1) * 2 + (ix & 1);
+#pragma unroll
+      for (int q4 = 0; q4 < NQ; q4++) {
+        f32x4 D[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) D[e] = *(const f32x4*)(dout + q * ldd + 16 * q4 + 4 * e);
+#pragma unroll
+        for (int g = 1; g < 4; g++) {
+          f32x4 v = {D[0][g] * bt, D[1][g] * bt, D[2][g] * bt, D[3][g] * bt};
+          if (S == 2) {
+            const f32x4 va = *(const f32x4*)(xr + g * CQ + 4 * q4), vb = *(const f32x4*)(xr + C + g * CQ + 4 * q4);
+            const f32x4 vc = *(const f32x4*)(xr + (long)W * C + g * CQ + 4 * q4), vd = *(const f32x4*)(xr + (long)W * C + C + g * CQ + 4 * q4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              int best = 0; float bv = va[e];                   // first maximum in scan order, like MaxPool2d(2, 2)
+              if (vb[e] > bv) { bv = vb[e]; best = 1; }
+              if (vc[e] > bv) { bv = vc[e]; best = 2; }
+              if (vd[e] > bv) { bv = vd[e]; best = 3; }
+              if (best != me) v[e] = 0.f;
+            }
+          }
+          *(f32x4*)(drow + g * CQ + 4 * q4) = v;
+        }
+      }
+    }
   }
   if (S == 2 && threadIdx.x < CQ * CQ) wpart[(long)blockIdx.x * wtot + fr_off + threadIdx.x] = acc_fr;
 }
@@ -795,13 +836,14 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
                                                                 const float* __restrict__ coef_o, const float* __restrict__ mean_i,
                                                                 const float* __restrict__ invstd_i, const float* __restrict__ w_dw,
                                                                 const float* __restrict__ w_pw, int B, int H, int W,
-                                                                float* __restrict__ dst /* dx (MODE 0, 2) or dBN [P][CQ] (MODE 1) */,
-                                                                double* __restrict__ spart /* MODE 1: [grid][2*CQ][2] */,
+                                                                float* __restrict__ dst /* dx1c [B,H,W,CQ] (MODE 0, 2) or dBN [P][CQ] (MODE 1) */,
+                                                                int accumulate, double* __restrict__ spart /* MODE 1: [grid][2*CQ][2] */,
                                                                 float* __restrict__ wpart, int wtot, int dw_off, int pw_off) {
   constexpr int TPB = TH * TW, NQ = CQ / 4, KK = K * K, PAD = DIL * (K - 1) / 2, HB = (PAD + S - 1) / S;
   constexpr int IH = S * (TH - 1) + 2 * PAD + 1, IW = S * (TW - 1) + 2 * PAD + 1, IN = IH * IW;
   constexpr int DH = TH + 2 * HB, DW = TW + 2 * HB, DN = DH * DW;
-  constexpr int NDW = (CQ * KK + TPB - 1) / TPB;                // depthwise weight-gradient entries per thread
+  constexpr int NE = NQ * KK;                                   // depthwise weight-gradient entries (channel quad, tap): <= 100
+  constexpr int DSL = TPB / NE;                                 // pixel slices per entry
   constexpr int SL = TPB >= CQ * CQ ? TPB / (CQ * CQ) : 1;      // pixel slices of the 1x1 weight gradient
   constexpr int NPW = TPB >= CQ * CQ ? 1 : CQ * CQ / TPB;       // its entries per thread (narrow tiles at Cq = 16: 2)
   extern __shared__ __align__(16) unsigned char smem[];
@@ -830,9 +872,7 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
   const int tiles_y = (Ho + TH - 1) / TH, tiles_x = (Wo + TW - 1) / TW;
   const long ntiles = (long)B * tiles_y * tiles_x;
   const int ly = threadIdx.x / TW, lx = threadIdx.x % TW;
-  float acc_dw[NDW];
-#pragma unroll
-  for (int i = 0; i < NDW; i++) acc_dw[i] = 0.f;
+  f32x4 acc_dw = {0.f, 0.f, 0.f, 0.f};
   float acc_pw[NPW];
 #pragma unroll
   for (int i = 0; i < NPW; i++) acc_pw[i] = 0.f;
@@ -894,20 +934,21 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
         acc_pw[i] += a;
       }
     }
-    // ---- depthwise weight gradient: entry (c, tap) sums dd[o][c] * r[S*o - PAD + DIL*tap][c] over the tile's outputs ----
+    // ---- depthwise weight gradient: entry (channel quad, tap) sums dd[o][c] * r[S*o - PAD + DIL*tap][c] over the tile's
+    //      outputs; thread = entry x slice of the tile's pixels, 16-byte LDS reads ----
+    if (threadIdx.x < DSL * NE) {
+      const int ent = threadIdx.x % NE, sl = threadIdx.x / NE;
+      const int q4 = ent / KK, tap = ent % KK, tj = tap / K, ti = tap % K;
+      const f32x4* rp = rt + q4 * IN + DIL * tj * IW + DIL * ti;
+      const f32x4* dp = ddt + q4 * DN + HB * DW + HB;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      for (int pp = sl; pp < TPB; pp += DSL) {
+        const int py = pp / TW, px = pp % TW;
+        const f32x4 dv = dp[py * DW + px], rv = rp[S * py * IW + S * px];
 #pragma unroll
-    for (int i = 0; i < NDW; i++) {
-      const int ent = threadIdx.x + i * TPB;
-      if (ent < CQ * KK) {
-        const int c = ent / KK, tap = ent % KK, tj = tap / K, ti = tap % K;
-        const float* rp = (const float*)(rt + (c >> 2) * IN) + (c & 3);
-        const float* dp = (const float*)(ddt + (c >> 2) * DN) + (c & 3);
-        float a = 0.f;
-        for (int py = 0; py < TH; py++)
-          for (int px = 0; px < TW; px++)
-            a = fmaf(dp[((py + HB) * DW + px + HB) * 4], rp[((S * py + DIL * tj) * IW + S * px + DIL * ti) * 4], a);
-        acc_dw[i] += a;
+        for (int e = 0; e < 4; e++) a[e] = fmaf(dv[e], rv[e], a[e]);
       }
+      acc_dw += a;
     }
     // ---- input gradient at the owned input pixels (S*oy + a, S*ox + b): gather over the taps ----
     float stat[2][CQ];
@@ -942,16 +983,16 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
           }
         }
         if (live && iy < H && ix < W) {
-          if (MODE == 1) store_row<CQ>(dst + (((long)n * H + iy) * W + ix) * CQ, din);
-          else {
-            float* dp = dst + (((long)n * H + iy) * W + ix) * ldin;
+          float* dp = dst + (((long)n * H + iy) * W + ix) * CQ;
+          if (MODE != 1 && accumulate) {
 #pragma unroll
             for (int q4 = 0; q4 < NQ; q4++) {
-              f32x4 o = *(const f32x4*)(dp + 4 * q4);
-              o += f32x4{din[4 * q4], din[4 * q4 + 1], din[4 * q4 + 2], din[4 * q4 + 3]};
-              *(f32x4*)(dp + 4 * q4) = o;
+              const f32x4 o = *(const f32x4*)(dp + 4 * q4);
+#pragma unroll
+              for (int e = 0; e < 4; e++) din[4 * q4 + e] += o[e];
             }
           }
+          store_row<CQ>(dp, din);
         }
       }
     if (MODE == 1) phase_stats<CQ, 2, 2, TPB>(stat, live, red, seg, acc, 0);
@@ -959,11 +1000,16 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
   // ---- per-workgroup partial weight gradients ----
   __syncthreads();
   float* wrow = wpart + (long)blockIdx.x * wtot;
+  ((f32x4*)Ds)[threadIdx.x] = acc_dw;                            // [slice][entry] of float4
+  __syncthreads();
+  if (threadIdx.x < NE) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < DSL; sl++) a += ((const f32x4*)Ds)[sl * NE + threadIdx.x];
+    const int q4 = threadIdx.x / KK, tap = threadIdx.x % KK;
 #pragma unroll
-  for (int i = 0; i < NDW; i++) {
-    const int ent = threadIdx.x + i * TPB;
-    if (ent < CQ * KK) wrow[dw_off + ent] = acc_dw[i];
+    for (int e = 0; e < 4; e++) wrow[dw_off + (4 * q4 + e) * KK + tap] = a[e];
   }
+  __syncthreads();
   if (SL > 1) {
     Gs[threadIdx.x] = acc_pw[0];
     __syncthreads();
@@ -986,21 +1032,32 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
   }
 }
 
-// out[col] = sum over the workgroups' partial rows (fixed order, fp64); columns lo..hi-1 only
-__global__ __launch_bounds__(64) void edge_wgrad_finish_kernel(const float* __restrict__ part, int nblk, int wtot, int lo,
+// out[col] = sum over the partial rows of the kernel that produced the column (fixed order, fp64).  Column sections: the
+// depthwise gradients of conv 0..5 (9, 25, 9, 25, 9, 25 taps x Cq), their 1x1 gradients (Cq x Cq each), FactorizedReduce;
+// nb.n[i] = workgroups of conv kernel i (i = 0..5), nb.n[6] = of the pooling kernel.
+struct SectionRows { int n[7]; };
+__global__ __launch_bounds__(64) void edge_wgrad_finish_kernel(const float* __restrict__ part, SectionRows nb, int wtot, int CQ,
                                                                float* __restrict__ out) {
-  const int col = lo + blockIdx.x;
+  const int col = blockIdx.x;
+  const int taps[6] = {9, 25, 9, 25, 9, 25};
+  int sec = 6, o = 0;
+  if (col < 102 * CQ) {
+    for (int i = 0; i < 6; i++) { o += taps[i] * CQ; if (col < o) { sec = i; break; } }
+  } else if (col < 102 * CQ + 6 * CQ * CQ) {
+    sec = (col - 102 * CQ) / (CQ * CQ);
+  }
+  const int nblk = nb.n[sec];
   double a = 0.0;
   for (int k = threadIdx.x; k < nblk; k += 64) a += (double)part[(long)k * wtot + col];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  for (int o2 = 32; o2 > 0; o2 >>= 1) a += __shfl_xor(a, o2, 64);
   if (threadIdx.x == 0) out[col] = (float)a;
 }
 
 template <int CQ, int S, int TH, int TW>
 size_t bwd_pools_lds() {
   constexpr int TPB = TH * TW, NQ = CQ / 4, XN = (TH + 4) * (TW + 4), GN = (TH / S + 2) * (TW / S + 2);
-  size_t floats = (size_t)NQ * XN * 4 + 2 * NQ * GN * 4 + 6 * CQ + 3 * COEF + CQ * CQ + 3 * (TPB / 4) * CQ;
+  size_t floats = (size_t)NQ * XN * 4 + 3 * NQ * GN * 4 + 6 * CQ + 3 * COEF + CQ * CQ + 3 * (TPB / 4) * CQ;
   return floats * 4 + 16;
 }
 template <int CQ, int K, int DIL, int S, int MODE, int TH, int TW>
@@ -1025,11 +1082,39 @@ size_t fwd_b_lds() {
   return floats * 4 + 4 * CQ * 8 + 16;
 }
 
-int persistent_grid(long ntiles, int per_cu) {
-  long g = 256L * per_cu;
+// Workgroups of `kern` one CU holds at once (registers, LDS); also opts the kernel in to its dynamic LDS size.  Cached per kernel.
+int blocks_per_cu(const void* kern, int tpb, size_t lds) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, int> cache;
+  std::lock_guard<std::mutex> guard(mu);
+  auto it = cache.find(kern);
+  if (it != cache.end()) return it->second;
+  (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, tpb, lds) != hipSuccess || n < 1) n = 1;
+  if (n > 8) n = 8;
+  cache[kern] = n;
+  return n;
+}
+int cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n < 1) n = 256;
+  }
+  return n;
+}
+// Persistent grid of a tile kernel: one co-resident wave of workgroups (every CU filled to the kernel's own occupancy, so
+// there is no partial second round), never more than there are tiles or partial-buffer rows.
+int tile_grid(const void* kern, int tpb, size_t lds, long ntiles, int max_rows) {
+  long g = (long)cu_count() * blocks_per_cu(kern, tpb, lds);
   if (g > ntiles) g = ntiles;
+  if (g > max_rows) g = max_rows;
   return (int)(g < 1 ? 1 : g);
 }
+constexpr int MAX_ROWS = 2048;
 
 }  // namespace
 
@@ -1042,14 +1127,14 @@ int lctvqa_mixed_edge_supported(int B, int H, int W, int C, int stride) {
   if (stride == 2) return (H % 2 == 0 && W % 2 == 0 && H >= 2 && W >= 2) ? 1 : 0;
   return stride == 1 ? 1 : 0;
 }
-// number of workgroups every tile kernel of an edge is launched with (= rows of the partial-sum buffers): enough for the
-// larger of its two tile grids (output pixels; input pixels in the pooling backward), at most four per CU
+// rows of the per-workgroup partial buffers of an edge (an upper bound of every tile kernel's grid)
 int lctvqa_mixed_edge_grid(int B, int H, int W, int C, int stride) {
   const int Ho = H / stride, Wo = W / stride, CQ = C / 4;
   const int TH = 8, TW = (stride == 2 && CQ == 16) ? 16 : 32;
   const long t_out = (long)B * ((Ho + TH - 1) / TH) * ((Wo + TW - 1) / TW);
   const long t_in = (long)B * ((H + 7) / 8) * ((W + 31) / 32);
-  return persistent_grid(t_out > t_in ? t_out : t_in, 4);
+  const long t = t_out > t_in ? t_out : t_in;
+  return (int)(t > MAX_ROWS ? MAX_ROWS : t);
 }
 // floats of the flat weight-gradient vector: dw[6] (9, 25, 9, 25, 9, 25 taps x Cq), pw[6] (Cq x Cq), fr[2] (Cq/2 x Cq)
 int lctvqa_mixed_edge_wgrad_elems(int C) {
@@ -1060,12 +1145,13 @@ long lctvqa_mixed_edge_bwd_scratch_floats(int B, int H, int W, int C, int stride
   const int CQ = C / 4;
   const long P = (long)B * (H / stride) * (W / stride);
   const long G = lctvqa_mixed_edge_grid(B, H, W, C, stride);
-  return 3 * P * CQ + 1024L * (8 * CQ + 1) + 9 * COEF + G * lctvqa_mixed_edge_wgrad_elems(C) + 2 * (2 * G * 2 * CQ * 2) + 8;
+  return 3 * P * CQ + (long)B * H * W * CQ + 512L * (8 * CQ + 1) + 9 * COEF + G * lctvqa_mixed_edge_wgrad_elems(C) + 2 * (2 * G * 2 * CQ * 2) + 8;
 }
 
 // Forward of one edge.  w: 14 pointers = dw[6], pw[6], fr[2] (fr null on stride-1 edges); bn: 27 pointers = run_mean[9],
 // run_var[9], tracked[9] (null for the identity skip); pre [9][P][Cq]; stats mean/invstd [9][Cq]; part: fp64 scratch of
-// grid * 7*Cq * 2 doubles; wsel [7] live architecture weights (PRIMITIVES order without 'none'); beta [1]; out row stride ldo.
+// lctvqa_mixed_edge_grid * 7*Cq * 2 doubles; wsel [7] live architecture weights (PRIMITIVES order without 'none'); beta [1];
+// out row stride ldo.
 int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride, const void* const* w, void* const* bn,
                           float* pre, float* mean, float* invstd, double* part, const float* wsel, const float* beta,
                           float* out, long ldo, int accumulate, int training, float momentum, float eps, void* stream) {
@@ -1080,20 +1166,20 @@ int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride
   for (int i = 0; i < NSLOT; i++) { eb.run_mean[i] = (float*)bn[i]; eb.run_var[i] = (float*)bn[9 + i]; eb.tracked[i] = (long*)bn[18 + i]; }
   const int CQ = C / 4, Ho = H / stride, Wo = W / stride;
   const long P = (long)B * Ho * Wo;
-  const int grid = lctvqa_mixed_edge_grid(B, H, W, C, stride);
+  const int rows = lctvqa_mixed_edge_grid(B, H, W, C, stride);
   const int skip_slot = stride == 1 ? 2 : -1;
+  int rc, grid = 1;
+#define TILES(THv, TWv) ((long)B * ((Ho + (THv) - 1) / (THv)) * ((Wo + (TWv) - 1) / (TWv)))
 #define EDGE_A(CQv, Sv, THv, TWv)                                                                                          \
   {                                                                                                                        \
-    static bool attr = false;                                                                                              \
     const size_t lds = fwd_a_lds<CQv, Sv, THv, TWv>();                                                                     \
-    if (!attr) { hipFuncSetAttribute((const void*)edge_fwd_a_kernel<CQv, Sv, THv, TWv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
+    grid = tile_grid((const void*)edge_fwd_a_kernel<CQv, Sv, THv, TWv>, THv * TWv, lds, TILES(THv, TWv), rows);           \
     hipLaunchKernelGGL((edge_fwd_a_kernel<CQv, Sv, THv, TWv>), dim3(grid), dim3(THv * TWv), lds, st, x, B, H, W, ew, pre, part); \
   }
 #define EDGE_B(CQv, THv, TWv)                                                                                              \
   {                                                                                                                        \
-    static bool attr = false;                                                                                              \
     const size_t lds = fwd_b_lds<CQv, THv, TWv>();                                                                         \
-    if (!attr) { hipFuncSetAttribute((const void*)edge_fwd_b_kernel<CQv, THv, TWv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
+    grid = tile_grid((const void*)edge_fwd_b_kernel<CQv, THv, TWv>, THv * TWv, lds, TILES(THv, TWv), rows);               \
     hipLaunchKernelGGL((edge_fwd_b_kernel<CQv, THv, TWv>), dim3(grid), dim3(THv * TWv), lds, st, B, Ho, Wo, ew, mean, invstd, pre, part); \
   }
   if (CQ == 4 && stride == 1) EDGE_A(4, 1, 8, 32)
@@ -1102,8 +1188,7 @@ int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride
   else if (CQ == 8) EDGE_A(8, 2, 8, 32)
   else if (stride == 1) EDGE_A(16, 1, 8, 32)
   else EDGE_A(16, 2, 8, 16)
-  int rc = lct_check_launch("edge_fwd_a");
-  if (rc) return rc;
+  if ((rc = lct_check_launch("edge_fwd_a"))) return rc;
   hipLaunchKernelGGL(edge_stats_finish_kernel, dim3(7 * CQ), dim3(64), 0, st, part, grid, 7, 0, CQ, P, eps, momentum, training, eb,
                      skip_slot, mean, invstd);
   if ((rc = lct_check_launch("edge_stats_finish(a)"))) return rc;
@@ -1125,6 +1210,7 @@ int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride
   return lct_check_launch("edge_fwd_c");
 #undef EDGE_A
 #undef EDGE_B
+#undef TILES
 }
 
 // Backward of one edge (see the block comment above edge_bwd_sums_kernel).  dx [B,H,W,C] is written completely; dwsel [7],
@@ -1149,75 +1235,80 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
   const int fr_off = 102 * CQ + 6 * CQ * CQ;
   float* dY = scratch;
   float* dBN = dY + P * CQ;                                    // [2][P][CQ]
-  float* part1 = dBN + 2 * P * CQ;                             // [<=1024][8*CQ+1]
-  float* coef = part1 + 1024L * (8 * CQ + 1);
+  float* dx1c = dBN + 2 * P * CQ;                              // [B][H][W][CQ]: what the conv stages send to x1
+  float* part1 = dx1c + (long)B * H * W * CQ;                  // [<=512][8*CQ+1]
+  float* coef = part1 + 512L * (8 * CQ + 1);
   coef += (4 - ((coef - scratch) & 3)) & 3;
   float* wpart = coef + 9 * COEF;                              // [G][wtot]
   float* sp = wpart + (long)G * wtot;
   sp += ((uintptr_t)sp & 7) ? 1 : 0;
   double* spart = (double*)sp;                                 // [2][G][2*CQ][2]
-  int rc;
+  SectionRows rows;
+  for (int i = 0; i < 7; i++) rows.n[i] = 0;
+  int rc, grid = 1, g3b = 1, g5b = 1;
   {
     long nb = (P * (CQ / 4) + 255) / 256;
-    if (nb > 1024) nb = 1024;
+    if (nb > 512) nb = 512;
     if (stride == 1)
-      hipLaunchKernelGGL(edge_bwd_sums_kernel<1>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, dx, part1);
+      hipLaunchKernelGGL(edge_bwd_sums_kernel<1>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, part1);
     else
-      hipLaunchKernelGGL(edge_bwd_sums_kernel<2>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, dx, part1);
+      hipLaunchKernelGGL(edge_bwd_sums_kernel<2>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, part1);
     if ((rc = lct_check_launch("edge_bwd_sums"))) return rc;
     hipLaunchKernelGGL(edge_bwd_coef_kernel, dim3(1), dim3(256), 0, st, part1, (int)nb, CQ, P, stride, training, wsel, beta, invstd, coef, dwsel, dbeta);
     if ((rc = lct_check_launch("edge_bwd_coef"))) return rc;
   }
-#define EDGE_LAUNCH(KERN, LDS, ...)                                                                                        \
+#define TILES(Hv, Wv, THv, TWv) ((long)B * (((Hv) + (THv) - 1) / (THv)) * (((Wv) + (TWv) - 1) / (TWv)))
+  // CONV(CQ, K, DIL, S, MODE, TH, TW, conv index, slot of its output BN, input tensor, ldin, H, W, gradient source, dst, accumulate, spart)
+#define CONV(CQv, Kv, DILv, Sv, MODEv, THv, TWv, ci, slot, inp, ldv, Hv, Wv, gs, dstp, accv, spp)                           \
   {                                                                                                                        \
-    static bool attr = false;                                                                                              \
-    const size_t lds = LDS;                                                                                                \
-    if (!attr) { hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
-    hipLaunchKernelGGL(KERN, __VA_ARGS__);                                                                                 \
+    const size_t lds = bwd_conv_lds<CQv, Kv, DILv, Sv, MODEv, THv, TWv>();                                                 \
+    grid = tile_grid((const void*)edge_bwd_conv_kernel<CQv, Kv, DILv, Sv, MODEv, THv, TWv>, THv * TWv, lds,               \
+                     TILES((Hv) / Sv, (Wv) / Sv, THv, TWv), G);                                                            \
+    rows.n[ci] = grid;                                                                                                     \
+    hipLaunchKernelGGL((edge_bwd_conv_kernel<CQv, Kv, DILv, Sv, MODEv, THv, TWv>), dim3(grid), dim3(THv * TWv), lds, st, inp, (long)(ldv), gs, \
+                       pre + (long)(slot) * P * CQ, mean + (slot) * CQ, invstd + (slot) * CQ, coef + (slot) * COEF,       \
+                       mean + ((slot) - 4) * CQ, invstd + ((slot) - 4) * CQ, ew.dw[ci], ew.pw[ci], B, Hv, Wv, dstp, accv, spp, wpart, wtot, \
+                       dw_off[ci], pw_off[ci]);                                                                            \
   }
-#define POOLS(CQv, Sv)                                                                                                     \
-  EDGE_LAUNCH((edge_bwd_pools_kernel<CQv, Sv, 8, 32>), (bwd_pools_lds<CQv, Sv, 8, 32>()), dim3(G), dim3(256), lds, st, x, dY, pre, mean, invstd, coef, \
-              B, H, W, ew, dx, wpart, wtot, fr_off)
-  if (CQ == 4 && stride == 1) POOLS(4, 1) else if (CQ == 4) POOLS(4, 2)
-  else if (CQ == 8 && stride == 1) POOLS(8, 1) else if (CQ == 8) POOLS(8, 2)
-  else if (stride == 1) POOLS(16, 1) else POOLS(16, 2)
-  if ((rc = lct_check_launch("edge_bwd_pools"))) return rc;
-  // CONV(CQ, K, DIL, S, MODE, TH, TW, conv index, slot of its output BN, input tensor, ldin, H, W, gradient source, dst, spart)
-#define CONV(CQv, Kv, DILv, Sv, MODEv, THv, TWv, ci, slot, inp, ldv, Hv, Wv, gs, dstp, spp)                                 \
-  EDGE_LAUNCH((edge_bwd_conv_kernel<CQv, Kv, DILv, Sv, MODEv, THv, TWv>), (bwd_conv_lds<CQv, Kv, DILv, Sv, MODEv, THv, TWv>()), dim3(G), dim3(THv * TWv), \
-              lds, st, inp, (long)(ldv), gs, pre + (long)(slot) * P * CQ, mean + (slot) * CQ, invstd + (slot) * CQ, coef + (slot) * COEF,         \
-              mean + ((slot) - 4) * CQ, invstd + ((slot) - 4) * CQ, ew.dw[ci], ew.pw[ci], B, Hv, Wv, dstp, spp, wpart, wtot, dw_off[ci], pw_off[ci])
-  // second stages of the sep_convs and the dil_convs (any order: they add into different things / dx1 sequentially)
-#define STAGE_FINAL(CQv, Sv, THv, TWv)                                                                                     \
+#define STAGES(CQv, Sv, THv, TWv)                                                                                          \
   {                                                                                                                        \
-    CONV(CQv, 3, 2, Sv, 0, THv, TWv, 2, 5, x, C, H, W, dY, dx, (double*)nullptr)                                           \
+    CONV(CQv, 3, 2, Sv, 0, THv, TWv, 2, 5, x, C, H, W, dY, dx1c, 0, (double*)nullptr)                                      \
     if ((rc = lct_check_launch("edge_bwd_conv(dil3)"))) return rc;                                                         \
-    CONV(CQv, 5, 2, Sv, 0, THv, TWv, 3, 6, x, C, H, W, dY, dx, (double*)nullptr)                                           \
+    CONV(CQv, 5, 2, Sv, 0, THv, TWv, 3, 6, x, C, H, W, dY, dx1c, 1, (double*)nullptr)                                      \
     if ((rc = lct_check_launch("edge_bwd_conv(dil5)"))) return rc;                                                         \
-    CONV(CQv, 3, 1, 1, 1, 8, 32, 4, 7, pre + 3L * P * CQv, CQv, Ho, Wo, dY, dBN, spart)                                    \
+    CONV(CQv, 3, 1, 1, 1, 8, 32, 4, 7, pre + 3L * P * CQv, CQv, Ho, Wo, dY, dBN, 0, spart)                                 \
+    g3b = grid;                                                                                                            \
     if ((rc = lct_check_launch("edge_bwd_conv(sep3b)"))) return rc;                                                        \
-    CONV(CQv, 5, 1, 1, 1, 8, 32, 5, 8, pre + 4L * P * CQv, CQv, Ho, Wo, dY, dBN + P * CQv, spart + (long)G * 2 * CQv * 2)  \
+    CONV(CQv, 5, 1, 1, 1, 8, 32, 5, 8, pre + 4L * P * CQv, CQv, Ho, Wo, dY, dBN + P * CQv, 0, spart + (long)G * 2 * CQv * 2) \
+    g5b = grid;                                                                                                            \
     if ((rc = lct_check_launch("edge_bwd_conv(sep5b)"))) return rc;                                                        \
-    hipLaunchKernelGGL(edge_bwd_coef_a_kernel, dim3(2 * CQv), dim3(64), 0, st, spart, G, CQv, P, training, invstd, coef);  \
+    hipLaunchKernelGGL(edge_bwd_coef_a_kernel, dim3(2 * CQv), dim3(64), 0, st, spart, G, g3b, g5b, CQv, P, training, invstd, coef); \
     if ((rc = lct_check_launch("edge_bwd_coef_a"))) return rc;                                                             \
-    CONV(CQv, 3, 1, Sv, 2, THv, TWv, 0, 3, x, C, H, W, dBN, dx, (double*)nullptr)                                          \
+    CONV(CQv, 3, 1, Sv, 2, THv, TWv, 0, 3, x, C, H, W, dBN, dx1c, 1, (double*)nullptr)                                     \
     if ((rc = lct_check_launch("edge_bwd_conv(sep3a)"))) return rc;                                                        \
-    CONV(CQv, 5, 1, Sv, 2, THv, TWv, 1, 4, x, C, H, W, dBN + P * CQv, dx, (double*)nullptr)                                \
+    CONV(CQv, 5, 1, Sv, 2, THv, TWv, 1, 4, x, C, H, W, dBN + P * CQv, dx1c, 1, (double*)nullptr)                           \
     if ((rc = lct_check_launch("edge_bwd_conv(sep5a)"))) return rc;                                                        \
+    {                                                                                                                      \
+      const size_t lds = bwd_pools_lds<CQv, Sv, 8, 32>();                                                                  \
+      grid = tile_grid((const void*)edge_bwd_pools_kernel<CQv, Sv, 8, 32>, 256, lds, TILES(H, W, 8, 32), G);               \
+      rows.n[6] = grid;                                                                                                    \
+      hipLaunchKernelGGL((edge_bwd_pools_kernel<CQv, Sv, 8, 32>), dim3(grid), dim3(256), lds, st, x, dY, dout, ldd, beta, pre, mean, invstd, \
+                         coef, dx1c, B, H, W, ew, dx, wpart, wtot, fr_off);                                                \
+      if ((rc = lct_check_launch("edge_bwd_pools"))) return rc;                                                            \
+    }                                                                                                                      \
   }
-  if (CQ == 4 && stride == 1) STAGE_FINAL(4, 1, 8, 32)
-  else if (CQ == 4) STAGE_FINAL(4, 2, 8, 32)
-  else if (CQ == 8 && stride == 1) STAGE_FINAL(8, 1, 8, 32)
-  else if (CQ == 8) STAGE_FINAL(8, 2, 8, 32)
-  else if (stride == 1) STAGE_FINAL(16, 1, 8, 32)
-  else STAGE_FINAL(16, 2, 8, 16)
+  if (CQ == 4 && stride == 1) STAGES(4, 1, 8, 32)
+  else if (CQ == 4) STAGES(4, 2, 8, 32)
+  else if (CQ == 8 && stride == 1) STAGES(8, 1, 8, 32)
+  else if (CQ == 8) STAGES(8, 2, 8, 32)
+  else if (stride == 1) STAGES(16, 1, 8, 32)
+  else STAGES(16, 2, 8, 16)
   const int ncols = stride == 2 ? wtot : fr_off;               // stride-1 edges have no FactorizedReduce
-  hipLaunchKernelGGL(edge_wgrad_finish_kernel, dim3(ncols), dim3(64), 0, st, wpart, G, wtot, 0, wgrad);
+  hipLaunchKernelGGL(edge_wgrad_finish_kernel, dim3(ncols), dim3(64), 0, st, wpart, rows, wtot, CQ, wgrad);
   return lct_check_launch("edge_wgrad_finish");
-#undef STAGE_FINAL
+#undef STAGES
 #undef CONV
-#undef POOLS
-#undef EDGE_LAUNCH
+#undef TILES
 }
 
 }  // extern "C"

@@ -390,8 +390,15 @@ class MixedEdgeFn(torch.autograd.Function):
         x, wsel, beta, pre, stats = ctx.saved_tensors[:5]
         weights = list(ctx.saved_tensors[5:])
         stride, training, has_prev = ctx.cfg
-        dout = _chk(dout)
         B, H, W, C = x.shape
+        Ho, Wo = H // stride, W // stride
+        # the node's gradient usually arrives as a channel slice of the gradient of the cell's concatenated output: rows of
+        # C floats, ldd apart -- taken as it is (the kernels take a row stride) instead of being copied
+        ldd = dout.stride(2)
+        if not (dout.is_cuda and dout.dtype == torch.float32 and dout.stride(3) == 1 and ldd % 4 == 0 and dout.stride(1) == Wo * ldd
+                and dout.stride(0) == Ho * Wo * ldd and dout.data_ptr() % 16 == 0):
+            dout = _chk(dout)
+            ldd = C
         Cq, dev = C // 4, x.device
         dx = torch.empty_like(x)
         dw = torch.empty(7, dtype=torch.float32, device=dev)
@@ -399,7 +406,7 @@ class MixedEdgeFn(torch.autograd.Function):
         wgrad = torch.empty(lib.query('mixed_edge_wgrad_elems', C), dtype=torch.float32, device=dev)
         scratch = _scratch(lib.query('mixed_edge_bwd_scratch_floats', B, H, W, C, stride), torch.float32, dev)
         wptr = (ctypes.c_void_p * 14)(*([w.data_ptr() for w in weights] + [None] * (14 - len(weights))))
-        lib('mixed_edge_bwd', dout, dout.stride(2), x, B, H, W, C, stride, wptr, pre, stats[0], stats[1], wsel, beta, dx, dw, dbeta,
+        lib('mixed_edge_bwd', dout, ldd, x, B, H, W, C, stride, wptr, pre, stats[0], stats[1], wsel, beta, dx, dw, dbeta,
             wgrad, scratch, training)
         grads, o = [], 0
         for w in weights:
