@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # same guide: dense bf16 MFMA (AMD's 5 PF figure includes 2:1 sparsity)
 DIMS = dict(embed_size=512, qst_vocab_size=17858, ans_vocab_size=3129, word_embed_size=300, num_layers=1, hidden_size=512)
 
 
@@ -60,6 +61,9 @@ def parse():
                          "experiment.py:216-268 (EF fixed encoder + generate + W soft loss), reported under its own metric name")
     ap.add_argument('--lct-no-share', dest='lct_share_trunk', action='store_false',
                     help="--workload lct: evaluate the examiner's frozen trunk separately for stage 1 and stage 2 (default: once per batch)")
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help="arithmetic of the frozen VGG19 trunk: 'f32' = the reference's (the headline); 'bf16' = bf16 activations/weights with fp32 "
+                         "accumulation (BASELINE.json's bf16 configurations), reported under its OWN metric name, never as the headline")
     ap.add_argument('--conv-algo', default=None, choices=['winograd', 'winograd2', 'direct'],
                     help='trunk convolution algorithm (default: LCTVQA_CONV_ALGO or winograd = F(4x4,3x3) / F(2x2,3x3) / direct by shape; all fp32)')
     return ap.parse_args()
@@ -91,7 +95,7 @@ def conv_source_stamp():
     """Hash of the trunk-convolution kernel sources: a committed PMC profile is only quoted for the kernels it measured."""
     import hashlib
     h = hashlib.sha256()
-    for f in ('conv3x3.hip', 'conv3x3_wino.hip', 'conv3x3_wino4.hip', 'common.h'):
+    for f in ('conv3x3.hip', 'conv3x3_bf16.hip', 'conv3x3_wino.hip', 'conv3x3_wino4.hip', 'common.h'):
         with open(os.path.join(ROOT, 'lct_vqa_amd', 'csrc', f), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -165,6 +169,7 @@ def main():
     lib.load()                                      # fail loudly if the HIP library is missing
     if args.conv_algo:
         ops.set_conv_algo(args.conv_algo)
+    ops.set_compute_dtype(args.dtype)
     rank, world, local = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
@@ -401,16 +406,19 @@ def main():
     executed = tot_exec / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     nwino = sum(1 for r in conv if r['name'].startswith('wino'))
     nw4 = sum(1 for r in conv if r['name'].startswith('wino4'))
+    nbf = sum(1 for r in conv if r['name'].startswith('bf16'))
+    peak = BF16_MFMA_PEAK_TFLOPS if nbf else FP32_MFMA_PEAK_TFLOPS
     # achieved / frac: the multiply-adds the kernels' ALGORITHM performs on the MFMA pipe (Winograd F(4x4,3x3): 36 per
     # 4x4 output tile and channel pair = 1/4 of direct convolution's 144; F(2x2,3x3): 1/2.25) over the live HIP-event
     # time of those launches, against the dense fp32 MFMA peak: a utilisation, <= 1.  What Winograd buys on top is
     # `algorithmic_speedup`; `direct_equivalent_tflops` = the direct-convolution FLOP count per second.
     roofline = {'bound': 'mfma',
-                'kernel': ('conv3x3_wino4_kernel (Winograd F(4x4,3x3), %d launches) + conv3x3_wino2/3_kernel (F(2x2,3x3), %d) + '
+                'kernel': ('conv3x3_bf16_kernel (direct implicit GEMM on v_mfma_f32_32x32x16_bf16, fp32 accumulate, %d launches)' % nbf) if nbf else
+                          ('conv3x3_wino4_kernel (Winograd F(4x4,3x3), %d launches) + conv3x3_wino2/3_kernel (F(2x2,3x3), %d) + '
                            'conv3x3_mfma_kernel (direct, %d): fp32 MFMA' % (nw4, nwino - nw4, nlaunch - nwino)) if nwino else
                           'conv3x3_mfma_kernel (direct implicit GEMM, 15 VGG19 layers/step)',
-                'algorithm': algo, 'achieved': round(executed, 2),
-                'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
+                'algorithm': 'direct' if nbf else algo, 'achieved': round(executed, 2),
+                'peak': peak, 'unit': 'TFLOP/s', 'frac': round(executed / peak, 4),
                 'algorithmic_speedup': round(tot_flops / tot_exec, 3) if tot_exec else None,
                 'direct_equivalent_tflops': round(direct_equiv, 2),
                 'traffic': None, 'launches': nlaunch, 'avg_launch_ms': round(tot_ms / nlaunch, 4),
@@ -420,7 +428,7 @@ def main():
     # HBM bytes per launch of the same kernel family from the committed rocprofv3 --pmc passes of this command (FETCH_SIZE,
     # WRITE_SIZE: tools/pmc_profile.py); used only while the kernels are the ones that were profiled (source stamp)
     try:
-        pfile = 'r02_pmc_conv_wino.json' if nwino else 'r01_pmc_conv_gemm.json'
+        pfile = 'r02_pmc_conv_bf16.json' if nbf else 'r02_pmc_conv_wino.json' if nwino else 'r01_pmc_conv_gemm.json'
         pm = json.load(open(os.path.join(ROOT, 'profiles', pfile)))
         if pm.get('csrc_stamp') in (None, conv_source_stamp()):
             roofline['traffic'] = pm['conv3x3_family']['hbm_bytes_per_launch']
@@ -442,10 +450,11 @@ def main():
                 f.write(f"{k}: {a['ms'] / a['n']:.3f} ms/launch, {a['flops'] / a['ms'] / 1e9:.1f} TFLOP/s ({a['n']} launches)\n")
     out = {
         'metric': ('image-question pairs/sec (train step) at 224x224, seq=14, 3129-way' if args.workload == 'w' else
-                   'image-question pairs/sec (LCT stage1+stage2 step: EF + generate + W soft loss) at 224x224, seq=14, 3129-way'),
+                   'image-question pairs/sec (LCT stage1+stage2 step: EF + generate + W soft loss) at 224x224, seq=14, 3129-way')
+                  + (' [bf16 frozen trunk, fp32 accumulate, fp32 heads: NOT the headline fp32 metric]' if args.dtype == 'bf16' else ''),
         'value': round(value, 2),
         'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': ('basic_vqa VGG19+LSTM fp32 W-model train step (frozen VGG19 trunk, fwd+CE+bwd+clip+Adam), '
                                 'batch %d per GPU, 224x224x3 images, 14-token questions, 3129 answers, QV=17858' % B)
                                if args.workload == 'w' else

@@ -237,6 +237,17 @@ int lctvqa_mixed_combine_bwd_scalars(const float* dout, long ldd, const float* c
                                      const float* beta, const float* x, int B, int Ho, int Wo, int C, int reduce, float* dw,
                                      float* dbeta, float* scratch, void* stream);
 
+/* ---- bf16 compute path of a FROZEN VGG19 trunk (BASELINE.json's bf16 configurations; the reference is fp32 throughout,
+ *      basic_vqa/models.py:23-42): bf16 NHWC activations and packed weights, fp32 accumulation on
+ *      v_mfma_f32_32x32x16_bf16, fused bias + ReLU (+ 2x2 max pool): csrc/conv3x3_bf16.hip ---- */
+int lctvqa_conv3x3_bf16_supported(int B, int H, int W, int Cin, int Cout, int pool);
+int lctvqa_conv3x3_bf16_pack_weights(const float* w_oihw, void* w_packed /* Cout*Cin*9 bf16 */, int Cout, int Cin, void* stream);
+int lctvqa_conv3x3_bf16_nhwc(const void* x_bf16, const void* w_packed, const float* bias, void* y_bf16, int B, int H, int W, int Cin,
+                             int Cout, int relu, int pool, void* stream);
+int lctvqa_conv3x3_first_nchw_bf16(const float* x_nchw, const float* w_oihw, const float* bias, void* y_nhwc_bf16, int B, int H, int W,
+                                   int Cout, int relu, void* stream);
+int lctvqa_adaptive_avgpool7_flatten_bf16(const void* x_nhwc_bf16, float* y, int B, int H, int W, int C, void* stream);
+
 /* One PC-DARTS MixedOp edge as fused tile kernels (model_search.py:22-55 + the seven live primitives of operations.py:4-20
  * on x[..., :C/4], their BatchNorms, the alpha-weighted sum, bypass, channel shuffle and the beta-weighted accumulation
  * into the node's sum, model_search.py:87): csrc/mixed_edge.hip.  w = 14 device pointers: depthwise weights [Cq][K][K] of

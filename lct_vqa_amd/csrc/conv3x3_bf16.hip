@@ -1,0 +1,428 @@
+// 3x3 / stride 1 / pad 1 convolution of a FROZEN VGG19 trunk in bf16 (fp32 accumulate) on gfx950: the mixed-precision
+// form of the path in conv3x3.hip, for BASELINE.json's bf16 configurations.  The reference is fp32 throughout
+// (basic_vqa/models.py:23-42); this is an opt-in compute dtype (ops.set_compute_dtype('bf16')) whose results are
+// compared with the fp32 oracle under a stated tolerance, never the headline path.
+//
+// Same design as the fp32 direct kernel (conv3x3.hip): NHWC activations as "stacked rows", implicit GEMM M = pixels,
+// N = Cout, K = 9*Cin with no im2col buffer, zero-padded halo patch brought HBM->LDS by LDS-DMA once per channel chunk
+// and reused by the 9 taps, image boundaries inside a patch as one shared zero row per image, planar 16-byte LDS slots
+// (every fragment read is ds_read_b128 at base + immediate), fused bias + ReLU + 2x2 max-pool epilogue.  What changes:
+//   * a 16-byte slot holds 8 bf16 channels, a channel chunk is 32 channels (4 planes), and the contraction runs on
+//     v_mfma_f32_32x32x16_bf16: lane half h of k16-step kk reads plane 2*kk + h -- 16x the MFMA rate of the fp32 form,
+//     so a (chunk, tap) step is only ~500 MFMA cycles and the kernel lives on two workgroups per CU covering each
+//     other's barriers, and on a wave tile with TWO 32-channel N-subtiles (4 A + 2 B fragment reads per 8 MFMAs)
+//     to stay off the LDS bandwidth;
+//   * weights are packed to bf16 [Cout/32][(Cin/32)*9][4 planes][32 cout][8 ch]; activations are stored bf16.
+// Roofline: MFMA (dense bf16 peak ~2.5 PFLOP/s); algorithmic bytes per launch = 2 B * (B*H*W*Cin + B*Ho*Wo*Cout).
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+__device__ __attribute__((aligned(64))) float g_zero_page_bf16[64];
+
+__device__ __forceinline__ unsigned short f2bf(float v) {
+  const __bf16 b = (__bf16)v;                                   // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+// OIHW fp32 [Cout][Cin][3][3] -> bf16 [Cout/32][S = (Cin/32)*9][4 planes][32 cout][8 ch]
+__global__ void conv3x3_bf16_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cout, int Cin) {
+  const long total = (long)Cout * Cin * 9;
+  const int S = (Cin / 32) * 9;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const int e = o & 7;
+    const int j = (o >> 3) & 31;
+    const int c = (o >> 8) & 3;
+    const long rest = o >> 10;
+    const int s = rest % S;
+    const int nt = rest / S;
+    const int chunk = s / 9, tap = s % 9;
+    const int co = nt * 32 + j;
+    const int ci = chunk * 32 + c * 8 + e;
+    wp[o] = f2bf(w[((long)co * Cin + ci) * 9 + tap]);
+  }
+}
+
+// pixel of row rr of M-subtile msub (see conv3x3.hip: the four pixels of a 2x2 pooling window share a lane)
+template <int SH, int SW, int TW>
+__device__ __forceinline__ void subtile_pixel(int msub, int rr, int& ty, int& tx) {
+  static_assert(SH * SW == 32 && SH % 2 == 0 && SW % 2 == 0, "sub-tile shape");
+  const int a = rr >> 3, hh = (rr >> 2) & 1, b = rr & 3;
+  const int u = (a >> 1) * 4 + hh * 2 + (b >> 1);
+  const int cx = u % (SW / 2), cy = u / (SW / 2);
+  const int sx = 2 * cx + (b & 1), sy = 2 * cy + (a & 1);
+  constexpr int SPR = TW / SW;
+  ty = (msub / SPR) * SH + sy;
+  tx = (msub % SPR) * SW + sx;
+}
+
+// WM x WNW waves (= 4); a wave owns MT M-subtiles (32 pixels) x NT2 N-subtiles (32 channels); BN = 32 * WNW * NT2
+template <int TH, int TW, int RS, int SH, int SW, int WM, int WNW, int MT, int NT2, bool POOL>
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wp,
+                                                              const float* __restrict__ bias, unsigned short* __restrict__ y, int Btot,
+                                                              int H, int W, int Cin, int Cout, int relu, int G) {
+  static_assert(TH * TW == WM * MT * 32, "tile mismatch");
+  static_assert(TW % SW == 0 && TH % SH == 0, "sub-tile must tile the patch");
+  static_assert(WM * WNW == 4, "4 waves");
+  static_assert(RS >= TW + 2, "LDS row stride must cover the halo row");
+  constexpr int TWP = RS;
+  constexpr int HRMAX = TH + 4;
+  constexpr int PMAX = HRMAX * TWP;
+  constexpr int AROUNDS = (PMAX + 63) / 64;
+  constexpr int PPAD = AROUNDS * 64;
+  constexpr int PLANE = PPAD * 4;                     // floats (16 B per pixel) per 8-channel plane
+  constexpr int ASZ = 4 * PLANE;
+  constexpr int NP = WNW * NT2;                       // 32-channel weight pieces per step
+  constexpr int WSZ = NP * 512;                       // floats per weight step tile (2 KB per piece)
+  constexpr int WCHUNKS = NP * 128;                   // 16-B slots per weight step tile
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* abuf = smem;                // [2][ASZ]
+  float* wbuf = smem + 2 * ASZ;      // [2][WSZ]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WNW, wn = wave % WNW;
+  const int j = lane & 31, h = lane >> 5;
+
+  const int NT = Cout / (32 * NP);
+  const int n_tile = blockIdx.x % NT;                 // blocks are dealt round-robin over the XCDs: one n-tile's weights per L2
+  const int m_tile = blockIdx.x / NT;
+  const int CT = W / TW;
+  const int ct = m_tile % CT, rt = m_tile / CT;
+  const int R0 = rt * TH, x0 = ct * TW;
+  const int Rtot = Btot * H;
+  const int n0img = R0 / H, y0 = R0 % H;
+  const int NCH = Cin / 32;
+  const int S = NCH * 9;
+  const int PLIVE = (TH + 2 + G) * TWP;
+
+  int aoff[AROUNDS];                                  // element offset of this lane's 16-B slot of halo pixel r*64 + lane (plane = wave)
+#pragma unroll
+  for (int r = 0; r < AROUNDS; r++) {
+    const int p = r * 64 + lane;
+    const int hr = p / TWP, hx = p % TWP;
+    const int xx = x0 - 1 + hx;
+    int yv = y0 - 1 + hr;
+    int n = n0img;
+    while (yv > H) { yv -= (H + 1); n++; }
+    const bool ok = (p < PLIVE) && (hx < TW + 2) && (yv >= 0) && (yv < H) && (n < Btot) && (xx >= 0) && (xx < W);
+    aoff[r] = ok ? (((n * H + yv) * W + xx) * Cin + wave * 8) : -1;
+  }
+  int base[MT];
+#pragma unroll
+  for (int m = 0; m < MT; m++) {
+    int ty, tx;
+    subtile_pixel<SH, SW, TW>(wm * MT + m, j, ty, tx);
+    const int yy = y0 + ty;
+    const int g = (yy >= H) + (yy >= 2 * H);
+    base[m] = ((ty + g) * TWP + tx) * 4 + h * PLANE;
+  }
+  const int bbase = (wn * NT2) * 512 + h * 128 + j * 4;
+  const unsigned short* wsrc = wp + (long)(n_tile * NP) * S * 1024;      // [NP pieces][S][1024 bf16]
+
+  auto stage_a = [&](int chunk, float* dst) {
+#pragma unroll
+    for (int r = 0; r < AROUNDS; r++) {
+      if (r * 64 < PLIVE) {
+        const float* src = (aoff[r] >= 0) ? (const float*)(x + (long)aoff[r] + chunk * 32) : g_zero_page_bf16;
+        glds16(src, dst + wave * PLANE + r * 256);
+      }
+    }
+  };
+  auto stage_w = [&](int s, float* dst) {
+#pragma unroll
+    for (int r = 0; r < (WCHUNKS + 255) / 256; r++) {
+      const int q = r * 256 + tid;
+      if (WCHUNKS >= 256 * (r + 1) || q < WCHUNKS) {
+        const int piece = q >> 7, within = q & 127;
+        glds16((const float*)(wsrc + ((long)piece * S + s) * 1024 + within * 8), dst + (r * 256 + wave * 64) * 4);
+      }
+    }
+  };
+
+  f32x16 acc[MT][NT2];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int nn = 0; nn < NT2; nn++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][nn][r] = 0.f;
+
+  stage_a(0, abuf);
+  stage_w(0, wbuf);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int s = 0;
+  for (int chunk = 0; chunk < NCH; chunk++) {
+    const float* ab = abuf + (chunk & 1) * ASZ;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++, s++) {
+      if (s + 1 < S) stage_w(s + 1, wbuf + ((s + 1) & 1) * WSZ);
+      if (tap == 0 && chunk + 1 < NCH) stage_a(chunk + 1, abuf + ((chunk + 1) & 1) * ASZ);
+      const float* wb = wbuf + (s & 1) * WSZ + bbase;
+      const int tapoff = ((tap / 3) * TWP + (tap % 3)) * 4;
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++) {
+        bf16x8 bf[NT2];
+#pragma unroll
+        for (int nn = 0; nn < NT2; nn++) bf[nn] = __builtin_bit_cast(bf16x8, *(const f32x4*)(wb + nn * 512 + kk * 256));
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+          const bf16x8 af = __builtin_bit_cast(bf16x8, *(const f32x4*)(ab + base[m] + tapoff + kk * 2 * PLANE));
+#pragma unroll
+          for (int nn = 0; nn < NT2; nn++) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nn], acc[m][nn], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: bias + ReLU (+ in-register 2x2 max pool), bf16 NHWC store ----
+#pragma unroll
+  for (int nn = 0; nn < NT2; nn++) {
+    const int co = (n_tile * NP + wn * NT2 + nn) * 32 + j;
+    const float bv = bias ? bias[co] : 0.f;
+    if (!POOL) {
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+          int ty, tx;
+          subtile_pixel<SH, SW, TW>(wm * MT + m, rr, ty, tx);
+          const int R = R0 + ty;
+          if (R < Rtot) {
+            float v = acc[m][nn][r] + bv;
+            if (relu) v = fmaxf(v, 0.f);
+            y[((long)R * W + x0 + tx) * Cout + co] = f2bf(v);
+          }
+        }
+      }
+    } else {
+      const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+#pragma unroll
+        for (int ap = 0; ap < 2; ap++) {
+#pragma unroll
+          for (int bp = 0; bp < 2; bp++) {
+            const int r00 = 8 * ap + 2 * bp;
+            float v = fmaxf(fmaxf(acc[m][nn][r00], acc[m][nn][r00 + 1]), fmaxf(acc[m][nn][r00 + 4], acc[m][nn][r00 + 5])) + bv;
+            if (relu) v = fmaxf(v, 0.f);
+            const int rr = (2 * bp) + 8 * (2 * ap) + 4 * h;
+            int ty, tx;
+            subtile_pixel<SH, SW, TW>(wm * MT + m, rr, ty, tx);
+            const int R = R0 + ty;
+            if (R < Rtot) {
+              const int n = R / H, yy = R % H;
+              const long opix = ((long)n * Ho + (yy >> 1)) * Wo + ((x0 + tx) >> 1);
+              y[opix * Cout + co] = f2bf(v);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// first layer (Cin = 3): fp32 NCHW image -> bf16 NHWC, bias + ReLU.  HBM-write bound; lane = output channel, 8 pixels of
+// a row per wave iteration held in registers, the three zero-padded input rows of each channel in LDS read as wave-uniform
+// 16-byte broadcasts (the scheme of conv3x3_first_kernel in conv3x3.hip).
+__global__ __launch_bounds__(256) void conv3x3_first_bf16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, unsigned short* __restrict__ y, int B, int H,
+                                                                 int W, int Cout, int relu) {
+  constexpr int PX = 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [9 (ch, row)][WP] with index i <-> x = i - 1, then [27][64] weights
+  const int WP = (W + 2 + PX + 3) & ~3;
+  const int R = blockIdx.x, n = R / H, yy = R % H;
+  for (int i = threadIdx.x; i < 9 * WP; i += blockDim.x) {
+    const int cr = i / WP, xx = i % WP - 1;
+    const int c = cr / 3, iy = yy + (cr % 3) - 1;
+    const bool ok = iy >= 0 && iy < H && xx >= 0 && xx < W;
+    smem[i] = ok ? x[(((long)n * 3 + c) * H + iy) * W + xx] : 0.f;
+  }
+  float* wsm = smem + 9 * WP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int cg = 0; cg < Cout; cg += 64) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * 64; i += blockDim.x) wsm[i] = w[min(cg + (i & 63), Cout - 1) * 27 + (i >> 6)];
+    __syncthreads();
+    const int co = cg + lane;
+    const float bv = (bias && co < Cout) ? bias[co] : 0.f;
+    for (int x0 = wave * PX; x0 < W; x0 += nw * PX) {
+      float a[PX];
+#pragma unroll
+      for (int i = 0; i < PX; i++) a[i] = bv;
+#pragma unroll 1
+      for (int cr = 0; cr < 9; cr++) {
+        const float* row = smem + cr * WP + x0;                  // wave-uniform, 16-byte aligned
+        const f32x4 i0 = *(const f32x4*)row, i1 = *(const f32x4*)(row + 4), i2 = *(const f32x4*)(row + 8);
+        const float in[12] = {i0[0], i0[1], i0[2], i0[3], i1[0], i1[1], i1[2], i1[3], i2[0], i2[1], i2[2], i2[3]};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const float wv = wsm[(cr * 3 + k) * 64 + lane];
+#pragma unroll
+          for (int i = 0; i < PX; i++) a[i] = fmaf(in[i + k], wv, a[i]);
+        }
+      }
+      if (co < Cout) {
+#pragma unroll
+        for (int i = 0; i < PX; i++)
+          if (x0 + i < W) y[((long)R * W + x0 + i) * Cout + co] = f2bf(relu ? fmaxf(a[i], 0.f) : a[i]);
+      }
+    }
+  }
+}
+
+// AdaptiveAvgPool2d((7,7)) + flatten in NCHW order: bf16 NHWC [B,H,W,C] -> fp32 [B, C*49]
+__global__ void adaptive_avgpool7_flatten_bf16_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
+  const long total = (long)B * C * 49;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const int c = o % C;
+    const int cell = (o / C) % 49;
+    const int n = o / ((long)C * 49);
+    const int oy = cell / 7, ox = cell % 7;
+    const int ys = (oy * H) / 7, ye = ((oy + 1) * H + 6) / 7;
+    const int xs = (ox * W) / 7, xe = ((ox + 1) * W + 6) / 7;
+    float a = 0.f;
+    for (int iy = ys; iy < ye; iy++)
+      for (int ix = xs; ix < xe; ix++) {
+        const unsigned int bits = (unsigned int)x[(((long)n * H + iy) * W + ix) * C + c] << 16;
+        a += __builtin_bit_cast(float, bits);
+      }
+    y[((long)n * C + c) * 49 + cell] = a / (float)((ye - ys) * (xe - xs));
+  }
+}
+
+int max_boundaries(int H, int TH, long Rtot) {
+  int best = 0;
+  const long lim = Rtot < (long)H * TH * 2 ? Rtot : (long)H * TH * 2;
+  for (long R0 = 0; R0 < lim; R0 += TH) {
+    const int g = (int)((R0 + TH - 1) / H - R0 / H);
+    if (g > best) best = g;
+  }
+  return best;
+}
+
+template <int TH, int TW, int RS, int SH, int SW, int WM, int WNW, int MT, int NT2>
+int launch_conv(const unsigned short* x, const unsigned short* wp, const float* bias, unsigned short* y, int B, int H, int W, int Cin,
+                int Cout, int relu, int pool, int G, hipStream_t st) {
+  constexpr int AROUNDS = ((TH + 4) * RS + 63) / 64;
+  constexpr int ASZ = AROUNDS * 64 * 16;
+  constexpr int WSZ = WNW * NT2 * 512;
+  const size_t lds = (size_t)(2 * ASZ + 2 * WSZ) * sizeof(float);
+  const long Rtot = (long)B * H;
+  const int mtiles = cdiv(Rtot, TH) * (W / TW);
+  const int ntiles = Cout / (32 * WNW * NT2);
+  const dim3 grid(mtiles * ntiles);
+  if (pool) {
+    auto k = conv3x3_bf16_kernel<TH, TW, RS, SH, SW, WM, WNW, MT, NT2, true>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, wp, bias, y, B, H, W, Cin, Cout, relu, G);
+  } else {
+    auto k = conv3x3_bf16_kernel<TH, TW, RS, SH, SW, WM, WNW, MT, NT2, false>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, wp, bias, y, B, H, W, Cin, Cout, relu, G);
+  }
+  return lct_check_launch("conv3x3_bf16");
+}
+
+// patch: 1 (8,32), 2 (8,28), 4 (16,14), 5 (32,8); 0 none
+int select_patch(int W) {
+  if (W % 32 == 0) return 1;
+  if (W % 8 == 0) return 5;
+  if (W % 28 == 0) return 2;
+  if (W % 14 == 0) return 4;
+  return 0;
+}
+int patch_th(int sel) { return sel == 1 || sel == 2 ? 8 : (sel == 5 ? 32 : 16); }
+
+}  // namespace
+
+extern "C" {
+
+// 1 when the bf16 MFMA kernel tiles this layer
+int lctvqa_conv3x3_bf16_supported(int B, int H, int W, int Cin, int Cout, int pool) {
+  if (Cin % 32 || Cout % 64) return 0;
+  if (pool && ((H & 1) || (W & 1))) return 0;
+  const int sel = select_patch(W);
+  if (!sel) return 0;
+  if ((sel == 2 || sel == 4) && Cout % 128) return 0;         // the 224-pixel patches exist in the 1 x 4 wave layout only
+  if (max_boundaries(H, patch_th(sel), (long)B * H) > 2) return 0;
+  if ((long)B * H * W * Cin >= (1L << 31)) return 0;
+  return 1;
+}
+
+// fp32 OIHW parameter -> bf16 kernel layout (Cout*Cin*9 bf16)
+int lctvqa_conv3x3_bf16_pack_weights(const float* w_oihw, void* w_packed, int Cout, int Cin, void* stream) {
+  LCT_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3x3_bf16_pack_weights: need Cin%%32==0, Cout%%32==0 (got %d,%d)", Cin, Cout);
+  const long total = (long)Cout * Cin * 9;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(conv3x3_bf16_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, (unsigned short*)w_packed, Cout, Cin);
+  return lct_check_launch("conv3x3_bf16_pack");
+}
+
+// x bf16 NHWC [B,H,W,Cin] -> y bf16 NHWC [B,H,W,Cout] (or [B,H/2,W/2,Cout] when pool); bias fp32; fp32 accumulation
+int lctvqa_conv3x3_bf16_nhwc(const void* x, const void* w_packed, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                             int relu, int pool, void* stream) {
+  LCT_REQUIRE(lctvqa_conv3x3_bf16_supported(B, H, W, Cin, Cout, pool), "conv3x3_bf16_nhwc: unsupported shape H=%d W=%d Cin=%d Cout=%d", H, W, Cin, Cout);
+  LCT_REQUIRE((((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y) & 15) == 0, "conv3x3_bf16_nhwc: tensors must be 16-B aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned short* xs = (const unsigned short*)x;
+  const unsigned short* ws = (const unsigned short*)w_packed;
+  unsigned short* ys = (unsigned short*)y;
+  const long Rtot = (long)B * H;
+  const bool wide = (Cout % 128 == 0);
+  // 256-pixel patches: 2 x 2 waves, wave = 4 M-subtiles x 2 N-subtiles (128 channels) or x 1 (64 channels);
+  // 224-pixel patches: 1 x 4 waves, wave = 7 M-subtiles x 1 N-subtile (128 channels)
+#define LAUNCH256(TH, TW, RS, SH, SW)                                                                                       \
+  do {                                                                                                                     \
+    const int G = max_boundaries(H, TH, Rtot);                                                                             \
+    if (wide) return launch_conv<TH, TW, RS, SH, SW, 2, 2, 4, 2>(xs, ws, bias, ys, B, H, W, Cin, Cout, relu, pool, G, st);  \
+    return launch_conv<TH, TW, RS, SH, SW, 2, 2, 4, 1>(xs, ws, bias, ys, B, H, W, Cin, Cout, relu, pool, G, st);            \
+  } while (0)
+#define LAUNCH224(TH, TW, RS, SH, SW)                                                                                       \
+  do {                                                                                                                     \
+    const int G = max_boundaries(H, TH, Rtot);                                                                             \
+    return launch_conv<TH, TW, RS, SH, SW, 1, 4, 7, 1>(xs, ws, bias, ys, B, H, W, Cin, Cout, relu, pool, G, st);            \
+  } while (0)
+  switch (select_patch(W)) {
+    case 1: LAUNCH256(8, 32, 34, 2, 16); break;
+    case 5: LAUNCH256(32, 8, 10, 4, 8); break;
+    case 2: LAUNCH224(8, 28, 30, 8, 4); break;
+    case 4: LAUNCH224(16, 14, 18, 16, 2); break;
+    default: break;
+  }
+#undef LAUNCH256
+#undef LAUNCH224
+  lct_set_error("conv3x3_bf16_nhwc: no tiling for H=%d W=%d Cin=%d Cout=%d", H, W, Cin, Cout);
+  return LCT_EUNSUPPORTED;
+}
+
+// first VGG layer: fp32 NCHW image [B,3,H,W] -> bf16 NHWC [B,H,W,Cout]
+int lctvqa_conv3x3_first_nchw_bf16(const float* x_nchw, const float* w_oihw, const float* bias, void* y_nhwc, int B, int H, int W, int Cout,
+                                   int relu, void* stream) {
+  LCT_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_first_bf16: bad shape");
+  const size_t lds = (size_t)(9 * ((W + 2 + 8 + 3) & ~3) + 27 * 64) * sizeof(float);
+  LCT_REQUIRE(lds <= 64 * 1024, "conv3x3_first_bf16: W too large");
+  hipLaunchKernelGGL(conv3x3_first_bf16_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, x_nchw, w_oihw, bias,
+                     (unsigned short*)y_nhwc, B, H, W, Cout, relu);
+  return lct_check_launch("conv3x3_first_bf16");
+}
+
+int lctvqa_adaptive_avgpool7_flatten_bf16(const void* x_nhwc, float* y, int B, int H, int W, int C, void* stream) {
+  const long t = (long)B * C * 49;
+  int b = (int)((t + 255) / 256);
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(adaptive_avgpool7_flatten_bf16_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x_nhwc, y, B, H, W, C);
+  return lct_check_launch("adaptive_avgpool7_flatten_bf16");
+}
+
+}  // extern "C"

@@ -545,13 +545,11 @@ __global__ __launch_bounds__(256) void edge_bwd_coef_kernel(const float* __restr
                                                             float* __restrict__ dw, float* __restrict__ dbeta) {
   __shared__ double tot[8 * 16 + 1];
   const int ncol = 8 * CQ + 1;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int col = wv; col < ncol; col += 4) {
+  if (threadIdx.x < ncol) {                                    // thread = column: a row is read by neighbouring lanes (coalesced)
     double a = 0.0;
-    for (int b = lane; b < nblk; b += 64) a += (double)part[(long)b * ncol + col];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    if (lane == 0) tot[col] = a;
+#pragma unroll 8
+    for (int b = 0; b < nblk; b++) a += (double)part[(long)b * ncol + threadIdx.x];
+    tot[threadIdx.x] = a;
   }
   __syncthreads();
   const int slot_of[7] = {0, 1, 2, 7, 8, 5, 6};
@@ -1248,7 +1246,7 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
   int rc, grid = 1, g3b = 1, g5b = 1;
   {
     long nb = (P * (CQ / 4) + 255) / 256;
-    if (nb > 512) nb = 512;
+    if (nb > 256) nb = 256;                                      // one row of partials per workgroup: keep the finish short
     if (stride == 1)
       hipLaunchKernelGGL(edge_bwd_sums_kernel<1>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, part1);
     else

@@ -647,6 +647,25 @@ def get_conv_algo():
     return _conv_algo
 
 
+_compute_dtype = os.environ.get('LCTVQA_COMPUTE_DTYPE', 'f32')
+
+
+def set_compute_dtype(name):
+    """Arithmetic of a FROZEN VGG19 trunk's convolutions: 'f32' (default: the reference's arithmetic, the only headline
+    path) or 'bf16' (bf16 activations / weights, fp32 accumulation on v_mfma_f32_32x32x16_bf16, csrc/conv3x3_bf16.hip:
+    BASELINE.json's bf16 configurations).  Everything trainable -- classifier, question encoder, fusion head, a trunk that
+    needs gradients -- keeps fp32 master weights and fp32 kernels.  Returns the previous setting."""
+    global _compute_dtype
+    if name not in ('f32', 'bf16'):
+        raise ValueError(name)
+    prev, _compute_dtype = _compute_dtype, name
+    return prev
+
+
+def get_compute_dtype():
+    return _compute_dtype
+
+
 def _timed(name, flops, nbytes, fn):
     if _conv_timer is None:
         fn()
@@ -670,9 +689,9 @@ def _timed(name, flops, nbytes, fn):
 _pack_cache = {}
 
 
-def _packed_weights(w, kind, numel, pack, cache=False):
+def _packed_weights(w, kind, numel, pack, cache=False, dtype=torch.float32):
     if not cache:
-        dst = torch.empty(numel, dtype=torch.float32, device=w.device)
+        dst = torch.empty(numel, dtype=dtype, device=w.device)
         pack(dst)
         return dst
     key = (kind, w.data_ptr(), tuple(w.shape), torch.cuda.current_stream(w.device).cuda_stream)
@@ -680,7 +699,7 @@ def _packed_weights(w, kind, numel, pack, cache=False):
     if ent is not None and ent[2]() is not w:                 # same address, other (or dead) tensor: not this one's copy
         ent = None
     if ent is None or ent[0] != w._version:
-        dst = ent[1] if ent is not None else torch.empty(numel, dtype=torch.float32, device=w.device)
+        dst = ent[1] if ent is not None else torch.empty(numel, dtype=dtype, device=w.device)
         pack(dst)
         if len(_pack_cache) > 512:                            # entries of parameters that no longer exist
             for k in [k for k, e in _pack_cache.items() if e[2]() is None]:
@@ -759,6 +778,59 @@ def vgg_stem_forward(image, w, b):
     return out
 
 
+def _bf16_plan(convs, B, H, W):
+    """[(weight, bias, H, W, pool)] when every layer of this frozen trunk runs on the bf16 kernels at this input size, else None."""
+    plan, n, i, first = [], len(convs), 0, True
+    while i < n:
+        item = convs[i]
+        if isinstance(item, str):
+            return None                                      # an un-fusable pool (odd map size)
+        w, b = item
+        pool = (i + 1 < n) and isinstance(convs[i + 1], str)
+        if pool and (H % 2 or W % 2):
+            return None
+        if first:
+            if w.shape[1] != 3 or pool:
+                return None
+        elif not lib.query('conv3x3_bf16_supported', B, H, W, w.shape[1], w.shape[0], int(pool)):
+            return None
+        plan.append((w, b, H, W, pool))
+        first = False
+        if pool:
+            H, W = H // 2, W // 2
+            i += 2
+        else:
+            i += 1
+    return plan
+
+
+def _vgg_features_forward_bf16(image, plan, cache):
+    """vgg19.features + avgpool + flatten with bf16 activations (fp32 accumulation); returns fp32 [B, C*49]."""
+    B, dev = image.shape[0], image.device
+    cur = None
+    for li, (w, b, H, W, pool) in enumerate(plan):
+        w = _chk(w)
+        Cout, Cin = w.shape[0], w.shape[1]
+        Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=dev)
+        if li == 0:
+            lib('conv3x3_first_nchw_bf16', image, w, b, out, B, H, W, Cout, 1)
+        else:
+            wp = _packed_weights(w, 'bf16', Cout * Cin * 9, lambda dst: lib('conv3x3_bf16_pack_weights', w, dst, Cout, Cin), cache,
+                                 torch.bfloat16)
+            _timed(f'bf16_{H}x{W}_{Cin}->{Cout}{"+pool" if pool else ""}', 2.0 * B * H * W * Cout * Cin * 9,
+                   2.0 * B * (H * W * Cin + Ho * Wo * Cout), lambda: lib('conv3x3_bf16_nhwc', cur, wp, b, out, B, H, W, Cin, Cout, 1, int(pool)))
+        cur = out
+        if (li + 1) in _trunk_mark['after']:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            _trunk_mark['events'][li + 1] = ev
+    _, Hl, Wl, Cl = cur.shape
+    flat = torch.empty((B, Cl * 49), dtype=torch.float32, device=dev)
+    lib('adaptive_avgpool7_flatten_bf16', cur, flat, B, Hl, Wl, Cl)
+    return flat, (Hl, Wl, Cl)
+
+
 def vgg_features_forward(image, convs, fuse_pool=True, keep=None, cache=False, stem=None):
     """vgg19.features + avgpool + flatten.  image NCHW [B,3,H,W]; convs: list of (weight OIHW, bias) with 'M'
     marking MaxPool2d(2,2).  When ``keep`` (a list) is given it receives, per conv layer,
@@ -769,6 +841,10 @@ def vgg_features_forward(image, convs, fuse_pool=True, keep=None, cache=False, s
     if C != 3:
         raise RuntimeError('VGG19 expects 3 input channels')
     dev = image.device
+    if _compute_dtype == 'bf16' and keep is None and fuse_pool and stem is None:
+        plan = _bf16_plan(convs, B, H, W)                    # frozen trunk, no gradients wanted: the bf16 kernels
+        if plan is not None:
+            return _vgg_features_forward_bf16(image, plan, cache)
     fuse = fuse_pool and keep is None
     cur, i, n, nconv = None, 0, len(convs), 0
     while i < n:

@@ -1,0 +1,94 @@
+"""bf16 compute path of the frozen VGG19 trunk (csrc/conv3x3_bf16.hip, ops.set_compute_dtype('bf16')): BASELINE.json's bf16
+configurations.  The reference has no reduced-precision arithmetic, so the gates are: each layer against
+torch's fp32 convolution of the SAME bf16-rounded operands (what remains is accumulation order and the final rounding of the
+output to bf16: 2^-9 relative), and the whole W model against the reference's fp32 logits with the tolerance stated below and
+identical argmax answers."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import load, rel_err, full_params
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,pool', [
+    (3, 32, 32, 64, 64, 0), (3, 32, 32, 64, 64, 1),        # 8x32 patch, 64-channel tile
+    (2, 32, 64, 64, 128, 1), (2, 64, 32, 128, 256, 0),     # 8x32 patch, 128-channel tile, several row tiles per image
+    (5, 16, 16, 32, 128, 1), (2, 56, 56, 64, 128, 0),      # 32x8 patch: a patch spans up to three images
+    (5, 28, 28, 128, 256, 1), (3, 28, 28, 256, 128, 0),    # 8x28 patch (224 pixels, 1 x 4 waves)
+    (7, 14, 14, 128, 256, 1), (4, 14, 14, 512, 512, 0),    # 16x14 patch
+    (1, 224, 224, 64, 64, 1),
+])
+def test_conv_bf16_layer_vs_torch(hip_lib, B, H, W, Cin, Cout, pool):
+    lib = hip_lib
+    torch.manual_seed(B * 1000 + H + Cin)
+    assert lib.query('conv3x3_bf16_supported', B, H, W, Cin, Cout, pool)
+    x = torch.randn(B, H, W, Cin, device=DEV).bfloat16()
+    w = (torch.randn(Cout, Cin, 3, 3, device=DEV) * (2.0 / (9 * Cin)) ** 0.5)
+    b = torch.randn(Cout, device=DEV) * 0.1
+    wp = torch.empty(Cout * Cin * 9, dtype=torch.bfloat16, device=DEV)
+    lib('conv3x3_bf16_pack_weights', w, wp, Cout, Cin)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.full((B, Ho, Wo, Cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+    lib('conv3x3_bf16_nhwc', x, wp, b, y, B, H, W, Cin, Cout, 1, pool)
+    ref = F.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.bfloat16().float(), b, padding=1))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    ref = ref.permute(0, 2, 3, 1)
+    got = y.float()
+    assert torch.isfinite(got).all()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 6e-3 * scale             # output rounding 2^-9 of the value + accumulation order
+    assert ((got - ref).abs() <= 8e-3 * ref.abs() + 2e-3 * scale).all()
+
+
+def test_first_layer_and_avgpool_bf16(hip_lib):
+    lib = hip_lib
+    torch.manual_seed(2)
+    B, H, W = 3, 40, 36
+    img = torch.randn(B, 3, H, W, device=DEV)
+    w = torch.randn(64, 3, 3, 3, device=DEV) * 0.3
+    b = torch.randn(64, device=DEV) * 0.1
+    y = torch.empty((B, H, W, 64), dtype=torch.bfloat16, device=DEV)
+    lib('conv3x3_first_nchw_bf16', img, w, b, y, B, H, W, 64, 1)
+    ref = F.relu(F.conv2d(img, w, b, padding=1)).permute(0, 2, 3, 1)
+    assert (y.float() - ref).abs().max().item() <= 5e-3 * ref.abs().max().item()
+    x = torch.randn(B, 14, 14, 128, device=DEV).bfloat16()
+    flat = torch.empty((B, 128 * 49), dtype=torch.float32, device=DEV)
+    lib('adaptive_avgpool7_flatten_bf16', x, flat, B, 14, 14, 128)
+    ref = F.adaptive_avg_pool2d(x.float().permute(0, 3, 1, 2), 7).flatten(1)
+    assert rel_err(flat, ref) < 1e-6
+
+
+def test_w_model_bf16_trunk_against_reference_logits(hip_lib):
+    """BASELINE configs[1]'s model at B=4 with the trunk in bf16 against the reference's fp32 logits (golden w_full_b4.pt).
+    Tolerance: 3e-2 of the largest logit (16 layers of bf16 activations, 2^-9 relative rounding each; measured ~6e-3);
+    the argmax answers must be the reference's (smallest top-2 gap of the fixture: 5.8e-2 of the largest logit)."""
+    from lct_vqa_amd import ops
+    from lct_vqa_amd.basic_vqa import models, config
+    config.DEVICE = torch.device(DEV)
+    fx = load('w_full_b4.pt')
+    torch.manual_seed(fx['seed'])
+    m = models.VqaModel(**fx['dims']).to(DEV).eval()
+    torch.manual_seed(fx['data_seed'])
+    img = torch.randn(fx['B'], 3, 224, 224)
+    prev = ops.set_compute_dtype('bf16')
+    try:
+        with torch.no_grad():
+            out = m(img.to(DEV), fx['question'].to(DEV))
+            timer_was = ops._conv_timer
+            ops.conv_timer_start()
+            m(img.to(DEV), fx['question'].to(DEV))
+            used = [r['name'] for r in ops.conv_timer_stop()]
+            ops._conv_timer = timer_was
+    finally:
+        ops.set_compute_dtype(prev)
+    assert len(used) == 15 and all(n.startswith('bf16_') for n in used)       # every MFMA layer ran on the bf16 kernel
+    ref = fx['eval_logits']
+    assert rel_err(out, ref) < 3e-2
+    assert torch.equal(out.argmax(1).cpu(), fx['argmax'])
+    with torch.no_grad():
+        out32 = m(img.to(DEV), fx['question'].to(DEV))                         # and the default path is untouched
+    assert rel_err(out32, ref) < 1e-3
