@@ -96,10 +96,12 @@ class MixedOp(nn.Module):
             self.__dict__['_plan'] = plan
         return plan or None
 
-    def forward(self, x, weights, state=None, beta=None):
+    def forward(self, x, weights, state=None, beta=None, selected=False):
         """``state (+)= beta * shuffle(cat(sum_k w_k op_k(x[:C/4]), bypass(x[C/4:])))``; with the defaults this is the
-        reference's ``MixedOp.forward(x, weights)``."""
-        if self._live == list(range(self._live[0], self._live[-1] + 1)):
+        reference's ``MixedOp.forward(x, weights)``.  ``selected``: ``weights`` already holds the live primitives only."""
+        if selected:
+            wsel = weights
+        elif self._live == list(range(self._live[0], self._live[-1] + 1)):
             wsel = weights[self._live[0]:self._live[-1] + 1]        # a view: no gather / scatter kernels around the edge
         else:
             idx = self._live_index.get(weights.device)
@@ -133,10 +135,17 @@ class Cell(nn.Module):
 
     def forward(self, s0, s1, weights, weights2):
         states = [self.preprocess0(s0), self.preprocess1(s1)]
+        live = self._ops[0]._live
+        parts = None
+        if live == list(range(live[0], live[-1] + 1)) and all(op._live == live for op in self._ops):
+            parts = D.EdgeWeightsFn.apply(weights, weights2, live[0], live[-1] + 1)     # every edge's operands, one autograd node
         for first, last in _node_slices(self._steps):
             node = None
             for e in range(first, last):                           # edge e reads state e - first; the kernel accumulates
-                node = self._ops[e](states[e - first], weights[e], node, weights2[e])
+                if parts is not None:
+                    node = self._ops[e](states[e - first], parts[2 * e], node, parts[2 * e + 1], selected=True)
+                else:
+                    node = self._ops[e](states[e - first], weights[e], node, weights2[e])
             states.append(node)
         return torch.cat(states[-self._multiplier:], dim=3)
 

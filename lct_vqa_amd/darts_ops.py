@@ -345,6 +345,31 @@ def set_fused_edge(on):
     return prev
 
 
+class EdgeWeightsFn(torch.autograd.Function):
+    """The per-edge operands of a cell from its two weight tables in one autograd node: (w [E,K], b [E]) ->
+    (w[0, lo:hi], b[0:1], w[1, lo:hi], b[1:2], ...) as views.  Taken one by one with ``w[e]`` / ``b[e]`` every edge costs a
+    SelectBackward + SliceBackward pair (a zero-fill, a copy and an accumulation each); here the 2E small gradients are
+    assembled by three launches per cell."""
+
+    @staticmethod
+    def forward(ctx, w, b, lo, hi):
+        ctx.cfg = (tuple(w.shape), lo, hi)
+        out = []
+        for e in range(w.shape[0]):
+            out += [w[e, lo:hi], b[e:e + 1]]
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *g):
+        (E, K), lo, hi = ctx.cfg
+        ref = next(t for t in g if t is not None)
+        gws = [t if t is not None else ref.new_zeros(hi - lo) for t in g[0::2]]
+        gbs = [t if t is not None else ref.new_zeros(1) for t in g[1::2]]
+        gw = ref.new_zeros((E, K))
+        gw[:, lo:hi] = torch.stack(gws)
+        return gw, torch.cat(gbs), None, None
+
+
 class MixedEdgeFn(torch.autograd.Function):
     """One MixedOp + its edge accumulation as ONE autograd node on the fused tile kernels:
     ``state (+)= beta * shuffle(cat(sum_k w_k bn_k(op_k(x[..., :C/4])), bypass(x[..., C/4:])))`` (model_search.py:41-55,87).
