@@ -45,29 +45,45 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
   return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
 }
 
-// Zero-padded halo tile of NQ channel quads: tile[q * th*tw + ly*tw + lx] = src[n, y0+ly, x0+lx, 4q..4q+3] (row stride ld
+// Zero-padded halo tile of NQ channel quads: tile[q * TH_*TW_ + ly*TW_ + lx] = src[n, y0+ly, x0+lx, 4q..4q+3] (row stride ld
 // floats); ACT 0: as stored, 1: ReLU'd, 2: normalised + ReLU'd ((v - mean) * invstd, then max 0: the input of a sep_conv's
-// second stage).
-template <int NQ, int ACT>
+// second stage).  The trip counts are compile-time, so the loads of up to 8 rounds are issued back to back before the first
+// LDS store (one memory round trip per batch instead of one per round).
+template <int NQ, int ACT, int TH_, int TW_, int TPB>
 __device__ __forceinline__ void load_tile(f32x4* __restrict__ tile, const float* __restrict__ src, long ld, int n, int H, int W,
-                                          int y0, int x0, int th, int tw, const float* __restrict__ mean,
-                                          const float* __restrict__ invstd) {
-  const int npos = th * tw;
-  for (int idx = threadIdx.x; idx < npos * NQ; idx += blockDim.x) {
-    const int q = idx % NQ, pos = idx / NQ;
-    const int ly = pos / tw, lx = pos - ly * tw;
-    const int y = y0 + ly, x = x0 + lx;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (y >= 0 && y < H && x >= 0 && x < W) {
-      v = *(const f32x4*)(src + (((long)n * H + y) * W + x) * ld + 4 * q);
-      if (ACT == 2) {
+                                          int y0, int x0, const float* __restrict__ mean, const float* __restrict__ invstd) {
+  constexpr int NPOS = TH_ * TW_, TOT = NPOS * NQ, ROUNDS = (TOT + TPB - 1) / TPB, BATCH = NQ >= 4 ? 4 : 8;
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = fmaxf((v[e] - mean[4 * q + e]) * invstd[4 * q + e], 0.f);
-      } else if (ACT == 1) {
-        v = relu4(v);
+  for (int r0 = 0; r0 < ROUNDS; r0 += BATCH) {
+    f32x4 v[BATCH];
+    bool ok[BATCH];
+#pragma unroll
+    for (int r = 0; r < BATCH; r++) {
+      const int idx = threadIdx.x + (r0 + r) * TPB;
+      const int q = idx % NQ, pos = idx / NQ;
+      const int ly = pos / TW_, lx = pos - ly * TW_;
+      const int y = y0 + ly, x = x0 + lx;
+      ok[r] = (r0 + r < ROUNDS) && idx < TOT && y >= 0 && y < H && x >= 0 && x < W;
+      v[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok[r]) v[r] = *(const f32x4*)(src + (((long)n * H + y) * W + x) * ld + 4 * q);
+    }
+#pragma unroll
+    for (int r = 0; r < BATCH; r++) {
+      const int idx = threadIdx.x + (r0 + r) * TPB;
+      if (r0 + r < ROUNDS && idx < TOT) {
+        const int q = idx % NQ, pos = idx / NQ;
+        f32x4 t = v[r];
+        if (ACT == 2) {
+          if (ok[r]) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) t[e] = fmaxf((t[e] - mean[4 * q + e]) * invstd[4 * q + e], 0.f);
+          }
+        } else if (ACT == 1) {
+          t = relu4(t);
+        }
+        tile[q * NPOS + pos] = t;
       }
     }
-    tile[q * npos + pos] = v;
   }
 }
 
@@ -189,7 +205,7 @@ __global__ __launch_bounds__(TH * TW) void edge_fwd_a_kernel(const float* __rest
     const int tr = (int)(tidx % (tiles_y * tiles_x));
     const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
     __syncthreads();                                           // previous tile's readers are done (also orders the weight staging)
-    load_tile<NQ, 0>(tile, x, C, n, H, W, S * ty0 - 4, S * tx0 - 4, IH, IW, nullptr, nullptr);
+    load_tile<NQ, 0, IH, IW, TPB>(tile, x, C, n, H, W, S * ty0 - 4, S * tx0 - 4, nullptr, nullptr);
     __syncthreads();
     const int oy = ty0 + ly, ox = tx0 + lx;
     const bool live = oy < Ho && ox < Wo;
@@ -301,8 +317,8 @@ __global__ __launch_bounds__(TH * TW) void edge_fwd_b_kernel(int B, int Ho, int 
     const int tr = (int)(tidx % (tiles_y * tiles_x));
     const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
     __syncthreads();
-    load_tile<NQ, 2>(tile3, pre + 3 * P * CQ, CQ, n, Ho, Wo, ty0 - 2, tx0 - 2, IH, IW, ms, ms + 2 * CQ);
-    load_tile<NQ, 2>(tile5, pre + 4 * P * CQ, CQ, n, Ho, Wo, ty0 - 2, tx0 - 2, IH, IW, ms + CQ, ms + 3 * CQ);
+    load_tile<NQ, 2, IH, IW, TPB>(tile3, pre + 3 * P * CQ, CQ, n, Ho, Wo, ty0 - 2, tx0 - 2, ms, ms + 2 * CQ);
+    load_tile<NQ, 2, IH, IW, TPB>(tile5, pre + 4 * P * CQ, CQ, n, Ho, Wo, ty0 - 2, tx0 - 2, ms + CQ, ms + 3 * CQ);
     __syncthreads();
     const int oy = ty0 + ly, ox = tx0 + lx;
     const bool live = oy < Ho && ox < Wo;
@@ -537,18 +553,27 @@ __global__ __launch_bounds__(256) void edge_bwd_sums_kernel(const float* __restr
   }
 }
 
-// one workgroup: sums of the partials (fixed order, fp64; one wave per column at a time) -> coefficients of the seven final
-// slots, dw[7], dbeta
-__global__ __launch_bounds__(256) void edge_bwd_coef_kernel(const float* __restrict__ part, int nblk, int CQ, long P, int S, int training,
-                                                            const float* __restrict__ wsel, const float* __restrict__ beta,
-                                                            const float* __restrict__ invstd, float* __restrict__ coef,
-                                                            float* __restrict__ dw, float* __restrict__ dbeta) {
+// one workgroup of 1024 threads: sums of the partials (fixed order, fp64; thread = (row group, column), so a row is read by
+// neighbouring lanes) -> coefficients of the seven final slots, dw[7], dbeta
+__global__ __launch_bounds__(1024) void edge_bwd_coef_kernel(const float* __restrict__ part, int nblk, int CQ, long P, int S, int training,
+                                                             const float* __restrict__ wsel, const float* __restrict__ beta,
+                                                             const float* __restrict__ invstd, float* __restrict__ coef,
+                                                             float* __restrict__ dw, float* __restrict__ dbeta) {
+  __shared__ double grp[7][8 * 16 + 1];
   __shared__ double tot[8 * 16 + 1];
   const int ncol = 8 * CQ + 1;
-  if (threadIdx.x < ncol) {                                    // thread = column: a row is read by neighbouring lanes (coalesced)
+  const int ngrp = 1024 / ncol > 7 ? 7 : 1024 / ncol;            // 7 row groups at Cq = 4..16
+  const int g = threadIdx.x / ncol, col = threadIdx.x % ncol;
+  if (g < ngrp) {
     double a = 0.0;
-#pragma unroll 8
-    for (int b = 0; b < nblk; b++) a += (double)part[(long)b * ncol + threadIdx.x];
+#pragma unroll 4
+    for (int b = g; b < nblk; b += ngrp) a += (double)part[(long)b * ncol + col];
+    grp[g][col] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < ncol) {
+    double a = 0.0;
+    for (int k = 0; k < ngrp; k++) a += grp[k][threadIdx.x];
     tot[threadIdx.x] = a;
   }
   __syncthreads();
@@ -661,7 +686,7 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_pools_kernel(const float* __
     const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
     const int gy0 = ty0 / S - 1, gx0 = tx0 / S - 1;             // first output row / column of the gradient tiles
     __syncthreads();
-    load_tile<NQ, 0>(xt, x, C, n, H, W, ty0 - 2, tx0 - 2, XH, XW, nullptr, nullptr);
+    load_tile<NQ, 0, XH, XW, TPB>(xt, x, C, n, H, W, ty0 - 2, tx0 - 2, nullptr, nullptr);
     __syncthreads();
     for (int idx = threadIdx.x; idx < GN; idx += TPB) {
       const int gy = gy0 + idx / GW, gx = gx0 + idx % GW;
@@ -880,45 +905,73 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
     const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
     __syncthreads();
     // activated input tile
-    load_tile<NQ, MODE == 1 ? 2 : 1>(rt, in, ldin, n, H, W, S * ty0 - PAD, S * tx0 - PAD, IH, IW, msi, msi + CQ);
-    // dd = Wpw^T g over the outputs (ty0 - HB .. ty0 + TH - 1 + HB)
-    for (int idx = threadIdx.x; idx < DN; idx += TPB) {
-      const int oy = ty0 - HB + idx / DW, ox = tx0 - HB + idx % DW;
-      float dd[CQ];
-      if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) {
+    load_tile<NQ, MODE == 1 ? 2 : 1, IH, IW, TPB>(rt, in, ldin, n, H, W, S * ty0 - PAD, S * tx0 - PAD, msi, msi + CQ);
+    // dd = Wpw^T g over the outputs (ty0 - HB .. ty0 + TH - 1 + HB); the rows of dY / u of all of a thread's positions are
+    // requested before the first is used, and an owned position also leaves its g row for the 1x1 weight gradient
+    {
+      constexpr int ROUNDS = (DN + TPB - 1) / TPB, RB = NQ <= 2 ? ROUNDS : 1;    // rounds in flight together (registers)
+#pragma unroll
+      for (int r0 = 0; r0 < ROUNDS; r0 += RB) {
+      f32x4 dv[RB][NQ], uv[RB][NQ];
+      bool in[RB];
+#pragma unroll
+      for (int r = 0; r < RB; r++) {
+        const int idx = threadIdx.x + (r0 + r) * TPB;
+        const int oy = ty0 - HB + idx / DW, ox = tx0 - HB + idx % DW;
+        in[r] = idx < DN && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
         const long q = ((long)n * Ho + oy) * Wo + ox;
-        float g[CQ];
-        grad_row<CQ>(gsrc + q * CQ, usrc + q * CQ, mso, cfo, g);
 #pragma unroll
-        for (int c = 0; c < CQ; c++) {
-          float a = 0.f;
-#pragma unroll
-          for (int oc = 0; oc < CQ; oc++) a = fmaf(wpl[oc * CQ + c], g[oc], a);
-          dd[c] = a;
+        for (int q4 = 0; q4 < NQ; q4++) {
+          dv[r][q4] = f32x4{0.f, 0.f, 0.f, 0.f};
+          uv[r][q4] = dv[r][q4];
+          if (in[r]) { dv[r][q4] = *(const f32x4*)(gsrc + q * CQ + 4 * q4); uv[r][q4] = *(const f32x4*)(usrc + q * CQ + 4 * q4); }
         }
-      } else {
-#pragma unroll
-        for (int c = 0; c < CQ; c++) dd[c] = 0.f;
       }
 #pragma unroll
-      for (int q4 = 0; q4 < NQ; q4++) ddt[q4 * DN + idx] = f32x4{dd[4 * q4], dd[4 * q4 + 1], dd[4 * q4 + 2], dd[4 * q4 + 3]};
+      for (int r = 0; r < RB; r++) {
+        const int idx = threadIdx.x + (r0 + r) * TPB;
+        if (idx < DN) {
+          float g[CQ], dd[CQ];
+#pragma unroll
+          for (int q4 = 0; q4 < NQ; q4++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const int c = 4 * q4 + e;
+              const float xh = (uv[r][q4][e] - mso[c]) * mso[CQ + c];
+              g[c] = in[r] ? cfo[c] * (dv[r][q4][e] - cfo[16 + c] - xh * cfo[32 + c]) : 0.f;
+            }
+#pragma unroll
+          for (int c = 0; c < CQ; c++) {
+            float a = 0.f;
+#pragma unroll
+            for (int oc = 0; oc < CQ; oc++) a = fmaf(wpl[oc * CQ + c], g[oc], a);
+            dd[c] = a;
+          }
+#pragma unroll
+          for (int q4 = 0; q4 < NQ; q4++) ddt[q4 * DN + idx] = f32x4{dd[4 * q4], dd[4 * q4 + 1], dd[4 * q4 + 2], dd[4 * q4 + 3]};
+          const int py = idx / DW - HB, px = idx % DW - HB;       // position inside the owned tile?
+          if (py >= 0 && py < TH && px >= 0 && px < TW) {
+#pragma unroll
+            for (int c = 0; c < CQ; c++) Gs[(py * TW + px) * CQ + c] = g[c];
+          }
+        }
+      }
+      }
     }
     __syncthreads();
     const int oy = ty0 + ly, ox = tx0 + lx;
     const bool live = oy < Ho && ox < Wo;
-    // ---- own output pixel: g and the recomputed depthwise output d, staged for the 1x1 weight gradient ----
+    // ---- own output pixel: the recomputed depthwise output d, staged beside g for the 1x1 weight gradient ----
     {
-      float g[CQ], d[CQ];
+      float d[CQ];
       if (live) {
-        const long q = ((long)n * Ho + oy) * Wo + ox;
-        grad_row<CQ>(gsrc + q * CQ, usrc + q * CQ, mso, cfo, g);
         dw_at<CQ, K, DIL, false>(rt, IN, IW, S * ly, S * lx, wdl, d);
       } else {
 #pragma unroll
-        for (int c = 0; c < CQ; c++) { g[c] = 0.f; d[c] = 0.f; }
+        for (int c = 0; c < CQ; c++) d[c] = 0.f;
       }
 #pragma unroll
-      for (int c = 0; c < CQ; c++) { Gs[threadIdx.x * CQ + c] = g[c]; Ds[threadIdx.x * CQ + c] = d[c]; }
+      for (int c = 0; c < CQ; c++) Ds[threadIdx.x * CQ + c] = d[c];
     }
     __syncthreads();
 #pragma unroll
@@ -1143,7 +1196,7 @@ long lctvqa_mixed_edge_bwd_scratch_floats(int B, int H, int W, int C, int stride
   const int CQ = C / 4;
   const long P = (long)B * (H / stride) * (W / stride);
   const long G = lctvqa_mixed_edge_grid(B, H, W, C, stride);
-  return 3 * P * CQ + (long)B * H * W * CQ + 512L * (8 * CQ + 1) + 9 * COEF + G * lctvqa_mixed_edge_wgrad_elems(C) + 2 * (2 * G * 2 * CQ * 2) + 8;
+  return 3 * P * CQ + (long)B * H * W * CQ + 1536L * (8 * CQ + 1) + 9 * COEF + G * lctvqa_mixed_edge_wgrad_elems(C) + 2 * (2 * G * 2 * CQ * 2) + 8;
 }
 
 // Forward of one edge.  w: 14 pointers = dw[6], pw[6], fr[2] (fr null on stride-1 edges); bn: 27 pointers = run_mean[9],
@@ -1234,8 +1287,8 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
   float* dY = scratch;
   float* dBN = dY + P * CQ;                                    // [2][P][CQ]
   float* dx1c = dBN + 2 * P * CQ;                              // [B][H][W][CQ]: what the conv stages send to x1
-  float* part1 = dx1c + (long)B * H * W * CQ;                  // [<=512][8*CQ+1]
-  float* coef = part1 + 512L * (8 * CQ + 1);
+  float* part1 = dx1c + (long)B * H * W * CQ;                  // [<=1536][8*CQ+1]
+  float* coef = part1 + 1536L * (8 * CQ + 1);
   coef += (4 - ((coef - scratch) & 3)) & 3;
   float* wpart = coef + 9 * COEF;                              // [G][wtot]
   float* sp = wpart + (long)G * wtot;
@@ -1246,13 +1299,13 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
   int rc, grid = 1, g3b = 1, g5b = 1;
   {
     long nb = (P * (CQ / 4) + 255) / 256;
-    if (nb > 256) nb = 256;                                      // one row of partials per workgroup: keep the finish short
+    if (nb > 1536) nb = 1536;                                    // six workgroups per CU hide the load latency; one partial row each
     if (stride == 1)
       hipLaunchKernelGGL(edge_bwd_sums_kernel<1>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, part1);
     else
       hipLaunchKernelGGL(edge_bwd_sums_kernel<2>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, part1);
     if ((rc = lct_check_launch("edge_bwd_sums"))) return rc;
-    hipLaunchKernelGGL(edge_bwd_coef_kernel, dim3(1), dim3(256), 0, st, part1, (int)nb, CQ, P, stride, training, wsel, beta, invstd, coef, dwsel, dbeta);
+    hipLaunchKernelGGL(edge_bwd_coef_kernel, dim3(1), dim3(1024), 0, st, part1, (int)nb, CQ, P, stride, training, wsel, beta, invstd, coef, dwsel, dbeta);
     if ((rc = lct_check_launch("edge_bwd_coef"))) return rc;
   }
 #define TILES(Hv, Wv, THv, TWv) ((long)B * (((Hv) + (THv) - 1) / (THv)) * (((Wv) + (TWv) - 1) / (TWv)))

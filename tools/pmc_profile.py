@@ -50,12 +50,15 @@ def main():
              'mfma_busy_frac': round(sum(b.values()) / (4 * 256 * cyc), 4) if cyc else None,
              'clock_GHz': round(cyc / t * 1e-9, 3) if t else None, 'avg_ms_in_pmc_pass': round(t / max(1, len(g)) * 1e3, 4)}
         res[short(k)] = e
-        if 'conv3x3_mfma_kernel' in k or 'conv3x3_wino' in k:
+        if 'conv3x3_mfma_kernel' in k or 'conv3x3_wino' in k or 'conv3x3_bf16_kernel' in k:
             fam['launches'] += n
             fam['rd'] += rd * n; fam['wr'] += wr * n
             fam['busy'] += sum(b.values()); fam['cyc'] += cyc
     L = max(1, fam['launches'])
-    doc = {'note': note or 'rocprofv3 --pmc passes; FETCH_SIZE/WRITE_SIZE in KB, FETCH_SIZE doubled (gfx950 correction)',
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import conv_source_stamp
+    doc = {'csrc_stamp': conv_source_stamp(), 'note': note or 'rocprofv3 --pmc passes; FETCH_SIZE/WRITE_SIZE in KB, FETCH_SIZE doubled (gfx950 correction)',
            'kernels': res,
            'conv3x3_family': {'launches': L, 'hbm_read_GB_per_launch': round(fam['rd'] / L / 1e9, 4),
                               'hbm_write_GB_per_launch': round(fam['wr'] / L / 1e9, 4),
