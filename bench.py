@@ -56,9 +56,10 @@ def parse():
     ap.add_argument('--stem-after', type=int, default=0,
                     help='pipelined mode: run conv1_1 of batch i+1 on a stream of its own, released when the trunk of batch i has '
                          'launched past conv layer N (0 = conv1_1 stays at the head of its own trunk)')
-    ap.add_argument('--workload', default='w', choices=['w', 'lct'],
+    ap.add_argument('--workload', default='w', choices=['w', 'lct', 'resnet_gru'],
                     help="'w' = BASELINE configs[1] (default, the headline metric); 'lct' = stage-1 + stage-2 step of "
-                         "experiment.py:216-268 (EF fixed encoder + generate + W soft loss), reported under its own metric name")
+                         "experiment.py:216-268 (EF fixed encoder + generate + W soft loss), reported under its own metric name; "
+                         "'resnet_gru' = BASELINE configs[2]'s model shape (frozen ResNet-152 trunk + GRU + fusion head) train step, own metric name")
     ap.add_argument('--lct-no-share', dest='lct_share_trunk', action='store_false',
                     help="--workload lct: evaluate the examiner's frozen trunk separately for stage 1 and stage 2 (default: once per batch)")
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
@@ -178,7 +179,11 @@ def main():
     config.ARCH_TYPE = 'fixed'
 
     torch.manual_seed(10)                           # config.SEED: identical replicas on every rank
-    model = models.VqaModel(**DIMS).to(dev).train()
+    if args.workload == 'resnet_gru':
+        from lct_vqa_amd.basic_vqa import models_ext
+        model = models_ext.VqaModelResNetGRU(**DIMS).to(dev).train()
+    else:
+        model = models.VqaModel(**DIMS).to(dev).train()
     opt = FusedAdam(model.trainable_parameters(), lr=config.LEARNING_RATE, flatten=True)
     trainable = opt.flat['params']
     reducer = parallel.FlatGradReducer(trainable, opt.flat_grad, scale_fn=parallel.hip_scale) if world > 1 else None
@@ -245,7 +250,7 @@ def main():
     # The W model's VGG19 is frozen by construction (models.py:35-36; no optimizer or architect of this step holds its
     # parameters): keep its kernel-layout weights between steps instead of re-packing 15 layers per step.
     model.img_encoder.model.cache_packed_weights = True
-    pipelined = (args.workload == 'w') and not args.no_pipeline
+    pipelined = (args.workload in ('w', 'resnet_gru')) and not args.no_pipeline
     if pipelined:
         # Two-stream software pipeline.  The VGG19 trunk is frozen (models.py:35-36) so trunk(batch i+1) is independent
         # of step i's parameter update: it runs on `trunk_stream` while head fwd/bwd + all-reduce + clip + Adam of batch
@@ -260,6 +265,8 @@ def main():
         stem_stream = torch.cuda.Stream()
         img_parts = [p.contiguous() for p in img.chunk(nsplit)]
         vgg = model.img_encoder.model
+        if args.workload == 'resnet_gru':
+            stem_after = 0
 
         def launch_stem(after_event):
             # conv1_1 of the NEXT batch (HBM-write bound, 3.3 GB) on a stream of its own, released when the current trunk
@@ -400,6 +407,7 @@ def main():
     algo = ops.get_conv_algo()
     tot_flops = sum(r['flops'] for r in conv)
     tot_exec = sum(r['flops'] / (4.0 if r['name'].startswith('wino4') else 2.25 if r['name'].startswith('wino') else 1.0) for r in conv)
+    ngemm = sum(1 for r in conv if r['name'].startswith('gemm'))
     tot_ms = sum(r['ms'] for r in conv)
     nlaunch = max(1, len(conv))
     direct_equiv = tot_flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
@@ -413,7 +421,8 @@ def main():
     # time of those launches, against the dense fp32 MFMA peak: a utilisation, <= 1.  What Winograd buys on top is
     # `algorithmic_speedup`; `direct_equivalent_tflops` = the direct-convolution FLOP count per second.
     roofline = {'bound': 'mfma',
-                'kernel': ('conv3x3_bf16_kernel (direct implicit GEMM on v_mfma_f32_32x32x16_bf16, fp32 accumulate, %d launches)' % nbf) if nbf else
+                'kernel': ('gemm_f32_kernel (1x1 convolutions of the bottlenecks as fp32 MFMA GEMMs, %d launches) + conv3x3_wino4_kernel (%d)' % (ngemm, nw4)) if ngemm else
+                          ('conv3x3_bf16_kernel (direct implicit GEMM on v_mfma_f32_32x32x16_bf16, fp32 accumulate, %d launches)' % nbf) if nbf else
                           ('conv3x3_wino4_kernel (Winograd F(4x4,3x3), %d launches) + conv3x3_wino2/3_kernel (F(2x2,3x3), %d) + '
                            'conv3x3_mfma_kernel (direct, %d): fp32 MFMA' % (nw4, nwino - nw4, nlaunch - nwino)) if nwino else
                           'conv3x3_mfma_kernel (direct implicit GEMM, 15 VGG19 layers/step)',
@@ -450,6 +459,7 @@ def main():
                 f.write(f"{k}: {a['ms'] / a['n']:.3f} ms/launch, {a['flops'] / a['ms'] / 1e9:.1f} TFLOP/s ({a['n']} launches)\n")
     out = {
         'metric': ('image-question pairs/sec (train step) at 224x224, seq=14, 3129-way' if args.workload == 'w' else
+                   'image-question pairs/sec (ResNet-152+GRU train step, frozen trunk) at 224x224, seq=14, 3129-way' if args.workload == 'resnet_gru' else
                    'image-question pairs/sec (LCT stage1+stage2 step: EF + generate + W soft loss) at 224x224, seq=14, 3129-way')
                   + (' [bf16 frozen trunk, fp32 accumulate, fp32 heads: NOT the headline fp32 metric]' if args.dtype == 'bf16' else ''),
         'value': round(value, 2),
@@ -458,6 +468,10 @@ def main():
         'config': {'workload': ('basic_vqa VGG19+LSTM fp32 W-model train step (frozen VGG19 trunk, fwd+CE+bwd+clip+Adam), '
                                 'batch %d per GPU, 224x224x3 images, 14-token questions, 3129 answers, QV=17858' % B)
                                if args.workload == 'w' else
+                               ('ResNet-152 (frozen, BatchNorm on running statistics folded into the convolutions) + GRU + fusion head, fp32 train '
+                                'step (fwd+CE+bwd through the trainable head+clip+Adam), batch %d per GPU, 224x224x3, 14 tokens, 3129 answers, QV=17858: '
+                                "BASELINE configs[2]'s model shape on one GPU; the reference has no ResNet / GRU" % B)
+                               if args.workload == 'resnet_gru' else
                                ('basic_vqa LCT stage-1 + stage-2 step fp32 (experiment.py:216-268): examiner (models_lct, frozen '
                                 'pretrained VGG19) fwd+loss+bwd+clip+Adam, examiner.generate (14 tokens), W soft-loss '
                                 'fwd+bwd+clip+Adam; batch %d per GPU, 224x224x3, QV=17858, A=3129; frozen-trunk conv features '

@@ -248,6 +248,18 @@ int lctvqa_conv3x3_first_nchw_bf16(const float* x_nchw, const float* w_oihw, con
                                    int Cout, int relu, void* stream);
 int lctvqa_adaptive_avgpool7_flatten_bf16(const void* x_nhwc_bf16, float* y, int B, int H, int W, int C, void* stream);
 
+/* ---- frozen ResNet-152 trunk (BASELINE.json configs[2]; not in the reference): what the VGG / GEMM
+ *      kernels do not already cover -- BatchNorm (running statistics) folded into the convolution in front of it,
+ *      the 7x7 / stride-2 stem (fp32 NCHW -> NHWC, bias + ReLU), global average pool: csrc/resnet.hip ---- */
+int lctvqa_fold_bn(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps, int Cout,
+                   long K, float* w_out, float* shift, void* stream);
+int lctvqa_conv7x7_s2_stem(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc, int B, int H, int W, int relu,
+                           void* stream);
+int lctvqa_global_avgpool_nhwc(const float* x, float* y, int B, int HW, int C, void* stream);
+/* dst[n][oy+y][ox+x][:] = relu?(src[n][sy+y][sx+x][:]) for an h x w window of NHWC tensors (pad a small map / crop it back) */
+int lctvqa_copy_window_nhwc(const float* src, float* dst, int B, int Hs, int Ws, int Hd, int Wd, int C, int sy, int sx, int oy, int ox,
+                            int h, int w, int relu, void* stream);
+
 /* One PC-DARTS MixedOp edge as fused tile kernels (model_search.py:22-55 + the seven live primitives of operations.py:4-20
  * on x[..., :C/4], their BatchNorms, the alpha-weighted sum, bypass, channel shuffle and the beta-weighted accumulation
  * into the node's sum, model_search.py:87): csrc/mixed_edge.hip.  w = 14 device pointers: depthwise weights [Cq][K][K] of

@@ -1,10 +1,14 @@
 """Extensions by analogy named by BASELINE.json but absent from the reference:
 the GRU question encoder of configs[2] ("ResNet-152+GRU").  The reference pins nothing here; the oracle is
 torch.nn.GRU + the same surrounding arithmetic as basic_vqa/models.py:45-68 with (h) in place of cat(h,c).
-ResNet-152 is NOT built (the image encoder of these classes is the VGG19 trunk)."""
+``ImgEncoderResNet`` / ``VqaModelResNetGRU``: the same model with a FROZEN ResNet-152 trunk (lct_vqa_amd/resnet.py) in place of
+the frozen VGG19 -- the reference's ImgEncoder pattern (models.py:12-42: pretrained trunk under no_grad -> fc -> / detached L2
+norm) applied to the encoder configs[2] names.  The trainable-trunk form of that configuration is not built."""
+import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, vgg
+from ..resnet import ResNet152Trunk
 from .models import VqaModel
 
 
@@ -33,3 +37,28 @@ class VqaModelGRU(VqaModel):
     def __init__(self, embed_size, qst_vocab_size, ans_vocab_size, word_embed_size, num_layers, hidden_size):
         super(VqaModelGRU, self).__init__(embed_size, qst_vocab_size, ans_vocab_size, word_embed_size, num_layers, hidden_size)
         self.qst_encoder = QstEncoderGRU(qst_vocab_size, word_embed_size, embed_size, num_layers, hidden_size)
+
+
+class ImgEncoderResNet(nn.Module):
+    """Frozen ResNet-152 (minus fc) -> fc -> / detached L2 norm: reference models.py:12-42 with the other trunk."""
+
+    def __init__(self, embed_size):
+        super().__init__()
+        self.model = ResNet152Trunk()
+        self.fc = nn.Linear(self.model.out_features, embed_size)
+
+    def trunk(self, image):
+        with torch.no_grad():
+            return self.model(image)
+
+    def forward(self, image, trunk_feature=None, conv_feature=None):
+        feat = self.trunk(image) if trunk_feature is None else trunk_feature
+        return vgg.embed_feature(feat, self.fc)
+
+
+class VqaModelResNetGRU(VqaModelGRU):
+    """BASELINE.json configs[2]'s model shape: ResNet-152 image encoder (frozen) + GRU question encoder + the fusion head."""
+
+    def __init__(self, embed_size, qst_vocab_size, ans_vocab_size, word_embed_size, num_layers, hidden_size):
+        super().__init__(embed_size, qst_vocab_size, ans_vocab_size, word_embed_size, num_layers, hidden_size)
+        self.img_encoder = ImgEncoderResNet(embed_size)

@@ -1,0 +1,137 @@
+"""Frozen ResNet-152 image trunk on the HIP kernels (BASELINE.json configs[2], "ResNet-152+GRU"; the reference has no ResNet,
+SURVEY.md section 0.1: parity unpinned by the reference, checked against oracle/resnet_oracle.py).
+
+``ResNet152Trunk`` holds torchvision-named parameters and buffers (``conv1``, ``bn1``, ``layer{1..4}.{i}.conv{1,2,3}`` /
+``bn{1,2,3}`` / ``downsample.{0,1}``) so a torchvision ``resnet152`` state_dict loads, and runs as a FEATURE EXTRACTOR: under
+``no_grad``, BatchNorms on their running statistics whatever the module's mode (a frozen trunk; the statistics are then a
+per-channel affine map folded into the preceding convolution, csrc/resnet.hip).  A trunk that needs gradients, or batch
+statistics, raises: the trainable bottleneck / BatchNorm backward is not built.
+
+Execution: NHWC fp32; 7x7/s2 stem kernel; MaxPool(3,2,1) = pool3x3; 3x3 convolutions on the VGG trunk's kernels
+(Winograd F(4x4,3x3) / direct MFMA, bias + ReLU fused; stride 2 = stride 1 then a 2x subsample); 1x1 convolutions as the
+strided fp32 MFMA GEMM over NHWC rows with the epilogue relu(acc + shift + identity); global average pool."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import lib
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class ResNet152Trunk(nn.Module):
+    """torchvision resnet152 minus its fc: [B,3,H,W] -> [B,2048]."""
+
+    def __init__(self, layers=(3, 8, 36, 3)):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, layers[0], 1)
+        self.layer2 = self._make_layer(128, layers[1], 2)
+        self.layer3 = self._make_layer(256, layers[2], 2)
+        self.layer4 = self._make_layer(512, layers[3], 2)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.out_features = 2048
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+        self._folded = {}                                        # id(conv) -> (versions, w', shift): the trunk is frozen
+
+    def _make_layer(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes * 4:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
+        layers = [_Bottleneck(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * 4
+        layers += [_Bottleneck(self.inplanes, planes, 1, None) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    # ---- BatchNorm (running statistics) folded into the convolution in front of it -----------------------------------
+    def _fold(self, conv, bn):
+        key = id(conv)
+        ver = (conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+               conv.weight.data_ptr())
+        hit = self._folded.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1], hit[2]
+        w = ops._chk(conv.weight)
+        Cout = w.shape[0]
+        wf = torch.empty_like(w)
+        shift = torch.empty(Cout, dtype=torch.float32, device=w.device)
+        lib('fold_bn', w, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), Cout, w.numel() // Cout, wf, shift)
+        self._folded[key] = (ver, wf, shift)
+        return wf, shift
+
+    def _conv1x1(self, x, conv, bn, relu, identity=None):
+        """x NHWC -> NHWC: relu?(x . w'^T + shift (+ identity))"""
+        B, H, W, Cin = x.shape
+        wf, shift = self._fold(conv, bn)
+        Cout = wf.shape[0]
+        P = B * H * W
+        y = torch.empty((P, Cout), dtype=torch.float32, device=x.device)
+        ops._timed(f'gemm1x1_{H}x{W}_{Cin}->{Cout}', 2.0 * P * Cin * Cout, 4.0 * P * (Cin + Cout * (1 if identity is None else 2)),
+                   lambda: ops.linear_fwd(x.reshape(P, Cin), wf.reshape(Cout, Cin), shift, ops.ACT_RELU if relu else ops.ACT_NONE,
+                                          addend=None if identity is None else identity.reshape(P, Cout), out=y))
+        return y.reshape(B, H, W, Cout)
+
+    def _conv3x3(self, x, conv, bn, stride):
+        B, H, W, _ = x.shape
+        wf, shift = self._fold(conv, bn)
+        y = ops._conv_block(x, wf, shift, B, H, W, 0, cache=True)  # conv + shift + ReLU at stride 1 (the folded weights are
+                                                                   # this trunk's own frozen tensors: their packed form is kept)
+        return y if stride == 1 else self._subsample(y)
+
+    @staticmethod
+    def _subsample(x):
+        B, H, W, C = x.shape
+        y = torch.empty((B, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
+        if H % 2 or W % 2:
+            raise NotImplementedError('ResNet152Trunk: odd feature-map size at a stride-2 block')
+        lib('subsample2_fwd', x, y, B, H, W, C, 0, 0)
+        return y
+
+    def forward(self, image):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError('ResNet152Trunk is a frozen feature extractor: call it under no_grad or freeze its parameters '
+                                      '(the trainable bottleneck / BatchNorm backward is not built)')
+        with torch.no_grad():
+            image = ops._chk(image, 'image')
+            B, C, H, W = image.shape
+            if C != 3:
+                raise RuntimeError('ResNet expects 3 input channels')
+            wf, shift = self._fold(self.conv1, self.bn1)
+            Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            x = torch.empty((B, Ho, Wo, 64), dtype=torch.float32, device=image.device)
+            lib('conv7x7_s2_stem', image, wf, shift, x, B, H, W, 1)
+            Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+            y = torch.empty((B, Hp, Wp, 64), dtype=torch.float32, device=image.device)
+            lib('pool3x3_fwd', x, y, B, Ho, Wo, 64, 2, 0)
+            x = y
+            for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+                for blk in layer:
+                    identity = x
+                    if blk.downsample is not None:
+                        src = x if blk.stride == 1 else self._subsample(x)
+                        identity = self._conv1x1(src, blk.downsample[0], blk.downsample[1], relu=False)
+                    out = self._conv1x1(x, blk.conv1, blk.bn1, relu=True)
+                    out = self._conv3x3(out, blk.conv2, blk.bn2, blk.stride)
+                    x = self._conv1x1(out, blk.conv3, blk.bn3, relu=True, identity=identity)
+            B, H, W, C = x.shape
+            feat = torch.empty((B, C), dtype=torch.float32, device=x.device)
+            lib('global_avgpool_nhwc', x, feat, B, H * W, C)
+            return feat
