@@ -56,10 +56,12 @@ def parse():
     ap.add_argument('--stem-after', type=int, default=0,
                     help='pipelined mode: run conv1_1 of batch i+1 on a stream of its own, released when the trunk of batch i has '
                          'launched past conv layer N (0 = conv1_1 stays at the head of its own trunk)')
-    ap.add_argument('--workload', default='w', choices=['w', 'lct', 'resnet_gru'],
+    ap.add_argument('--workload', default='w', choices=['w', 'lct', 'resnet_gru', 'darts_vqa'],
                     help="'w' = BASELINE configs[1] (default, the headline metric); 'lct' = stage-1 + stage-2 step of "
                          "experiment.py:216-268 (EF fixed encoder + generate + W soft loss), reported under its own metric name; "
-                         "'resnet_gru' = BASELINE configs[2]'s model shape (frozen ResNet-152 trunk + GRU + fusion head) train step, own metric name")
+                         "'resnet_gru' = BASELINE configs[2]'s model shape (frozen ResNet-152 trunk + GRU + fusion head) train step, own metric name; "
+                         "'darts_vqa' = BASELINE configs[4] in fp32 on one GPU: darts_vqa VqaModel(img_encoder_type='darts') weight step "
+                         "(darts_vqa/experiment.py:188-200), own metric name; one 2nd-order Architect.step is timed beside it (not in value)")
     ap.add_argument('--lct-no-share', dest='lct_share_trunk', action='store_false',
                     help="--workload lct: evaluate the examiner's frozen trunk separately for stage 1 and stage 2 (default: once per batch)")
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
@@ -159,6 +161,85 @@ def self_launch(args):
     return subprocess.call(cmd)
 
 
+def bench_darts_vqa(args, rank, world, dev, img, qst, lab):
+    """BASELINE configs[4] (fp32 form, one GPU): the weight step of the darts_vqa driver with the PC-DARTS search encoder,
+    K timed steps between the barriers; the architecture step (2-level, second order) is timed once beside it."""
+    import types
+    from lct_vqa_amd import parallel
+    from lct_vqa_amd.darts_vqa import config as dconfig, factory
+    from lct_vqa_amd.basic_vqa import config as bconfig
+    from lct_vqa_amd.optim import FusedAdam
+    dconfig.DEVICE = bconfig.DEVICE = dev
+    a = types.SimpleNamespace(unified=False, embed_size=512, word_embed_size=300, num_layers=1, hidden_size=512, arch_type='darts',
+                              learn_rate=1e-3, step_size=10, gamma=0.1, arch_learn_rate=6e-4, arch_wt_decay=1e-3, qst_only=False)
+    ds = types.SimpleNamespace(qst_vocab=types.SimpleNamespace(vocab_size=DIMS['qst_vocab_size']),
+                               ans_vocab=types.SimpleNamespace(vocab_size=DIMS['ans_vocab_size']))
+    torch.manual_seed(10)
+    model = factory.get_vqa_model(a, ds).to(dev).train()
+    opt = FusedAdam(model.parameters(), lr=a.learn_rate, flatten=True)
+    arch = factory.get_architect(a, model)
+    red = parallel.FlatGradReducer(opt.flat['params'], opt.flat_grad, scale_fn=parallel.hip_scale) if world > 1 else None
+    B = args.batch
+
+    def step():
+        opt.zero_grad()
+        loss = model._loss(img, qst, lab, False)
+        loss.backward()
+        if red is not None:
+            red.finish()
+        opt.step(max_grad_norm=5.0)
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    arch_ms = None
+    if rank == 0 and world == 1:
+        arch.step(img, qst, lab, img, qst, lab, a.learn_rate, opt)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        arch.step(img, qst, lab, img, qst, lab, a.learn_rate, opt)
+        torch.cuda.synchronize()
+        arch_ms = (time.perf_counter() - t1) * 1e3
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        # algorithmic HBM bytes of the encoder's 56 MixedOp edges per pair (csrc/mixed_edge.hip: 29 T forward + 60 T backward per
+        # edge, T = 4 * P * Cq bytes): cells at 224^2 x 16, 112^2 x 32 (reduction), 56^2 x 64 (reduction), 56^2 x 64
+        T = [224 * 224 * 4 * 4, 112 * 112 * 8 * 4, 56 * 56 * 16 * 4, 56 * 56 * 16 * 4]
+        enc_bytes = 89 * 14 * sum(T)
+        out = {'metric': 'image-question pairs/sec (darts_vqa weight step: PC-DARTS search encoder + LSTM encoder-decoder) at 224x224, seq=14, 3129-way',
+               'value': round(world * B * args.steps / dt, 2), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': "darts_vqa VqaModel(img_encoder_type='darts') fp32 weight step (fwd + CE(ans) + CE(qst) + bwd + clip + Adam), "
+                                      'batch %d per GPU, 224x224x3, 14 tokens, A=3129, QV=17858: BASELINE configs[4] on one GPU in fp32' % B,
+                          'global_batch': world * B, 'seq_len': 14, 'parallelism': f'dp{world}',
+                          'architect_step_ms': None if arch_ms is None else round(arch_ms, 1)},
+               'loss': round(float(loss.item()), 5),
+               'roofline': {'bound': 'hbm', 'kernel': 'edge_fwd_* / edge_bwd_* (fused MixedOp edge kernels, 56 edges x 17 launches)',
+                            'achieved': round(enc_bytes * B / (ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                            'frac': round(enc_bytes * B / (ms * 1e-3) / 8e12, 4), 'traffic': None,
+                            'algorithmic_bytes_per_pair': enc_bytes,
+                            'note': 'algorithmic bytes of the encoder edges only, over the WHOLE step time (LSTM, token head and torch glue included): a lower bound of the edge kernels\' own rate'},
+               'cpu_baseline': None}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -195,6 +276,9 @@ def main():
     qst = qst.to(dev)
     lab = torch.randint(DIMS['ans_vocab_size'], (B,), generator=g).to(dev)
     ops.manual_seed(10 + rank)
+
+    if args.workload == 'darts_vqa':
+        return bench_darts_vqa(args, rank, world, dev, img, qst, lab)
 
     def step():
         opt.zero_grad()
