@@ -67,6 +67,8 @@ def parse():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="arithmetic of the frozen VGG19 trunk: 'f32' = the reference's (the headline); 'bf16' = bf16 activations/weights with fp32 "
                          "accumulation (BASELINE.json's bf16 configurations), reported under its OWN metric name, never as the headline")
+    ap.add_argument('--train-encoder', action='store_true',
+                    help="--workload resnet_gru: train the ResNet-152 trunk too (batch-statistics BatchNorm, full backward) instead of the frozen trunk")
     ap.add_argument('--conv-algo', default=None, choices=['winograd', 'winograd2', 'direct'],
                     help='trunk convolution algorithm (default: LCTVQA_CONV_ALGO or winograd = F(4x4,3x3) / F(2x2,3x3) / direct by shape; all fp32)')
     return ap.parse_args()
@@ -262,7 +264,7 @@ def main():
     torch.manual_seed(10)                           # config.SEED: identical replicas on every rank
     if args.workload == 'resnet_gru':
         from lct_vqa_amd.basic_vqa import models_ext
-        model = models_ext.VqaModelResNetGRU(**DIMS).to(dev).train()
+        model = models_ext.VqaModelResNetGRU(pretrained=not args.train_encoder, **DIMS).to(dev).train()
     else:
         model = models.VqaModel(**DIMS).to(dev).train()
     opt = FusedAdam(model.trainable_parameters(), lr=config.LEARNING_RATE, flatten=True)
@@ -334,7 +336,7 @@ def main():
     # The W model's VGG19 is frozen by construction (models.py:35-36; no optimizer or architect of this step holds its
     # parameters): keep its kernel-layout weights between steps instead of re-packing 15 layers per step.
     model.img_encoder.model.cache_packed_weights = True
-    pipelined = (args.workload in ('w', 'resnet_gru')) and not args.no_pipeline
+    pipelined = (args.workload in ('w', 'resnet_gru')) and not args.no_pipeline and not args.train_encoder
     if pipelined:
         # Two-stream software pipeline.  The VGG19 trunk is frozen (models.py:35-36) so trunk(batch i+1) is independent
         # of step i's parameter update: it runs on `trunk_stream` while head fwd/bwd + all-reduce + clip + Adam of batch
@@ -543,7 +545,7 @@ def main():
                 f.write(f"{k}: {a['ms'] / a['n']:.3f} ms/launch, {a['flops'] / a['ms'] / 1e9:.1f} TFLOP/s ({a['n']} launches)\n")
     out = {
         'metric': ('image-question pairs/sec (train step) at 224x224, seq=14, 3129-way' if args.workload == 'w' else
-                   'image-question pairs/sec (ResNet-152+GRU train step, frozen trunk) at 224x224, seq=14, 3129-way' if args.workload == 'resnet_gru' else
+                   ('image-question pairs/sec (ResNet-152+GRU train step, %s trunk) at 224x224, seq=14, 3129-way' % ('trainable' if args.train_encoder else 'frozen')) if args.workload == 'resnet_gru' else
                    'image-question pairs/sec (LCT stage1+stage2 step: EF + generate + W soft loss) at 224x224, seq=14, 3129-way')
                   + (' [bf16 frozen trunk, fp32 accumulate, fp32 heads: NOT the headline fp32 metric]' if args.dtype == 'bf16' else ''),
         'value': round(value, 2),
@@ -552,9 +554,10 @@ def main():
         'config': {'workload': ('basic_vqa VGG19+LSTM fp32 W-model train step (frozen VGG19 trunk, fwd+CE+bwd+clip+Adam), '
                                 'batch %d per GPU, 224x224x3 images, 14-token questions, 3129 answers, QV=17858' % B)
                                if args.workload == 'w' else
-                               ('ResNet-152 (frozen, BatchNorm on running statistics folded into the convolutions) + GRU + fusion head, fp32 train '
-                                'step (fwd+CE+bwd through the trainable head+clip+Adam), batch %d per GPU, 224x224x3, 14 tokens, 3129 answers, QV=17858: '
-                                "BASELINE configs[2]'s model shape on one GPU; the reference has no ResNet / GRU" % B)
+                               (('ResNet-152 (TRAINABLE: batch-statistics BatchNorm, full backward)' if args.train_encoder else
+                                 'ResNet-152 (frozen, BatchNorm on running statistics folded into the convolutions)')
+                                + ' + GRU + fusion head, fp32 train step (fwd+CE+bwd+clip+Adam), batch %d per GPU, 224x224x3, 14 tokens, 3129 answers, '
+                                  "QV=17858: BASELINE configs[2]'s model shape on one GPU; the reference has no ResNet / GRU" % B)
                                if args.workload == 'resnet_gru' else
                                ('basic_vqa LCT stage-1 + stage-2 step fp32 (experiment.py:216-268): examiner (models_lct, frozen '
                                 'pretrained VGG19) fwd+loss+bwd+clip+Adam, examiner.generate (14 tokens), W soft-loss '

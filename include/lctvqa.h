@@ -256,6 +256,20 @@ int lctvqa_fold_bn(const float* w, const float* gamma, const float* beta, const 
 int lctvqa_conv7x7_s2_stem(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc, int B, int H, int W, int relu,
                            void* stream);
 int lctvqa_global_avgpool_nhwc(const float* x, float* y, int B, int HW, int C, void* stream);
+/* BatchNorm2d over dense NHWC rows [P][C] for any C % 4 == 0, fused with the ReLU / residual add that follows it in a bottleneck:
+ * y = relu?(bn(x) (+ residual)); batch statistics (running estimates + counter updated) when training, else running statistics.
+ * Backward: g = dy * (y_out > 0) when y_out is given, dres = g, dx / dgamma / dbeta as nn.BatchNorm2d's. */
+int lctvqa_bn_wide_blocks(long P);
+int lctvqa_bn_wide_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var, long* tracked,
+                       const float* residual, int relu, float* y, float* mean, float* invstd, double* part, long P, int C, int training,
+                       float momentum, float eps, void* stream);
+int lctvqa_bn_wide_bwd(const float* dy, const float* y_out, const float* x, const float* mean, const float* invstd, const float* gamma,
+                       float* dx, float* dres, float* dgamma, float* dbeta, float* sums, double* part, long P, int C, int training,
+                       void* stream);
+int lctvqa_global_avgpool_nhwc_bwd(const float* dy, float* dx, int B, int HW, int C, void* stream);
+/* weight gradient of the 7x7 / stride-2 stem: per-workgroup partials [blocks][147 (c,ky,kx)][64 cout] */
+int lctvqa_conv7x7_s2_stem_wgrad_blocks(int B, int H);
+int lctvqa_conv7x7_s2_stem_wgrad(const float* x_nchw, const float* dz_nhwc, float* part, int B, int H, int W, void* stream);
 /* dst[n][oy+y][ox+x][:] = relu?(src[n][sy+y][sx+x][:]) for an h x w window of NHWC tensors (pad a small map / crop it back) */
 int lctvqa_copy_window_nhwc(const float* src, float* dst, int B, int Hs, int Ws, int Hd, int Wd, int C, int sy, int sx, int oy, int ox,
                             int h, int w, int relu, void* stream);

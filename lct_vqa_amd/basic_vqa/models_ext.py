@@ -2,8 +2,8 @@
 the GRU question encoder of configs[2] ("ResNet-152+GRU").  The reference pins nothing here; the oracle is
 torch.nn.GRU + the same surrounding arithmetic as basic_vqa/models.py:45-68 with (h) in place of cat(h,c).
 ``ImgEncoderResNet`` / ``VqaModelResNetGRU``: the same model with a FROZEN ResNet-152 trunk (lct_vqa_amd/resnet.py) in place of
-the frozen VGG19 -- the reference's ImgEncoder pattern (models.py:12-42: pretrained trunk under no_grad -> fc -> / detached L2
-norm) applied to the encoder configs[2] names.  The trainable-trunk form of that configuration is not built."""
+the VGG19 -- the reference's ImgEncoder pattern (models.py:12-42: pretrained trunk under no_grad -> fc -> / detached L2
+norm; models_lct.py:62-63: ``pretrained=False`` trains the trunk) applied to the encoder configs[2] names."""
 import torch
 import torch.nn as nn
 
@@ -40,15 +40,17 @@ class VqaModelGRU(VqaModel):
 
 
 class ImgEncoderResNet(nn.Module):
-    """Frozen ResNet-152 (minus fc) -> fc -> / detached L2 norm: reference models.py:12-42 with the other trunk."""
+    """ResNet-152 (minus fc) -> fc -> / detached L2 norm: reference models.py:12-42 (pretrained=True: frozen trunk under
+    no_grad) and models_lct.py:35-69 (pretrained=False: the trunk trains) with the other trunk."""
 
-    def __init__(self, embed_size):
+    def __init__(self, embed_size, pretrained=True):
         super().__init__()
         self.model = ResNet152Trunk()
         self.fc = nn.Linear(self.model.out_features, embed_size)
+        self.pretrained = pretrained
 
     def trunk(self, image):
-        with torch.no_grad():
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not self.pretrained):
             return self.model(image)
 
     def forward(self, image, trunk_feature=None, conv_feature=None):
@@ -59,6 +61,10 @@ class ImgEncoderResNet(nn.Module):
 class VqaModelResNetGRU(VqaModelGRU):
     """BASELINE.json configs[2]'s model shape: ResNet-152 image encoder (frozen) + GRU question encoder + the fusion head."""
 
-    def __init__(self, embed_size, qst_vocab_size, ans_vocab_size, word_embed_size, num_layers, hidden_size):
+    def __init__(self, embed_size, qst_vocab_size, ans_vocab_size, word_embed_size, num_layers, hidden_size, pretrained=True):
         super().__init__(embed_size, qst_vocab_size, ans_vocab_size, word_embed_size, num_layers, hidden_size)
-        self.img_encoder = ImgEncoderResNet(embed_size)
+        self.img_encoder = ImgEncoderResNet(embed_size, pretrained)
+
+    def trainable_parameters(self):
+        frozen = self.img_encoder.pretrained
+        return [p for n, p in self.named_parameters() if not (frozen and n.startswith('img_encoder.model.'))]

@@ -716,7 +716,7 @@ def clear_pack_cache():
 _tap_major = {}
 
 
-def _conv3x3_small_map(cur, w, b, B, H, W):
+def _conv3x3_small_map(cur, w, b, B, H, W, relu=1):
     """conv3x3 + bias + ReLU on a map too small for the tiled kernels (the 7x7 maps of a ResNet's last stage): the map is
     zero-padded into a bordered (H+2) x (W+2) grid on which a tap is a constant ROW SHIFT, so the convolution is nine fp32 MFMA
     GEMMs over all grid rows accumulating into one buffer (border rows compute garbage that is cropped away).  (H+2)(W+2)/(HW)
@@ -740,12 +740,18 @@ def _conv3x3_small_map(cur, w, b, B, H, W):
         a = grid[slack + shift: slack + shift + rows]
         gemm(a, Cin, 1, wt[t // 3, t % 3], Cin, 1, rows, Cout, Cin, b if t == 0 else None, None if t == 0 else acc, ACT_NONE, out=acc)
     out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
-    lib('copy_window_nhwc', acc, out, B, Hg, Wg, H, W, Cout, 1, 1, 0, 0, H, W, 1)
+    lib('copy_window_nhwc', acc, out, B, Hg, Wg, H, W, Cout, 1, 1, 0, 0, H, W, int(relu))
     return out
 
 
-def _conv_block(cur, w, b, B, H, W, pool, cache=False):
-    """conv3x3 + bias + ReLU (+ fused 2x2 max pool) on an NHWC activation -> NHWC output."""
+def _small_map(B, H, W, Cin, Cout):
+    """True when a 3x3 convolution of this shape has no tiled kernel and runs as shifted GEMMs (_conv3x3_small_map)."""
+    return (not lib.query('conv3x3_uses_mfma', B, H, W, Cin, Cout, 0) and _wino_variant(B, H, W, Cin, Cout, 0) is None
+            and H * W <= 256 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 64)
+
+
+def _conv_block(cur, w, b, B, H, W, pool, cache=False, relu=1):
+    """conv3x3 + bias (+ ReLU) (+ fused 2x2 max pool) on an NHWC activation -> NHWC output."""
     dev = cur.device
     Cout, Cin = w.shape[0], w.shape[1]
     wv = _wino_variant(B, H, W, Cin, Cout, pool)
@@ -756,11 +762,11 @@ def _conv_block(cur, w, b, B, H, W, pool, cache=False):
         out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
         _timed(f'{wv}_{H}x{W}_{Cin}->{Cout}{"+pool" if pool else ""}', 2.0 * B * H * W * Cout * Cin * 9,
                4.0 * B * (H * W * Cin + Ho * Wo * Cout),
-               lambda: lib(f'conv3x3_{wv}_nhwc', cur, up, b, out, B, H, W, Cin, Cout, 1, pool))
+               lambda: lib(f'conv3x3_{wv}_nhwc', cur, up, b, out, B, H, W, Cin, Cout, int(relu), pool))
         return out
     mfma = lib.query('conv3x3_uses_mfma', B, H, W, Cin, Cout, pool)
     if not mfma and not pool and H * W <= 256 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 64:
-        return _conv3x3_small_map(cur, w, b, B, H, W)
+        return _conv3x3_small_map(cur, w, b, B, H, W, relu)
     wp = tmp = None
     if mfma:
         wp = _packed_weights(w, 'direct', Cout * Cin * 9, lambda dst: lib('conv3x3_pack_weights', w, dst, Cout, Cin), cache)
@@ -768,7 +774,7 @@ def _conv_block(cur, w, b, B, H, W, pool, cache=False):
         tmp = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
-    launch = lambda: lib('conv3x3_nhwc', cur, w, wp, b, out, tmp, B, H, W, Cin, Cout, 1, pool)
+    launch = lambda: lib('conv3x3_nhwc', cur, w, wp, b, out, tmp, B, H, W, Cin, Cout, int(relu), pool)
     if mfma:
         _timed(f'conv{H}x{W}_{Cin}->{Cout}{"+pool" if pool else ""}', 2.0 * B * H * W * Cout * Cin * 9,
                4.0 * B * (H * W * Cin + Ho * Wo * Cout), launch)

@@ -2,10 +2,12 @@
 SURVEY.md section 0.1: parity unpinned by the reference, checked against oracle/resnet_oracle.py).
 
 ``ResNet152Trunk`` holds torchvision-named parameters and buffers (``conv1``, ``bn1``, ``layer{1..4}.{i}.conv{1,2,3}`` /
-``bn{1,2,3}`` / ``downsample.{0,1}``) so a torchvision ``resnet152`` state_dict loads, and runs as a FEATURE EXTRACTOR: under
-``no_grad``, BatchNorms on their running statistics whatever the module's mode (a frozen trunk; the statistics are then a
-per-channel affine map folded into the preceding convolution, csrc/resnet.hip).  A trunk that needs gradients, or batch
-statistics, raises: the trainable bottleneck / BatchNorm backward is not built.
+``bn{1,2,3}`` / ``downsample.{0,1}``) so a torchvision ``resnet152`` state_dict loads.  Two execution modes:
+  * FROZEN (no gradient wanted: under ``no_grad`` or all parameters frozen): a feature extractor with its BatchNorms on their
+    running statistics whatever the module's mode; the statistics are then a per-channel affine map folded into the preceding
+    convolution (csrc/resnet.hip), so every layer is one kernel with a fused bias + ReLU (+ residual) epilogue;
+  * TRAINABLE (gradients wanted): every convolution, BatchNorm (batch statistics in train mode, running statistics in eval mode)
+    and pool is an autograd node on the HIP kernels (resnet_ops.py), nn.Module semantics throughout.
 
 Execution: NHWC fp32; 7x7/s2 stem kernel; MaxPool(3,2,1) = pool3x3; 3x3 convolutions on the VGG trunk's kernels
 (Winograd F(4x4,3x3) / direct MFMA, bias + ReLU fused; stride 2 = stride 1 then a 2x subsample); 1x1 convolutions as the
@@ -105,10 +107,36 @@ class ResNet152Trunk(nn.Module):
         lib('subsample2_fwd', x, y, B, H, W, C, 0, 0)
         return y
 
+    # ---- trainable path: nn.Module semantics, every layer an autograd node ------------------------------------------
+    @staticmethod
+    def _t_conv1x1(x, conv):
+        B, H, W, Cin = x.shape
+        Cout = conv.weight.shape[0]
+        return ops.linear(x.reshape(B * H * W, Cin), conv.weight.reshape(Cout, Cin)).reshape(B, H, W, Cout)
+
+    def _forward_trainable(self, image):
+        from . import resnet_ops as R
+        from . import darts_ops as D
+        bn = lambda x, m, relu, res=None: R.BnActFn.apply(x, m.weight, m.bias, res, m, relu)
+        x = bn(R.StemFn.apply(image, self.conv1.weight), self.bn1, True)
+        x = D.Pool3x3Fn.apply(x, 2, 0)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                identity = x
+                if blk.downsample is not None:
+                    src = x if blk.stride == 1 else D.Subsample2Fn.apply(x, False)[0]
+                    identity = bn(self._t_conv1x1(src, blk.downsample[0]), blk.downsample[1], False)
+                out = bn(self._t_conv1x1(x, blk.conv1), blk.bn1, True)
+                out = R.Conv3x3Fn.apply(out, blk.conv2.weight)
+                if blk.stride == 2:
+                    out = D.Subsample2Fn.apply(out, False)[0]
+                out = bn(out, blk.bn2, True)
+                x = bn(self._t_conv1x1(out, blk.conv3), blk.bn3, True, identity)
+        return R.GlobalAvgPoolFn.apply(x)
+
     def forward(self, image):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError('ResNet152Trunk is a frozen feature extractor: call it under no_grad or freeze its parameters '
-                                      '(the trainable bottleneck / BatchNorm backward is not built)')
+            return self._forward_trainable(image)
         with torch.no_grad():
             image = ops._chk(image, 'image')
             B, C, H, W = image.shape

@@ -60,10 +60,6 @@ def test_resnet152_trunk_vs_oracle(hip_lib, size):
         again = net(img.to(DEV))
     assert got.shape == (2, 2048) and torch.equal(got, again)
     assert rel_err(got, want) < 1e-3
-    for p in net.parameters():
-        p.requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        net(img.to(DEV))                                        # not silently wrong: no gradients through this trunk
 
 
 def test_resnet_gru_model_train_step(hip_lib):
@@ -100,3 +96,87 @@ def test_resnet_gru_model_train_step(hip_lib):
     grads = torch.autograd.grad(loss, list(m.parameters()), allow_unused=True)
     none = {n for (n, _), g in zip(m.named_parameters(), grads) if g is None}
     assert none == {n for n, _ in m.named_parameters() if n.startswith('img_encoder.model.')}
+
+
+def test_bn_act_and_conv3x3_functions_vs_torch(hip_lib):
+    """The bottleneck's autograd nodes one by one against torch autograd: wide BatchNorm (+ residual + ReLU) in both modes, the
+    3x3 convolution on a tiled map and on a small map (shifted-GEMM path), the stem, the global average pool."""
+    import torch.nn.functional as F
+    from lct_vqa_amd import resnet_ops as R
+    torch.manual_seed(11)
+    for C, H, training, with_res, relu in ((512, 5, True, True, True), (64, 12, True, False, True), (2048, 2, False, True, True),
+                                            (256, 7, True, False, False)):
+        x = torch.randn(3, H, H, C, device=DEV, requires_grad=True)
+        res = torch.randn(3, H, H, C, device=DEV, requires_grad=True) if with_res else None
+        bn = torch.nn.BatchNorm2d(C).to(DEV).train(training)
+        bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.2)
+        bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+        ref_bn = torch.nn.BatchNorm2d(C).to(DEV).train(training)
+        ref_bn.load_state_dict(bn.state_dict())
+        y = R.BnActFn.apply(x, bn.weight, bn.bias, res, bn, relu)
+        xr = x.detach().clone().requires_grad_()
+        rr = res.detach().clone().requires_grad_() if with_res else None
+        yr = ref_bn(xr.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        if with_res:
+            yr = yr + rr
+        if relu:
+            yr = F.relu(yr)
+        assert rel_err(y, yr) < 1e-5
+        gy = torch.randn_like(y)
+        got = torch.autograd.grad(y, [x, bn.weight, bn.bias] + ([res] if with_res else []), gy)
+        want = torch.autograd.grad(yr, [xr, ref_bn.weight, ref_bn.bias] + ([rr] if with_res else []), gy)
+        for a, b in zip(got, want):
+            assert rel_err(a, b) < 2e-4, (C, H, training)
+        assert rel_err(bn.running_mean, ref_bn.running_mean) < 1e-5 and rel_err(bn.running_var, ref_bn.running_var) < 1e-5
+        assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked)
+    for Cin, Cout, H in ((64, 64, 16), (128, 128, 7), (512, 512, 3), (256, 256, 14)):
+        x = torch.randn(2, H, H, Cin, device=DEV, requires_grad=True)
+        w = (torch.randn(Cout, Cin, 3, 3, device=DEV) * 0.05).requires_grad_()
+        y = R.Conv3x3Fn.apply(x, w)
+        xr, wr = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
+        yr = F.conv2d(xr.permute(0, 3, 1, 2), wr, padding=1).permute(0, 2, 3, 1)
+        assert rel_err(y, yr) < 2e-5, (Cin, H)
+        gy = torch.randn_like(y)
+        for a, b in zip(torch.autograd.grad(y, [x, w], gy), torch.autograd.grad(yr, [xr, wr], gy)):
+            assert rel_err(a, b) < 1e-4, (Cin, H)
+    img = torch.randn(2, 3, 36, 44, device=DEV)
+    w = (torch.randn(64, 3, 7, 7, device=DEV) * 0.1).requires_grad_()
+    y = R.StemFn.apply(img, w)
+    wr = w.detach().clone().requires_grad_()
+    yr = F.conv2d(img, wr, stride=2, padding=3).permute(0, 2, 3, 1)
+    gy = torch.randn_like(y)
+    assert rel_err(y, yr) < 1e-5
+    assert rel_err(torch.autograd.grad(y, [w], gy)[0], torch.autograd.grad(yr, [wr], gy)[0]) < 1e-4
+    x = torch.randn(3, 4, 5, 32, device=DEV, requires_grad=True)
+    y = R.GlobalAvgPoolFn.apply(x)
+    assert rel_err(y, x.mean(dim=(1, 2))) < 1e-6
+    assert rel_err(torch.autograd.grad(y.sum() * 2, [x])[0], torch.full_like(x, 2.0 / 20)) < 1e-6
+
+
+def test_trainable_resnet152_vs_oracle(hip_lib):
+    """The trainable trunk (train-mode BatchNorm: batch statistics) against torch autograd on the restated architecture: output,
+    running statistics and the gradients of parameters from every stage."""
+    from oracle import resnet_oracle
+    from lct_vqa_amd.resnet import ResNet152Trunk
+    torch.manual_seed(7)
+    ref = resnet_oracle.resnet152().train()
+    _randomise_bn(ref, 8)
+    net = ResNet152Trunk()
+    net.load_state_dict(ref.state_dict())
+    net = net.to(DEV).train()
+    img = torch.randn(4, 3, 64, 64)
+    want = ref(img)
+    got = net(img.to(DEV))
+    assert rel_err(got, want) < 2e-3
+    names = ['conv1.weight', 'bn1.weight', 'layer1.0.conv2.weight', 'layer1.0.downsample.0.weight', 'layer2.0.conv2.weight',
+             'layer2.3.bn2.bias', 'layer3.0.downsample.1.weight', 'layer3.20.conv1.weight', 'layer4.0.conv2.weight', 'layer4.2.conv3.weight',
+             'layer4.2.bn3.weight']
+    gy = torch.randn(4, 2048)
+    rp, npar = dict(ref.named_parameters()), dict(net.named_parameters())
+    gw = torch.autograd.grad(want, [rp[n] for n in names], gy)
+    gg = torch.autograd.grad(got, [npar[n] for n in names], gy.to(DEV))
+    for n, a, b in zip(names, gg, gw):
+        assert rel_err(a, b) < 3e-2, (n, rel_err(a, b))
+    sd, rsd = net.state_dict(), ref.state_dict()
+    for k in ('bn1.running_mean', 'layer2.0.bn2.running_var', 'layer4.2.bn3.running_mean', 'layer3.5.bn1.num_batches_tracked'):
+        assert rel_err(sd[k].float(), rsd[k].float()) < 1e-3, k
