@@ -16,6 +16,7 @@ class Architect(object):
         self.model = model
         self.optimizer = bilevel.arch_optimizer(model.arch_parameters(), cfg.ARCH_LEARNING_RATE, cfg.ARCH_WEIGHT_DECAY)
         self.trace = None      # set to a dict to have the next step leave its intermediates there (parity tests)
+        self._twins = {}       # the virtual-step twins of the previous step, re-used (bilevel.virtual_step)
 
     def step(self, img_train, qst_train, label_train, img_valid, qst_valid, label_valid, eta=None,
              network_optimizer=None, unrolled=True):
@@ -37,7 +38,7 @@ class Architect(object):
     def _second_order(self, img_train, qst_train, label_train, img_valid, qst_valid, label_valid, eta):
         model = self.model
         weights = list(model.parameters())
-        ahead = bilevel.virtual_step(model, bilevel.grads(model._loss(img_train, qst_train, label_train), weights), eta)
+        ahead = bilevel.virtual_step(model, bilevel.grads(model._loss(img_train, qst_train, label_train), weights), eta, self._twins)
         ahead_alphas, ahead_weights = ahead.arch_parameters(), list(ahead.parameters())
         g = bilevel.grads(ahead._loss(img_valid, qst_valid, label_valid), ahead_alphas + ahead_weights)
         dalpha, v = g[:len(ahead_alphas)], g[len(ahead_alphas):]

@@ -28,6 +28,7 @@ class ArchitectLct(object):
         self.ef_optimizer, self.w_optimizer = ef_optimizer, w_optimizer
         self.optimizer = bilevel.arch_optimizer(ef_model.arch_parameters(), cfg.ARCH_LEARNING_RATE, cfg.ARCH_WEIGHT_DECAY)
         self.trace = None      # set to a dict to have the next step leave its intermediates there (parity tests)
+        self._twins = {}       # the virtual-step twins of the previous step, re-used (bilevel.virtual_step)
 
     def step(self, img_train, qst_train, label_train, img_valid, qst_valid, label_valid, ef_lr, w_lr):
         for opt in (self.ef_optimizer, self.w_optimizer, self.optimizer):
@@ -52,10 +53,10 @@ class ArchitectLct(object):
         ef, w = self.ef_model, self.w_model
         ef_weights, w_weights = list(ef.parameters()), list(w.parameters())
 
-        ef_ahead = bilevel.virtual_step(ef, bilevel.grads(ef._loss(img_train, qst_train, label_train), ef_weights, 0), ef_lr)
+        ef_ahead = bilevel.virtual_step(ef, bilevel.grads(ef._loss(img_train, qst_train, label_train), ef_weights, 0), ef_lr, self._twins, 'ef')
         pseudo_qst, pseudo_ans = self._tests(ef_ahead, img_train)
         soft = w._soft_loss(img_train, qst_train, label_train, pseudo_qst, pseudo_ans)
-        w_ahead = bilevel.virtual_step(w, bilevel.grads(soft, w_weights, self.W_FROZEN), w_lr)
+        w_ahead = bilevel.virtual_step(w, bilevel.grads(soft, w_weights, self.W_FROZEN), w_lr, self._twins, 'w')
 
         val_loss = w_ahead._loss(img_valid, qst_valid, label_valid)
         v = bilevel.grads(val_loss, w_ahead.parameters(), self.W_FROZEN)

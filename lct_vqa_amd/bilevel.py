@@ -41,11 +41,38 @@ def shift_(params, direction, alpha):
     torch._foreach_add_([p.data for p in params], list(direction), alpha=alpha)
 
 
-def virtual_step(model, g, lr):
+def virtual_step(model, g, lr, cache=None, key='twin'):
     """An independent copy of ``model`` (its own ``new()``: same class, same device, architecture parameters included)
-    whose parameters are theta - lr * g; buffers are copied as they are."""
-    twin = model.new()
-    twin.load_state_dict(model.state_dict())
+    whose parameters are theta - lr * g; buffers are copied as they are.
+
+    ``cache`` (a dict owned by the caller, e.g. an architect): the twin of the previous step is re-used instead of being
+    constructed again -- the reference builds a fresh model per step, which for the W model means initialising and uploading
+    a 575 MB VGG19 every time.  A re-used twin is refilled completely (every state_dict tensor and the architecture
+    parameters, a handful of multi-tensor copies), and nothing else of it is ever changed by the architects, so it is
+    indistinguishable from a fresh ``new()`` + ``load_state_dict``."""
+    twin = cache.get(key) if cache is not None else None
+    src = model.state_dict()
+    if twin is not None:
+        dst = twin.state_dict()
+        if list(dst) != list(src) or any(a.shape != b.shape for a, b in zip(dst.values(), src.values())):
+            twin = None                                          # another model: start over
+    if twin is None:
+        twin = model.new()
+        twin.load_state_dict(src)
+        if cache is not None:
+            cache[key] = twin
+    else:
+        with torch.no_grad():
+            for flt in (True, False):                            # one multi-tensor copy per dtype family
+                d = [t for t in dst.values() if t.is_floating_point() == flt]
+                s = [t for t in src.values() if t.is_floating_point() == flt]
+                if d:
+                    torch._foreach_copy_(d, s)
+            if hasattr(model, 'arch_parameters'):
+                try:
+                    torch._foreach_copy_([a.data for a in twin.arch_parameters()], [a.data for a in model.arch_parameters()])
+                except AttributeError:                           # a model without a search encoder
+                    pass
     shift_(list(twin.parameters()), g, -lr)
     return twin
 

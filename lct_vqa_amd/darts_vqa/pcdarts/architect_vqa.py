@@ -11,6 +11,7 @@ class Architect(object):
         self.model, self.args = model, args
         self.exp_zero_grad = 6 if args.qst_only else 0
         self.optimizer = bilevel.arch_optimizer(model.arch_parameters(), args.arch_learn_rate, args.arch_wt_decay)
+        self._twins = {}       # the virtual-step twins of the previous step, re-used (bilevel.virtual_step)
 
     def step(self, img_train, qst_train, label_train, img_valid, qst_valid, label_valid, eta, network_optimizer=None,
              unrolled=True):
@@ -34,7 +35,7 @@ class Architect(object):
         model = self.model
         weights = list(model.parameters())
         g_train = bilevel.grads(self._train_loss(model, img_train, qst_train, label_train), weights, self.exp_zero_grad)
-        ahead = bilevel.virtual_step(model, g_train, eta)
+        ahead = bilevel.virtual_step(model, g_train, eta, self._twins)
         ahead_alphas, ahead_weights = ahead.arch_parameters(), list(ahead.parameters())
         g = bilevel.grads(self._train_loss(ahead, img_valid, qst_valid, label_valid), ahead_alphas + ahead_weights)
         dalpha, v = g[:len(ahead_alphas)], g[len(ahead_alphas):]

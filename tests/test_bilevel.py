@@ -101,3 +101,29 @@ def test_two_level_architect_step_matches_exact_hypergradient(monkeypatch):
     a_before = m.a.detach().clone()
     arch.optimizer.step()
     assert not torch.equal(m.a.detach(), a_before)
+
+
+def test_cached_twin_is_indistinguishable_from_a_fresh_one():
+    """virtual_step(..., cache): the twin of the previous step is re-used; after the model's parameters, buffers and
+    architecture parameters moved it must hold exactly what a fresh new() + load_state_dict + SGD step would."""
+    torch.manual_seed(3)
+    m = Toy()
+    x, y = _data(4)
+    cache = {}
+    first = bilevel.virtual_step(m, bilevel.grads(m._loss(x, y), m.parameters(), 1), 0.05, cache)
+    assert cache['twin'] is first
+    with torch.no_grad():                                       # the model moves on: weights, buffer, architecture parameter
+        for p in m.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+        m.count.fill_(11.0)
+        m.a.add_(0.2)
+    g = bilevel.grads(m._loss(x, y), m.parameters(), 1)
+    again = bilevel.virtual_step(m, g, 0.05, cache)
+    fresh = bilevel.virtual_step(m, g, 0.05)
+    assert again is first and fresh is not first
+    for (k, a), (_, b) in zip(again.state_dict().items(), fresh.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert torch.equal(again.a, fresh.a) and again.a.data_ptr() != m.a.data_ptr()
+    other = Toy(4)                                              # a different model under the same cache: starts over
+    t = bilevel.virtual_step(other, [torch.zeros_like(p) for p in other.parameters()], 0.1, cache)
+    assert t is not first and t.w1.shape == (4,)
