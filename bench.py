@@ -53,6 +53,9 @@ def parse():
                     help='pipelined mode: hold the head of batch i until the trunk of batch i+1 has launched past conv layer N '
                          '(1..16; 0 = start it as soon as its own trunk is done).  Default 8 = after conv3_4: the head shares the chip with the '
                          '28x28 layers; 0.8 %% faster than 0, 12 and later leave it too little time')
+    ap.add_argument('--classifier-with-head', action='store_true',
+                    help='pipelined mode: the trunk stream runs vgg19.features + avgpool only; the classifier (fc6, fc7 + dropouts) runs with '
+                         'the head on the main stream (same work per step, other stream)')
     ap.add_argument('--stem-after', type=int, default=0,
                     help='pipelined mode: run conv1_1 of batch i+1 on a stream of its own, released when the trunk of batch i has '
                          'launched past conv layer N (0 = conv1_1 stays at the head of its own trunk)')
@@ -381,6 +384,8 @@ def main():
                     if stem is not None:
                         st.wait_event(stem[1])
                         feats.append(model.img_encoder.trunk(part, stem=stem[0]))
+                    elif args.classifier_with_head:
+                        feats.append(model.img_encoder.conv_features(part))
                     else:
                         feats.append(model.img_encoder.trunk(part))
             for st in trunk_streams[1:]:
@@ -409,7 +414,8 @@ def main():
                         main_stream.wait_event(ops.trunk_marker_event(args.head_after))
                 main_stream.wait_event(ev)
                 opt.zero_grad()
-                out = ops.cross_entropy(model(img, qst, feat), lab)
+                logits = model(img, qst, conv_feature=feat) if args.classifier_with_head else model(img, qst, feat)
+                out = ops.cross_entropy(logits, lab)
                 out.backward()
                 if reducer is not None:
                     reducer.finish()

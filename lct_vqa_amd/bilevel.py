@@ -17,17 +17,46 @@ exactly the in-place ``p.data`` writes the kernels are required to observe (SURV
 caches anything derived from a trainable parameter.
 """
 import torch
+import torch.distributed as dist
+
+_dp = {'group': None, 'on': False}
+
+
+def data_parallel(on=True, process_group=None):
+    """Under data parallelism every gradient the architecture steps take (dtheta of the virtual steps, grad_wprime, kappa,
+    both halves of every finite difference: SURVEY.md section 8e / 2.4) must be the gradient of the GLOBAL batch.  With this
+    switched on, ``grads`` averages its result over the ranks (one flat all-reduce per call), so every quantity derived from
+    it -- the virtual steps, ||v|| in R = r / ||v||, the alpha gradient -- is identical on all ranks and equal to the
+    single-process large-batch step (losses are means over samples; equal shards).  Returns the previous setting."""
+    prev = _dp['on']
+    _dp['on'], _dp['group'] = bool(on), process_group
+    return prev
+
+
+def _average_over_ranks(tensors):
+    world = dist.get_world_size(_dp['group']) if (_dp['on'] and dist.is_available() and dist.is_initialized()) else 1
+    if world == 1:
+        return tensors
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_dp['group'])
+    flat.mul_(1.0 / world)
+    out, o = [], 0
+    for t in tensors:
+        out.append(flat[o:o + t.numel()].view_as(t))
+        o += t.numel()
+    return out
 
 
 def grads(loss, tensors, expect_unused=None):
     """Gradients of ``loss`` w.r.t. ``tensors`` as a list; tensors the graph does not reach get zeros.  When
-    ``expect_unused`` is given, the number of unreached tensors must equal it (the reference asserts these counts)."""
+    ``expect_unused`` is given, the number of unreached tensors must equal it (the reference asserts these counts).
+    Averaged over the ranks when ``data_parallel`` is on."""
     tensors = list(tensors)
     got = torch.autograd.grad(loss, tensors, allow_unused=True)
     unused = sum(g is None for g in got)
     if expect_unused is not None and unused != expect_unused:
         raise AssertionError(f'{unused} tensors received no gradient, expected {expect_unused}')
-    return [torch.zeros_like(t) if g is None else g for g, t in zip(got, tensors)]
+    return _average_over_ranks([torch.zeros_like(t) if g is None else g for g, t in zip(got, tensors)])
 
 
 def global_norm(vectors):

@@ -126,3 +126,49 @@ def test_single_process_reducer_is_noop():
     before = flat.clone()
     red.finish()
     assert torch.equal(before, flat) and flat.abs().sum() > 0
+
+
+def _architect_worker(rank, world, port, out):
+    """A whole 2-level architecture step under data parallelism: each rank sees half of the train and of the valid batch,
+    bilevel.data_parallel() averages every gradient the step takes."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lct_vqa_amd import bilevel
+    from test_bilevel import Toy, _data
+    torch.manual_seed(5)
+    m = Toy()
+    x, y = _data(6, n=32)
+    vx, vy = _data(7, n=32)
+    sl = slice(rank * 16, (rank + 1) * 16)
+    bilevel.data_parallel(True)
+    try:
+        w = list(m.parameters())
+        ahead = bilevel.virtual_step(m, bilevel.grads(m._loss(x[sl], y[sl]), w, 1), 0.05)
+        g = bilevel.grads(ahead._loss(vx[sl], vy[sl]), ahead.arch_parameters() + list(ahead.parameters()), 1)
+        implicit = bilevel.fd_grad(w, g[1:], lambda: bilevel.grads(m._loss(x[sl], y[sl]), m.arch_parameters()))
+        dalpha = g[0] - 0.05 * implicit[0]
+    finally:
+        bilevel.data_parallel(False)
+    torch.save(dalpha.clone(), out + str(rank))
+    dist.destroy_process_group()
+
+
+def test_architecture_step_under_dp_equals_the_large_batch_step(tmp_path):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from lct_vqa_amd import bilevel
+    from test_bilevel import Toy, _data
+    out = str(tmp_path / 'a')
+    mp.spawn(_architect_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    a0, a1 = torch.load(out + '0'), torch.load(out + '1')
+    assert torch.equal(a0, a1)                                  # every rank holds the same architecture gradient
+    torch.manual_seed(5)
+    m = Toy()
+    x, y = _data(6, n=32)
+    vx, vy = _data(7, n=32)
+    w = list(m.parameters())
+    ahead = bilevel.virtual_step(m, bilevel.grads(m._loss(x, y), w, 1), 0.05)
+    g = bilevel.grads(ahead._loss(vx, vy), ahead.arch_parameters() + list(ahead.parameters()), 1)
+    implicit = bilevel.fd_grad(w, g[1:], lambda: bilevel.grads(m._loss(x, y), m.arch_parameters()))
+    ref = g[0] - 0.05 * implicit[0]
+    assert torch.allclose(a0, ref, rtol=1e-9, atol=1e-12)
