@@ -274,6 +274,20 @@ int lctvqa_conv7x7_s2_stem_wgrad(const float* x_nchw, const float* dz_nhwc, floa
 int lctvqa_copy_window_nhwc(const float* src, float* dst, int B, int Hs, int Ws, int Hd, int Wd, int C, int sy, int sx, int oy, int ox,
                             int h, int w, int relu, void* stream);
 
+/* ---- bf16 GEMM (fp32 accumulation, v_mfma_f32_32x32x16_bf16) and the bf16 helpers of the bf16 ResNet trunk: csrc/gemm_bf16.hip.
+ *      C[M][N] = act(A[M][K] . B[N][K]^T + bias[N] + addend[M][N]); A, B bf16 rows (strides in elements); C / addend bf16 when
+ *      out_bf16 else fp32 (addend may alias C); act 0 none / 1 ReLU ---- */
+int lctvqa_gemm_bf16_supported(long M, int N, int K);
+int lctvqa_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, long M, int N, int K, const float* bias,
+                     const void* addend, long ld_add, int act, int out_bf16, void* stream);
+int lctvqa_cvt_f32_to_bf16(const float* x, void* y, long n, void* stream);
+int lctvqa_cvt_bf16_to_f32(const void* x, float* y, long n, void* stream);
+int lctvqa_maxpool3x3_s2_bf16(const void* x, void* y, int B, int H, int W, int C, void* stream);
+int lctvqa_subsample2_bf16(const void* x, void* y, int B, int H, int W, int C, void* stream);
+int lctvqa_global_avgpool_bf16(const void* x, float* y, int B, int HW, int C, void* stream);
+int lctvqa_conv7x7_s2_stem_bf16(const float* x_nchw, const float* w_oihw, const float* bias, void* y_nhwc_bf16, int B, int H, int W, int relu,
+                                void* stream);
+
 /* One PC-DARTS MixedOp edge as fused tile kernels (model_search.py:22-55 + the seven live primitives of operations.py:4-20
  * on x[..., :C/4], their BatchNorms, the alpha-weighted sum, bypass, channel shuffle and the beta-weighted accumulation
  * into the node's sum, model_search.py:87): csrc/mixed_edge.hip.  w = 14 device pointers: depthwise weights [Cq][K][K] of

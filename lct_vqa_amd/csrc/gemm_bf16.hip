@@ -1,0 +1,274 @@
+// bf16 GEMM with fp32 accumulation on v_mfma_f32_32x32x16_bf16, "NT" form: C[M][N] = epi( sum_k A[m][k] * B[n][k] ),
+// A [M][K] and B [N][K] bf16 row-major (K contiguous: activations as NHWC rows, weights as stored), and the small bf16 helpers of
+// the bf16 ResNet trunk (BASELINE.json configs[2] in bf16; the reference has neither ResNet nor bf16).
+//   epi(v) = act( v + bias[n] + addend[m][n] ), output bf16 or fp32 (fp32 + in-place addend = accumulation over several calls).
+// Structure = the bf16 convolution kernel (conv3x3_bf16.hip) without taps and halo: workgroup tile 256 x 128 (or 64), 2 x 2 waves
+// of 4 x 2 (or 4 x 1) 32x32 accumulator tiles, K in steps of 32 (four 8-element planes of 16-byte LDS slots, lane half h of
+// k16-step kk reads plane 2kk + h), operand tiles by LDS-DMA, double buffered, one barrier per step, two workgroups per CU.
+// Rows beyond M read a zero page and are not stored.  Roofline: MFMA for K >= ~512, HBM below (1x1 convolutions with 64..256
+// input channels move (K + N) * 2 bytes per row for 2*K*N flops).
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+__device__ __attribute__((aligned(64))) float g_zero_page_gb[64];
+
+__device__ __forceinline__ unsigned short f2bf(float v) {
+  const __bf16 b = (__bf16)v;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned int)u << 16); }
+
+template <int NT2, bool OUT_BF16>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const unsigned short* __restrict__ A, long lda, const unsigned short* __restrict__ B,
+                                                           long ldb, void* __restrict__ Cv, long ldc, int M, int N, int K,
+                                                           const float* __restrict__ bias, const void* __restrict__ addv, long ld_add, int act) {
+  constexpr int BM = 256, BN = 64 * NT2, MT = 4;
+  constexpr int APL = BM * 4, BPL = BN * 4;                      // floats per 8-element plane of the A / B step tile
+  constexpr int ASZ = 4 * APL, BSZ = 4 * BPL;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* abuf = smem;                                           // [2][ASZ]
+  float* bbuf = smem + 2 * ASZ;                                 // [2][BSZ]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int j = lane & 31, h = lane >> 5;
+  const int NTL = N / BN;
+  const int n_tile = blockIdx.x % NTL, m_tile = blockIdx.x / NTL;
+  const long m0 = (long)m_tile * BM;
+  const int n0 = n_tile * BN;
+  const int S = K / 32;
+  long aoff[4];                                                 // element offset of this lane's rows of plane `wave` (or -1)
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const long row = m0 + r * 64 + lane;
+    aoff[r] = row < M ? row * lda + wave * 8 : -1;
+  }
+  long boff[NT2];
+#pragma unroll
+  for (int r = 0; r < NT2; r++) boff[r] = (long)(n0 + r * 64 + lane) * ldb + wave * 8;
+  auto stage = [&](int s, float* ad, float* bd) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float* src = aoff[r] >= 0 ? (const float*)(A + aoff[r] + (long)s * 32) : g_zero_page_gb;
+      glds16(src, ad + wave * APL + r * 256);
+    }
+#pragma unroll
+    for (int r = 0; r < NT2; r++) glds16((const float*)(B + boff[r] + (long)s * 32), bd + wave * BPL + r * 256);
+  };
+  f32x16 acc[MT][NT2];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int nn = 0; nn < NT2; nn++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][nn][r] = 0.f;
+  stage(0, abuf, bbuf);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int abase = h * APL + (wm * MT * 32 + j) * 4;
+  const int bbase = h * BPL + (wn * NT2 * 32 + j) * 4;
+  for (int s = 0; s < S; s++) {
+    if (s + 1 < S) stage(s + 1, abuf + ((s + 1) & 1) * ASZ, bbuf + ((s + 1) & 1) * BSZ);
+    const float* ab = abuf + (s & 1) * ASZ + abase;
+    const float* bb = bbuf + (s & 1) * BSZ + bbase;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      bf16x8 bf[NT2];
+#pragma unroll
+      for (int nn = 0; nn < NT2; nn++) bf[nn] = __builtin_bit_cast(bf16x8, *(const f32x4*)(bb + kk * 2 * BPL + nn * 128));
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+        const bf16x8 af = __builtin_bit_cast(bf16x8, *(const f32x4*)(ab + kk * 2 * APL + m * 128));
+#pragma unroll
+        for (int nn = 0; nn < NT2; nn++) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nn], acc[m][nn], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (OUT_BF16) {
+    // bf16 output: every 32-row x (32*NT2)-column block of a wave goes through a private LDS tile so that a lane stores 32
+    // consecutive bytes per 16 columns (whole 64..128-byte row segments per store instead of 2-byte scatters); bias, addend
+    // and activation are applied on the row segments, the addend read as 16-byte vectors too.
+    constexpr int TC = 32 * NT2, TS = TC + 1;                      // tile columns, padded row stride (floats)
+    float* T = smem + wave * 32 * TS;
+    const int trow = lane >> 1, tcol = (lane & 1) * (TC / 2);       // this lane's row and first column of the read-back
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+      __syncthreads();                                            // operand buffers / the previous block's read-back are done
+#pragma unroll
+      for (int nn = 0; nn < NT2; nn++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) T[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + nn * 32 + j] = acc[m][nn][r];
+      __syncthreads();
+      const long row = m0 + wm * 128 + m * 32 + trow;
+      const int col0 = n0 + wn * TC + tcol;
+      if (row < M) {
+        unsigned short* crow = (unsigned short*)Cv + row * ldc + col0;
+        const unsigned short* arow = addv ? (const unsigned short*)addv + row * ld_add + col0 : nullptr;
+#pragma unroll
+        for (int c8 = 0; c8 < TC / 16; c8++) {
+          typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+          us8 av = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (arow) av = *(const us8*)(arow + 8 * c8);
+          us8 ov;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            float v = T[trow * TS + tcol + 8 * c8 + e] + (bias ? bias[col0 + 8 * c8 + e] : 0.f);
+            if (arow) v += bf2f(av[e]);
+            if (act == 1) v = fmaxf(v, 0.f);
+            ov[e] = f2bf(v);
+          }
+          *(us8*)(crow + 8 * c8) = ov;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int nn = 0; nn < NT2; nn++) {
+      const int col = n0 + (wn * NT2 + nn) * 32 + j;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const long row = m0 + wm * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) {
+            float v = acc[m][nn][r] + bv;
+            if (addv) v += ((const float*)addv)[row * ld_add + col];
+            if (act == 1) v = fmaxf(v, 0.f);
+            ((float*)Cv)[row * ldc + col] = v;
+          }
+        }
+    }
+  }
+}
+
+// ---- elementwise / window helpers on bf16 NHWC tensors ----
+__global__ void cvt_f32_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n4) {
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n4; o += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = ((const f32x4*)x)[o];
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    ((us4*)y)[o] = us4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+  }
+}
+__global__ void cvt_bf16_f32_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, long n4) {
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n4; o += (long)gridDim.x * blockDim.x) {
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    const us4 v = ((const us4*)x)[o];
+    ((f32x4*)y)[o] = f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+  }
+}
+// MaxPool2d(3, stride 2, padding 1) on bf16 NHWC
+__global__ void maxpool3x3_s2_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int B, int H, int W, int C,
+                                          int Ho, int Wo) {
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < (long)B * Ho * Wo * C; o += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(o % C);
+    long q = o / C;
+    const int ox = (int)(q % Wo); q /= Wo;
+    const int oy = (int)(q % Ho);
+    const long n = q / Ho;
+    float a = -INFINITY;
+    for (int ky = 0; ky < 3; ky++) {
+      const int iy = 2 * oy - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; kx++) {
+        const int ix = 2 * ox - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        a = fmaxf(a, bf2f(x[((n * H + iy) * W + ix) * C + c]));
+      }
+    }
+    y[o] = f2bf(a);
+  }
+}
+// y[n][oy][ox][:] = x[n][2oy][2ox][:]  (bf16 NHWC, 16-byte vectors: C % 8 == 0)
+__global__ void subsample2_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int B, int H, int W, int C8) {
+  const int Ho = H / 2, Wo = W / 2;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < (long)B * Ho * Wo * C8; o += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(o % C8);
+    long q = o / C8;
+    const int ox = (int)(q % Wo); q /= Wo;
+    const int oy = (int)(q % Ho);
+    const long n = q / Ho;
+    ((f32x4*)y)[o] = ((const f32x4*)x)[((n * H + 2 * oy) * W + 2 * ox) * C8 + c];
+  }
+}
+// y[n][c] (fp32) = mean over the HW pixels of bf16 x[n][:][c]
+__global__ void global_avgpool_bf16_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, int B, int HW, int C) {
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < (long)B * C; o += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(o % C);
+    const long n = o / C;
+    float a = 0.f;
+    for (int p = 0; p < HW; p++) a += bf2f(x[(n * HW + p) * C + c]);
+    y[o] = a / (float)HW;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// 1 when lctvqa_gemm_bf16 takes this problem
+int lctvqa_gemm_bf16_supported(long M, int N, int K) { return (M >= 1 && N >= 64 && N % 64 == 0 && K >= 32 && K % 32 == 0) ? 1 : 0; }
+
+// C[M][N] = act(A[M][K] . B[N][K]^T + bias[N] + addend[M][N]); A, B bf16 with row strides lda / ldb (elements, multiples of 8);
+// out_bf16: C and addend are bf16, else fp32 (addend may alias C: accumulation).  act: 0 none, 1 ReLU.
+int lctvqa_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, long M, int N, int K, const float* bias,
+                     const void* addend, long ld_add, int act, int out_bf16, void* stream) {
+  LCT_REQUIRE(lctvqa_gemm_bf16_supported(M, N, K), "gemm_bf16: need N %% 64 == 0, K %% 32 == 0 (got M=%ld N=%d K=%d)", M, N, K);
+  LCT_REQUIRE((lda & 7) == 0 && (ldb & 7) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0, "gemm_bf16: operands must be 16-B aligned rows");
+  LCT_REQUIRE(!out_bf16 || ((ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && (!addend || ((ld_add & 7) == 0 && ((uintptr_t)addend & 15) == 0))),
+              "gemm_bf16: bf16 output / addend rows must be 16-B aligned");
+  LCT_REQUIRE(M < (1L << 31) && act >= 0 && act <= 1, "gemm_bf16: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned short* a = (const unsigned short*)A;
+  const unsigned short* b = (const unsigned short*)B;
+  const long mt = (M + 255) / 256;
+#define GB(NT2v, OBF)                                                                                                       \
+  {                                                                                                                        \
+    const size_t lds = (size_t)(2 * 4 * 256 * 4 + 2 * 4 * 64 * NT2v * 4) * sizeof(float);                                  \
+    auto k = gemm_bf16_kernel<NT2v, OBF>;                                                                                  \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+    hipLaunchKernelGGL(k, dim3((unsigned)(mt * (N / (64 * NT2v)))), dim3(256), lds, st, a, lda, b, ldb, C, ldc, (int)M, N, K, bias, addend, \
+                       ld_add, act);                                                                                       \
+  }
+  if (N % 128 == 0) { if (out_bf16) GB(2, true) else GB(2, false) }
+  else { if (out_bf16) GB(1, true) else GB(1, false) }
+#undef GB
+  return lct_check_launch("gemm_bf16");
+}
+
+int lctvqa_cvt_f32_to_bf16(const float* x, void* y, long n, void* stream) {
+  LCT_REQUIRE(n % 4 == 0, "cvt_f32_to_bf16: n %% 4");
+  long nb = (n / 4 + 255) / 256; if (nb > 8192) nb = 8192; if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)y, n / 4);
+  return lct_check_launch("cvt_f32_to_bf16");
+}
+int lctvqa_cvt_bf16_to_f32(const void* x, float* y, long n, void* stream) {
+  LCT_REQUIRE(n % 4 == 0, "cvt_bf16_to_f32: n %% 4");
+  long nb = (n / 4 + 255) / 256; if (nb > 8192) nb = 8192; if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(cvt_bf16_f32_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, y, n / 4);
+  return lct_check_launch("cvt_bf16_to_f32");
+}
+int lctvqa_maxpool3x3_s2_bf16(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  long nb = ((long)B * Ho * Wo * C + 255) / 256; if (nb > 16384) nb = 16384;
+  hipLaunchKernelGGL(maxpool3x3_s2_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)y, B, H, W, C, Ho, Wo);
+  return lct_check_launch("maxpool3x3_s2_bf16");
+}
+int lctvqa_subsample2_bf16(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+  LCT_REQUIRE(C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "subsample2_bf16: need C %% 8 == 0 and even H, W");
+  long nb = ((long)B * (H / 2) * (W / 2) * (C / 8) + 255) / 256; if (nb > 16384) nb = 16384;
+  hipLaunchKernelGGL(subsample2_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)y, B, H, W, C / 8);
+  return lct_check_launch("subsample2_bf16");
+}
+int lctvqa_global_avgpool_bf16(const void* x, float* y, int B, int HW, int C, void* stream) {
+  long nb = ((long)B * C + 255) / 256; if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(global_avgpool_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, y, B, HW, C);
+  return lct_check_launch("global_avgpool_bf16");
+}
+
+}  // extern "C"

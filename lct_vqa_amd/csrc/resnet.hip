@@ -29,8 +29,9 @@ __global__ void fold_bn_kernel(const float* __restrict__ w, const float* __restr
 // Stem: Conv2d(3, 64, 7, stride 2, padding 3) + bias + ReLU, fp32 NCHW image -> NHWC.  One workgroup per output row; the
 // 7 x 3 zero-padded input rows and the [147][64] weights sit in LDS; lane = output channel, a wave walks 8 output pixels at
 // a time (inputs as wave-uniform 16-byte broadcasts).  147 MACs per output: VALU work, HBM-write bound beyond that.
+template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void conv7x7_s2_stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, float* __restrict__ y, int B, int H,
+                                                              const float* __restrict__ bias, void* __restrict__ yv, int B, int H,
                                                               int W, int relu) {
   constexpr int PX = 8, CO = 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -72,7 +73,12 @@ __global__ __launch_bounds__(256) void conv7x7_s2_stem_kernel(const float* __res
     }
 #pragma unroll
     for (int i = 0; i < PX; i++)
-      if (x0 + i < Wo) y[(((long)n * Ho + oy) * Wo + x0 + i) * CO + lane] = relu ? fmaxf(a[i], 0.f) : a[i];
+      if (x0 + i < Wo) {
+        const float v = relu ? fmaxf(a[i], 0.f) : a[i];
+        const long o = (((long)n * Ho + oy) * Wo + x0 + i) * CO + lane;
+        if (OUT_BF16) { const __bf16 b = (__bf16)v; ((unsigned short*)yv)[o] = __builtin_bit_cast(unsigned short, b); }
+        else ((float*)yv)[o] = v;
+      }
   }
 }
 
@@ -301,18 +307,33 @@ int lctvqa_fold_bn(const float* w, const float* gamma, const float* beta, const 
   return lct_check_launch("fold_bn");
 }
 
-// fp32 NCHW [B,3,H,W] -> NHWC [B,Ho,Wo,64], Ho = (H - 1) / 2 + 1
-int lctvqa_conv7x7_s2_stem(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc, int B, int H, int W, int relu,
-                           void* stream) {
+static int launch_stem(const float* x_nchw, const float* w_oihw, const float* bias, void* y_nhwc, int B, int H, int W, int relu, int out_bf16,
+                       void* stream) {
   LCT_REQUIRE(B > 0 && H >= 7 && W >= 7, "conv7x7_s2_stem: bad shape");
   const int Ho = (H - 1) / 2 + 1;
   const int WP = (W + 6 + 16 + 7 + 3) & ~3;
   const size_t lds = (size_t)(21 * WP + 147 * 64) * sizeof(float);
   LCT_REQUIRE(lds <= 160 * 1024, "conv7x7_s2_stem: W too large");
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)conv7x7_s2_stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  hipLaunchKernelGGL(conv7x7_s2_stem_kernel, dim3(B * Ho), dim3(256), lds, (hipStream_t)stream, x_nchw, w_oihw, bias, y_nhwc, B, H, W, relu);
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv7x7_s2_stem_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv7x7_s2_stem_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  if (out_bf16)
+    hipLaunchKernelGGL(conv7x7_s2_stem_kernel<true>, dim3(B * Ho), dim3(256), lds, (hipStream_t)stream, x_nchw, w_oihw, bias, y_nhwc, B, H, W, relu);
+  else
+    hipLaunchKernelGGL(conv7x7_s2_stem_kernel<false>, dim3(B * Ho), dim3(256), lds, (hipStream_t)stream, x_nchw, w_oihw, bias, y_nhwc, B, H, W, relu);
   return lct_check_launch("conv7x7_s2_stem");
+}
+// fp32 NCHW [B,3,H,W] -> NHWC [B,Ho,Wo,64] fp32 (or bf16: the _bf16 form), Ho = (H - 1) / 2 + 1
+int lctvqa_conv7x7_s2_stem(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc, int B, int H, int W, int relu,
+                           void* stream) {
+  return launch_stem(x_nchw, w_oihw, bias, y_nhwc, B, H, W, relu, 0, stream);
+}
+int lctvqa_conv7x7_s2_stem_bf16(const float* x_nchw, const float* w_oihw, const float* bias, void* y_nhwc_bf16, int B, int H, int W, int relu,
+                                void* stream) {
+  return launch_stem(x_nchw, w_oihw, bias, y_nhwc_bf16, B, H, W, relu, 1, stream);
 }
 
 int lctvqa_copy_window_nhwc(const float* src, float* dst, int B, int Hs, int Ws, int Hd, int Wd, int C, int sy, int sx, int oy, int ox,

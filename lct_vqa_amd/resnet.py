@@ -6,6 +6,8 @@ SURVEY.md section 0.1: parity unpinned by the reference, checked against oracle/
   * FROZEN (no gradient wanted: under ``no_grad`` or all parameters frozen): a feature extractor with its BatchNorms on their
     running statistics whatever the module's mode; the statistics are then a per-channel affine map folded into the preceding
     convolution (csrc/resnet.hip), so every layer is one kernel with a fused bias + ReLU (+ residual) epilogue;
+    with ``ops.set_compute_dtype('bf16')`` the same layers run on the bf16 kernels (bf16 activations and folded weights, fp32
+    accumulation: bf16 GEMM for 1x1, conv3x3_bf16 for 3x3, fp32 for the 7x7 maps of the last stage);
   * TRAINABLE (gradients wanted): every convolution, BatchNorm (batch statistics in train mode, running statistics in eval mode)
     and pool is an autograd node on the HIP kernels (resnet_ops.py), nn.Module semantics throughout.
 
@@ -134,9 +136,94 @@ class ResNet152Trunk(nn.Module):
                 x = bn(self._t_conv1x1(out, blk.conv3), blk.bn3, True, identity)
         return R.GlobalAvgPoolFn.apply(x)
 
+    # ---- frozen path in bf16 (ops.set_compute_dtype('bf16')): bf16 activations / weights, fp32 accumulation ----------
+    def _fold_bf16(self, conv, bn, packed3x3=False):
+        """(bf16 weights, fp32 shift) of a folded convolution: [Cout][Cin] rows for the GEMM, or the 3x3 kernel's packed layout."""
+        wf, shift = self._fold(conv, bn)
+        key = ('bf16', id(conv), packed3x3)
+        hit = self._folded.get(key)
+        if hit is not None and hit[0] is wf:
+            return hit[1], shift
+        Cout, Cin = wf.shape[0], wf.shape[1]
+        wb = torch.empty(wf.numel(), dtype=torch.bfloat16, device=wf.device)
+        if packed3x3:
+            lib('conv3x3_bf16_pack_weights', wf, wb, Cout, Cin)
+        else:
+            lib('cvt_f32_to_bf16', wf, wb, wf.numel())
+        self._folded[key] = (wf, wb)
+        return wb, shift
+
+    def _b_conv1x1(self, x, conv, bn, relu, identity=None):
+        B, H, W, Cin = x.shape
+        wb, shift = self._fold_bf16(conv, bn)
+        Cout = conv.weight.shape[0]
+        P = B * H * W
+        y = torch.empty((B, H, W, Cout), dtype=torch.bfloat16, device=x.device)
+        ops._timed(f'gemm1x1_bf16_{H}x{W}_{Cin}->{Cout}', 2.0 * P * Cin * Cout, 2.0 * P * (Cin + Cout * (1 if identity is None else 2)),
+                   lambda: lib('gemm_bf16', x, Cin, wb, Cin, y, Cout, P, Cout, Cin, shift, identity, Cout, int(relu), 1))
+        return y
+
+    def _b_conv3x3(self, x, conv, bn, stride):
+        B, H, W, Cin = x.shape
+        Cout = conv.weight.shape[0]
+        dev = x.device
+        if lib.query('conv3x3_bf16_supported', B, H, W, Cin, Cout, 0):
+            wb, shift = self._fold_bf16(conv, bn, packed3x3=True)
+            y = torch.empty((B, H, W, Cout), dtype=torch.bfloat16, device=dev)
+            ops._timed(f'bf16_{H}x{W}_{Cin}->{Cout}', 2.0 * B * H * W * Cout * Cin * 9, 2.0 * B * H * W * (Cin + Cout),
+                       lambda: lib('conv3x3_bf16_nhwc', x, wb, shift, y, B, H, W, Cin, Cout, 1, 0))
+        else:                                                    # maps without a bf16 tiling (7x7): the fp32 path of this layer
+            xf = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+            lib('cvt_bf16_to_f32', x, xf, x.numel())
+            yf = self._conv3x3(xf, conv, bn, 1)
+            y = torch.empty((B, H, W, Cout), dtype=torch.bfloat16, device=dev)
+            lib('cvt_f32_to_bf16', yf, y, yf.numel())
+        if stride == 1:
+            return y
+        if H % 2 or W % 2:
+            raise NotImplementedError('ResNet152Trunk: odd feature-map size at a stride-2 block')
+        z = torch.empty((B, H // 2, W // 2, Cout), dtype=torch.bfloat16, device=dev)
+        lib('subsample2_bf16', y, z, B, H, W, Cout)
+        return z
+
+    def _forward_frozen_bf16(self, image):
+        image = ops._chk(image, 'image')
+        B, C, H, W = image.shape
+        dev = image.device
+        wf, shift = self._fold(self.conv1, self.bn1)
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        x = torch.empty((B, Ho, Wo, 64), dtype=torch.bfloat16, device=dev)
+        lib('conv7x7_s2_stem_bf16', image, wf, shift, x, B, H, W, 1)
+        Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+        y = torch.empty((B, Hp, Wp, 64), dtype=torch.bfloat16, device=dev)
+        lib('maxpool3x3_s2_bf16', x, y, B, Ho, Wo, 64)
+        x = y
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                identity = x
+                if blk.downsample is not None:
+                    src = x
+                    if blk.stride == 2:
+                        Bs, Hs, Ws, Cs = x.shape
+                        if Hs % 2 or Ws % 2:
+                            raise NotImplementedError('ResNet152Trunk: odd feature-map size at a stride-2 block')
+                        src = torch.empty((Bs, Hs // 2, Ws // 2, Cs), dtype=torch.bfloat16, device=dev)
+                        lib('subsample2_bf16', x, src, Bs, Hs, Ws, Cs)
+                    identity = self._b_conv1x1(src, blk.downsample[0], blk.downsample[1], relu=False)
+                out = self._b_conv1x1(x, blk.conv1, blk.bn1, relu=True)
+                out = self._b_conv3x3(out, blk.conv2, blk.bn2, blk.stride)
+                x = self._b_conv1x1(out, blk.conv3, blk.bn3, relu=True, identity=identity)
+        Bf, Hf, Wf, Cf = x.shape
+        feat = torch.empty((Bf, Cf), dtype=torch.float32, device=dev)
+        lib('global_avgpool_bf16', x, feat, Bf, Hf * Wf, Cf)
+        return feat
+
     def forward(self, image):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return self._forward_trainable(image)
+        if ops.get_compute_dtype() == 'bf16' and image.shape[1] == 3:
+            with torch.no_grad():
+                return self._forward_frozen_bf16(image)
         with torch.no_grad():
             image = ops._chk(image, 'image')
             B, C, H, W = image.shape

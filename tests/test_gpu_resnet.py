@@ -180,3 +180,56 @@ def test_trainable_resnet152_vs_oracle(hip_lib):
     sd, rsd = net.state_dict(), ref.state_dict()
     for k in ('bn1.running_mean', 'layer2.0.bn2.running_var', 'layer4.2.bn3.running_mean', 'layer3.5.bn1.num_batches_tracked'):
         assert rel_err(sd[k].float(), rsd[k].float()) < 1e-3, k
+
+
+def test_gemm_bf16_vs_torch(hip_lib):
+    lib = hip_lib
+    torch.manual_seed(13)
+    for M, N, K, act, with_add, out_bf16 in ((1000, 128, 64, 1, True, 1), (257, 64, 256, 0, False, 1), (3136, 256, 64, 1, False, 1),
+                                              (500, 2048, 512, 1, True, 1), (640, 512, 512, 0, True, 0)):
+        A = torch.randn(M, K, device=DEV).bfloat16()
+        Bw = (torch.randn(N, K, device=DEV) / K ** 0.5).bfloat16()
+        bias = torch.randn(N, device=DEV) * 0.1
+        add = torch.randn(M, N, device=DEV)
+        add = add.bfloat16() if out_bf16 else add
+        C = torch.full((M, N), float('nan'), device=DEV, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+        lib('gemm_bf16', A, K, Bw, K, C, N, M, N, K, bias, add if with_add else None, N, act, out_bf16)
+        ref = A.float() @ Bw.float().T + bias + (add.float() if with_add else 0)
+        if act:
+            ref = torch.relu(ref)
+        tol = 6e-3 if out_bf16 else 1e-5
+        assert (C.float() - ref).abs().max().item() <= tol * ref.abs().max().item(), (M, N, K)
+    C0 = torch.randn(300, 128, device=DEV)                      # fp32 accumulation over two calls (addend aliases the output)
+    A = torch.randn(300, 96, device=DEV).bfloat16(); Bw = torch.randn(128, 96, device=DEV).bfloat16()
+    C = C0.clone()
+    lib('gemm_bf16', A, 96, Bw, 96, C, 128, 300, 128, 96, None, C, 128, 0, 0)
+    assert rel_err(C, C0 + A.float() @ Bw.float().T) < 1e-5
+
+
+@pytest.mark.parametrize('size', [64, 224])
+def test_resnet152_trunk_bf16_vs_oracle(hip_lib, size):
+    """The frozen trunk in bf16 against the fp32 oracle: ~150 layers of bf16 activations; tolerance 5e-2 of the largest feature
+    (measured ~1e-2), the feature ranking of each image essentially unchanged (correlation > 0.999)."""
+    from oracle import resnet_oracle
+    from lct_vqa_amd import ops
+    from lct_vqa_amd.resnet import ResNet152Trunk
+    torch.manual_seed(3)
+    ref = resnet_oracle.resnet152().eval()
+    _randomise_bn(ref, 4)
+    net = ResNet152Trunk()
+    net.load_state_dict(ref.state_dict())
+    net = net.to(DEV).eval()
+    img = torch.randn(2, 3, size, size)
+    with torch.no_grad():
+        want = ref(img)
+    prev = ops.set_compute_dtype('bf16')
+    try:
+        with torch.no_grad():
+            got = net(img.to(DEV))
+    finally:
+        ops.set_compute_dtype(prev)
+    assert got.dtype == torch.float32 and got.shape == want.shape
+    assert rel_err(got, want) < 5e-2
+    g, w = got.cpu().double(), want.double()
+    for i in range(2):
+        assert torch.corrcoef(torch.stack([g[i], w[i]]))[0, 1].item() > 0.999
