@@ -176,12 +176,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
 #pragma unroll
     for (int s = 0; s < 4; s++) tcol(Vd, nu, s);
   };
-  // transform work of the main loop cut into slices pinned between the MFMAs of step q (slot i = 0, 1)
-  auto tslice = [&](const float* rwn, float* Vn, int q, int i, int nu) __attribute__((always_inline)) {
+  // transform work of the main loop cut into slices pinned between the MFMAs: slot k = 2 * step + i (i = 0, 1) of a phase of
+  // ntw steps.  The four column slices take the last four slots, the six row slices the odd slots before them (ntw >= 8), or
+  // slots 1 3 5 7 8 9 (ntw = 7), 2..7 (ntw = 6).
+  auto tslice = [&](const float* rwn, float* Vn, int q, int i, int nu, int ntw) __attribute__((always_inline)) {
     if (nu > 5) return;
-    // steps 0..5, slot 1: row q; steps 6, 7: the four column slices (every wave has at least 8 steps per phase)
-    if (i == 1 && q < 6) trow(rwn, q, nu);
-    if (q == 6 || q == 7) tcol(Vn, nu, (q - 6) * 2 + i);
+    const int k = 2 * q + i, k0 = 2 * ntw - 4;
+    if (k >= k0) { tcol(Vn, nu, k - k0); return; }
+    int r = -1;
+    if (ntw >= 8) r = (k & 1) && k <= 11 ? (k - 1) / 2 : -1;
+    else if (ntw == 7) r = k == 1 ? 0 : k == 3 ? 1 : k == 5 ? 2 : k >= 7 ? k - 4 : -1;
+    else r = k >= 2 ? k - 2 : -1;
+    if (r >= 0) trow(rwn, r, nu);
   };
 
   // -DW4_DIAG: per-wave s_memtime stamps (ticks parked at the end-of-phase wait + barrier, K-loop ticks, epilogue ticks)
@@ -202,76 +208,102 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
   // 8 to each of waves 0..5 (which also carry a transform column) and 12 to waves 6 and 7 (which do not): measured with
   // the even 9/9 split, waves 6/7 spent 31-37 % of the K loop parked at the phase barrier while the SIMDs carrying two
   // transform waves set the pace (-DW4_DIAG).  Tile ranges: wave w < 6: [8w, 8w+8), wave 6: [48, 60), wave 7: [60, 72).
-  f32x16 acc[12];
+  f32x16 acc[13];
 #pragma unroll
-  for (int q = 0; q < 12; q++)
+  for (int q = 0; q < 13; q++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
   const float* ubg0 = up + (long)(n_tile * 2) * NCH * UCH + (h * 32 + j) * 4;     // channel group cg = 0 / 1 of this n_tile
   const float* ubg1 = ubg0 + (long)NCH * UCH;
   const float* va0 = V + h * 128 + j * 4;
-  const int t0w = wave < 6 ? 8 * wave : 48 + 12 * (wave - 6);
-  // weights: ring of four slots; the slot of step s is refilled right behind its MFMAs with the weights of step s+4
-  // (this chunk's, or the next chunk's s+4-NTW): three steps of lead in 16 registers
-  f32x4 Bw[4];
+  // accumulator tiles per wave (sum 72).  Default 8 8 8 8 | 9 9 11 11 (SIMDs 17 17 19 19).
+#ifndef W4_N0
+#define W4_N0 8
+#define W4_N1 8
+#define W4_N2 8
+#define W4_N3 8
+#define W4_N4 9
+#define W4_N5 9
+#define W4_N6 11
+#define W4_N7 11
+#endif
+#define W4_T1 (W4_N0)
+#define W4_T2 (W4_T1 + W4_N1)
+#define W4_T3 (W4_T2 + W4_N2)
+#define W4_T4 (W4_T3 + W4_N3)
+#define W4_T5 (W4_T4 + W4_N4)
+#define W4_T6 (W4_T5 + W4_N5)
+#define W4_T7 (W4_T6 + W4_N6)
+  static_assert(W4_T7 + W4_N7 == 72, "the eight waves must cover the 72 accumulator tiles");
+  // ring size of the weight registers for a wave with N steps: every load needs at least three steps of lead (see below)
+#define W4_RING(N) ((N) == 6 ? 3 : ((N) % 4 == 1 || (N) == 10) ? 5 : 4)
+  const int t0w = wave == 0 ? 0 : wave == 1 ? W4_T1 : wave == 2 ? W4_T2 : wave == 3 ? W4_T3 : wave == 4 ? W4_T4 : wave == 5 ? W4_T5
+                  : wave == 6 ? W4_T6 : W4_T7;
+  const int ringw = wave == 0 ? W4_RING(W4_N0) : wave == 1 ? W4_RING(W4_N1) : wave == 2 ? W4_RING(W4_N2) : wave == 3 ? W4_RING(W4_N3)
+                    : wave == 4 ? W4_RING(W4_N4) : wave == 5 ? W4_RING(W4_N5) : wave == 6 ? W4_RING(W4_N6) : W4_RING(W4_N7);
+  // weights: ring of R register slots, step s uses slot s % R; right behind its MFMAs the slot is refilled with the weights of
+  // its next user: step s+R of this chunk, or (s was the slot's last user) step s % R of the next chunk.  R = 4 gives at least
+  // three steps of lead for 7, 8, 11 and 12 steps per phase; 9, 10 and 13 steps need R = 5 (with R = 4 step 8 and the next
+  // chunk's step 0 would share a slot back to back), 6 steps R = 3.
+  f32x4 Bw[5];
   f32x4 Aa, Ab;
 #define W4_XN(T0, S) (((T0) + (S)) % 36)
 #define W4_UB(T0, S) ((((T0) + (S)) / 36) ? ubg1 : ubg0)
-#define W4_MF(S, ACUR, E) acc[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(ACUR[E], Bw[(S) % 4][E], acc[S], 0, 0, 0)
+#define W4_MF(S, ACUR, E, R) acc[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(ACUR[E], Bw[(S) % (R)][E], acc[S], 0, 0, 0)
   // one tile: 4 MFMAs (8 channels); the other work is pinned between them in source order
-#define W4_STEP(S, ACUR, ANEXT, NXT, NU, T0, NTW)                                                      \
+#define W4_STEP(S, ACUR, ANEXT, NXT, NU, T0, NTW, R)                                                   \
   if ((S) < (NTW)) {                                                                                  \
-    W4_MF(S, ACUR, 0);                                                                                \
+    W4_MF(S, ACUR, 0, R);                                                                             \
     if ((S) + 1 < (NTW)) ANEXT = *(const f32x4*)(vc + W4_XN(T0, (S) + 1) * 256);                       \
     W4_SB();                                                                                          \
-    W4_MF(S, ACUR, 1);                                                                                \
-    if (NXT) tslice(rwn, Vn, S, 0, NU);                                                  \
+    W4_MF(S, ACUR, 1, R);                                                                             \
+    if (NXT) tslice(rwn, Vn, S, 0, NU, NTW);                                             \
     W4_SB();                                                                                          \
-    W4_MF(S, ACUR, 2);                                                                                \
-    if (NXT) tslice(rwn, Vn, S, 1, NU);                                                  \
+    W4_MF(S, ACUR, 2, R);                                                                             \
+    if (NXT) tslice(rwn, Vn, S, 1, NU, NTW);                                             \
     W4_SB();                                                                                          \
-    W4_MF(S, ACUR, 3);                                                                                \
-    if ((S) + 4 < (NTW)) {                                                                            \
-      Bw[(S) % 4] = *(const f32x4*)(W4_UB(T0, (S) + 4) + (long)chunk * UCH + W4_XN(T0, (S) + 4) * 256);   \
+    W4_MF(S, ACUR, 3, R);                                                                             \
+    if ((S) + (R) < (NTW)) {                                                                          \
+      Bw[(S) % (R)] = *(const f32x4*)(W4_UB(T0, (S) + (R)) + (long)chunk * UCH + W4_XN(T0, (S) + (R)) * 256);   \
     } else if (NXT) {                                                                                 \
-      Bw[(S) % 4] = *(const f32x4*)(W4_UB(T0, (S) + 4 - (NTW)) + (long)(chunk + 1) * UCH + W4_XN(T0, (S) + 4 - (NTW)) * 256); \
+      Bw[(S) % (R)] = *(const f32x4*)(W4_UB(T0, (S) % (R)) + (long)(chunk + 1) * UCH + W4_XN(T0, (S) % (R)) * 256); \
     }                                                                                                 \
     W4_SB();                                                                                          \
   }
-#define W4_PHASE(NXT, NU, T0, NTW)                                                                    \
+#define W4_PHASE(NXT, NU, T0, NTW, R)                                                                 \
   {                                                                                                   \
     const float* vc = va0 + (chunk & 1) * VSZ;                                                        \
     float* Vn = V + ((chunk + 1) & 1) * VSZ;                                                          \
     const float* rwn = raw + ((chunk + 1) & 1) * RAWSZ;                                               \
     Aa = *(const f32x4*)(vc + W4_XN(T0, 0) * 256);                                                    \
-    W4_STEP(0, Aa, Ab, NXT, NU, T0, NTW) W4_STEP(1, Ab, Aa, NXT, NU, T0, NTW) W4_STEP(2, Aa, Ab, NXT, NU, T0, NTW)     \
-    W4_STEP(3, Ab, Aa, NXT, NU, T0, NTW) W4_STEP(4, Aa, Ab, NXT, NU, T0, NTW) W4_STEP(5, Ab, Aa, NXT, NU, T0, NTW)     \
-    W4_STEP(6, Aa, Ab, NXT, NU, T0, NTW) W4_STEP(7, Ab, Aa, NXT, NU, T0, NTW) W4_STEP(8, Aa, Ab, NXT, NU, T0, NTW)     \
-    W4_STEP(9, Ab, Aa, NXT, NU, T0, NTW) W4_STEP(10, Aa, Ab, NXT, NU, T0, NTW) W4_STEP(11, Ab, Aa, NXT, NU, T0, NTW)   \
+    W4_STEP(0, Aa, Ab, NXT, NU, T0, NTW, R) W4_STEP(1, Ab, Aa, NXT, NU, T0, NTW, R) W4_STEP(2, Aa, Ab, NXT, NU, T0, NTW, R)     \
+    W4_STEP(3, Ab, Aa, NXT, NU, T0, NTW, R) W4_STEP(4, Aa, Ab, NXT, NU, T0, NTW, R) W4_STEP(5, Ab, Aa, NXT, NU, T0, NTW, R)     \
+    W4_STEP(6, Aa, Ab, NXT, NU, T0, NTW, R) W4_STEP(7, Ab, Aa, NXT, NU, T0, NTW, R) W4_STEP(8, Aa, Ab, NXT, NU, T0, NTW, R)     \
+    W4_STEP(9, Ab, Aa, NXT, NU, T0, NTW, R) W4_STEP(10, Aa, Ab, NXT, NU, T0, NTW, R) W4_STEP(11, Ab, Aa, NXT, NU, T0, NTW, R)   \
+    W4_STEP(12, Aa, Ab, NXT, NU, T0, NTW, R)                                                          \
   }
   // End of a phase: the raw patch of chunk+2 (LDS-DMA issued at the start of the phase) must have landed; the NTW weight
   // loads issued after it stay in flight.  Bare barrier (not __syncthreads(), whose fence would drain them); lgkmcnt(0)
   // retires the transform's LDS stores.
-#define W4_MAIN(NU, T0, NTW)                                                                          \
+#define W4_MAIN(NU, T0, NTW, R)                                                                        \
   {                                                                                                   \
     int chunk = 0;                                                                                    \
     for (; chunk < NCH - 1; chunk++) {                                                                \
-      W4_PHASE(true, NU, T0, NTW)                                                                     \
+      W4_PHASE(true, NU, T0, NTW, R)                                                                   \
       W4_DIAG_T0                                                                                      \
-      if ((NTW) == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");         \
-      else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");                   \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NTW) : "memory");                \
       W4_DIAG_T1                                                                                      \
       if (chunk + 3 < NCH) stage_raw(chunk + 3, raw + ((chunk + 1) & 1) * RAWSZ);      \
     }                                                                                                 \
-    W4_PHASE(false, NU, T0, NTW)                                                                      \
+    W4_PHASE(false, NU, T0, NTW, R)                                                                    \
   }
 
   stage_raw(0, raw);
   if (NCH > 1) stage_raw(1, raw + RAWSZ);
 #pragma unroll
-  for (int sl = 0; sl < 4; sl++) {
+  for (int sl = 0; sl < 5; sl++) {
     const int t = t0w + sl;
-    Bw[sl] = *(const f32x4*)((t >= 36 ? ubg1 : ubg0) + (t % 36) * 256);
+    if (sl < ringw) Bw[sl] = *(const f32x4*)((t >= 36 ? ubg1 : ubg0) + (t % 36) * 256);
   }
   // builtin (not asm): the compiler's waitcnt bookkeeping then sees the prologue loads retired and derives the counted
   // waits of the loop from the loop's own issue order.  0x0F70 = vmcnt(0), expcnt/lgkmcnt untouched.
@@ -282,14 +314,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
   if (NCH > 2) stage_raw(2, raw);
 
   switch (wave) {
-    case 0: W4_MAIN(0, 0, 8) break;
-    case 1: W4_MAIN(1, 8, 8) break;
-    case 2: W4_MAIN(2, 16, 8) break;
-    case 3: W4_MAIN(3, 24, 8) break;
-    case 4: W4_MAIN(4, 32, 8) break;
-    case 5: W4_MAIN(5, 40, 8) break;
-    case 6: W4_MAIN(6, 48, 12) break;
-    default: W4_MAIN(6, 60, 12) break;
+    case 0: W4_MAIN(0, 0, W4_N0, W4_RING(W4_N0)) break;
+    case 1: W4_MAIN(1, W4_T1, W4_N1, W4_RING(W4_N1)) break;
+    case 2: W4_MAIN(2, W4_T2, W4_N2, W4_RING(W4_N2)) break;
+    case 3: W4_MAIN(3, W4_T3, W4_N3, W4_RING(W4_N3)) break;
+    case 4: W4_MAIN(4, W4_T4, W4_N4, W4_RING(W4_N4)) break;
+    case 5: W4_MAIN(5, W4_T5, W4_N5, W4_RING(W4_N5)) break;
+    case 6: W4_MAIN(6, W4_T6, W4_N6, W4_RING(W4_N6)) break;
+    default: W4_MAIN(6, W4_T7, W4_N7, W4_RING(W4_N7)) break;
   }
 #undef W4_MAIN
 #undef W4_PHASE
@@ -313,14 +345,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
       _Pragma("unroll") for (int rr = 0; rr < 4; rr++) d[rr * 36 * 64] = acc[sq][4 * rnd + rr];        \
     }
     switch (wave) {
-      case 0: W4_EPI_WRITE(0, 8) break;
-      case 1: W4_EPI_WRITE(8, 8) break;
-      case 2: W4_EPI_WRITE(16, 8) break;
-      case 3: W4_EPI_WRITE(24, 8) break;
-      case 4: W4_EPI_WRITE(32, 8) break;
-      case 5: W4_EPI_WRITE(40, 8) break;
-      case 6: W4_EPI_WRITE(48, 12) break;
-      default: W4_EPI_WRITE(60, 12) break;
+      case 0: W4_EPI_WRITE(0, W4_N0) break;
+      case 1: W4_EPI_WRITE(W4_T1, W4_N1) break;
+      case 2: W4_EPI_WRITE(W4_T2, W4_N2) break;
+      case 3: W4_EPI_WRITE(W4_T3, W4_N3) break;
+      case 4: W4_EPI_WRITE(W4_T4, W4_N4) break;
+      case 5: W4_EPI_WRITE(W4_T5, W4_N5) break;
+      case 6: W4_EPI_WRITE(W4_T6, W4_N6) break;
+      default: W4_EPI_WRITE(W4_T7, W4_N7) break;
     }
 #undef W4_EPI_WRITE
     __syncthreads();
@@ -364,24 +396,38 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
       if (tile < NTILE) {
 #endif
         const int ty = tile / TX, tx = tile % TX;
-        const int R = R0 + 4 * ty;
-        const int n = R / Hp, yy = R % Hp, xx = x0 + 4 * tx;
+        // stacked padded row R0 + 4 ty -> (image, row): at most G boundaries inside a patch, no runtime division
+        int n = n0img, yy = y0 + 4 * ty;
+        while (yy >= Hp) { yy -= Hp; n++; }
+        const int xx = x0 + 4 * tx;
         if (n < Btot) {
+          // one 64-bit base per lane and round; the 16 (4 pooled) store offsets are wave-uniform
           if (POOL) {
+            float* yb = y + (((long)n * Ho + (yy >> 1)) * Wo + (xx >> 1)) * Cout + co;
+            const int rs = Wo * Cout;
+            const bool inside = (yy >> 1) + 1 < Ho && (xx >> 1) + 1 < Wo;        // false only on the padded rim (14x14 as 16x16)
 #pragma unroll
             for (int a = 0; a < 2; a++)
 #pragma unroll
               for (int b = 0; b < 2; b++) {
                 const float v = fmaxf(fmaxf(Y[2 * a][2 * b], Y[2 * a][2 * b + 1]), fmaxf(Y[2 * a + 1][2 * b], Y[2 * a + 1][2 * b + 1]));
-                const int py = (yy >> 1) + a, px = (xx >> 1) + b;
-                if (py < Ho && px < Wo) y[(((long)n * Ho + py) * Wo + px) * Cout + co] = v;
+                if (inside || ((yy >> 1) + a < Ho && (xx >> 1) + b < Wo)) yb[a * rs + b * Cout] = v;
               }
           } else {
+            float* yb = y + (((long)n * H + yy) * W + xx) * Cout + co;
+            const int rs = W * Cout;
+            if (yy + 3 < H && xx + 3 < W) {
 #pragma unroll
-            for (int a = 0; a < 4; a++)
+              for (int a = 0; a < 4; a++)
 #pragma unroll
-              for (int b = 0; b < 4; b++)
-                if (yy + a < H && xx + b < W) y[(((long)n * H + yy + a) * W + xx + b) * Cout + co] = Y[a][b];
+                for (int b = 0; b < 4; b++) yb[a * rs + b * Cout] = Y[a][b];
+            } else {
+#pragma unroll
+              for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                  if (yy + a < H && xx + b < W) yb[a * rs + b * Cout] = Y[a][b];
+            }
           }
         }
       }

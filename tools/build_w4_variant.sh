@@ -6,5 +6,6 @@ D=$(dirname $0)/../lct_vqa_amd/csrc
 C=$(dirname $0)/../lct_vqa_amd/_C
 T=$(mktemp -d)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -Wno-unused-value -Wno-inline-asm -I$D "$@" -c $D/conv3x3_wino4.hip -o $T/conv3x3_wino4.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $T/conv3x3_wino4.o $C/api.o $C/conv3x3.o $C/conv3x3_bwd.o $C/conv3x3_wino.o $C/darts.o $C/gemm.o $C/ops.o
+OBJS=$(ls $C/*.o | grep -v conv3x3_wino4.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $T/conv3x3_wino4.o $OBJS
 rm -rf "$T"
