@@ -98,6 +98,15 @@ int lctvqa_gemm_f32_ex(const float* A, long a_ms, long a_ks, const float* B, lon
                        int M, int N, int K, const float* bias, const float* addend, long ld_add, int act,
                        const uint8_t* mask, long ld_mask, float mask_scale, float* workspace, long workspace_bytes,
                        int relu_ab, void* stream);
+/* Both entry points above run on the LDS-DMA kernel (256 x 128 x 16 tiles, operands HBM -> LDS by global_load_lds) whenever both
+ * operands are 16-byte aligned and K- or row-contiguous with K % 4 == 0 and no operand ReLU is asked for; everything else takes the
+ * general VGPR-staged kernel.  lctvqa_gemm_force_general(1) routes every product through the general kernel (A/B, tests);
+ * returns the previous setting. */
+int lctvqa_gemm_force_general(int on);
+/* C[b] = act(A[b] . B[b]^T + bias) for b < batch: K-contiguous operands, element strides sA, sB, sC between batch members (the
+ * per-(xi,nu) products of a Winograd convolution whose transforms run as separate kernels; nn.Linear over a stack of inputs) */
+int lctvqa_gemm_f32_batched_nt(const float* A, long lda, long sA, const float* B, long ldb, long sB, float* C, long ldc, long sC,
+                               int batch, int M, int N, int K, const float* bias, int act, void* stream);
 /* fusion head, first half (models.py:96-100) in ONE GEMM launch: the pointwise mul+tanh+dropout(mask1) is applied to the A
  * operand while it is staged: h1 = mask2*scale2*tanh([mask1*scale1*tanh(img.qst)] . W1^T + b1); masks dense uint8 or NULL */
 int lctvqa_fusion_fc1(const float* img, const float* qst, const uint8_t* mask1, float scale1, const float* w1, const float* b1,

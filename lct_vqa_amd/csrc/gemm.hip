@@ -98,6 +98,58 @@ __device__ __forceinline__ float apply_epi(float v, int m, int n, const GemmEpi&
   return v;
 }
 
+// Epilogue of one wave: MT x NT accumulator tiles whose first output is (mw, nw).  Interior tiles with the common epilogues
+// (bias, residual addend, ReLU) take a path without per-element bounds, branches or index multiplies.
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_store_tiles(const f32x16 (&acc)[MT][NT], float* __restrict__ out, long ldc, int mw, int nw,
+                                                 int mlim, int nlim, int M, int N, const GemmEpi& epi, int direct, int j, int h) {
+  const bool fast = (mlim <= M) && (nlim <= N) && (!direct || (epi.mask == nullptr && epi.act != 2));
+  if (fast) {
+    const bool relu = direct && epi.act == 1;
+#pragma unroll
+    for (int b = 0; b < NT; b++) {
+      const int n = nw + b * 32 + j;
+      const float bv = (direct && epi.bias) ? epi.bias[n] : 0.f;
+#pragma unroll
+      for (int a = 0; a < MT; a++) {
+        const long m = mw + a * 32 + 4 * h;
+        float* po = out + m * ldc + n;
+        if (direct && epi.addend) {
+          const float* pa = epi.addend + m * epi.ld_add + n;
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            float v = acc[a][b][r] + bv + pa[ro * epi.ld_add];
+            po[ro * ldc] = relu ? fmaxf(v, 0.f) : v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            float v = acc[a][b][r] + bv;
+            po[ro * ldc] = relu ? fmaxf(v, 0.f) : v;
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < MT; a++)
+#pragma unroll
+    for (int b = 0; b < NT; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = mw + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int n = nw + b * 32 + j;
+        if (m < M && n < N) {
+          float v = acc[a][b][r];
+          if (direct) v = apply_epi(v, m, n, epi);
+          out[(long)m * ldc + n] = v;
+        }
+      }
+}
+
 template <int AMODE, int BMODE>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, long a_ms, long a_ks,
                                                           const float* __restrict__ B, long b_ns, long b_ks,
@@ -181,20 +233,145 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
   }
 
   float* out = direct ? C : C + (long)blockIdx.z * M * ldc;   // split-K slab [z][M][ldc]
+  gemm_store_tiles<2, 2>(acc, out, ldc, m0 + wm * 64, n0 + wn * 64, m0 + 128, n0 + 128, M, N, epi, direct, j, h);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product for operands the LDS-DMA can stage directly (16-byte aligned, K- or row-contiguous, no fused A prologue):
+// 256 x (64*NTW) x 16 tile, 4 waves (2 x 2), wave = 4 x NTW v_mfma_f32_32x32x2_f32 tiles (128 x 32*NTW outputs), both operand
+// tiles HBM -> LDS by global_load_lds (16 B per lane, no VGPR hop, no address VALU in the loop), double buffered with one
+// barrier per K step of 16 while the next step's 6 DMA instructions per wave are in flight.
+//   K-contiguous operand  X(r,k) = X[r*ld + k]: LDS rows of 64 B, the 16-B chunk XOR-swizzled by (row>>2)&3 exactly as in the
+//     general kernel (conflict-free ds_read_b128, one per four MFMAs; lane half h of half-step kk reads quad 2kk+h).  The DMA
+//     writes LDS linearly, so the swizzle is applied to the SOURCE: lane = (row, slot c) fetches quad c ^ ((row>>2)&3); the four
+//     lanes of a row still cover its 64 contiguous bytes;
+//   row-contiguous operand X(r,k) = X[k*ld + r] (the transposed operand of dX = dY.W and dW = dY^T.X): LDS [k][row], a fragment
+//     element is one conflict-free ds_read_b32 per MFMA; k = 8kk + 4h + e keeps the pairing of the two operand kinds equal.
+// blockIdx.y = batch (operand strides sA, sB, sC; the transformed-domain products of a Winograd convolution), blockIdx.z = K split.
+__device__ __attribute__((aligned(64))) float g_zero_page_g[64];
+
+template <bool AKM, bool BKM, int NTW>
+__global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
+                                                              long ldb, float* __restrict__ C, long ldc, int M, int N, int K,
+                                                              int kper, GemmEpi epi, int direct, long sA, long sB, long sC) {
+  constexpr int BM = 256, BN = 64 * NTW;
+  constexpr int ASZ = BM * 16, BSZ = BN * 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* abuf = smem;                 // [2][ASZ]
+  float* bbuf = smem + 2 * ASZ;       // [2][BSZ]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
+  const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM;
+  // workgroups are dealt to the 8 XCDs round-robin: with at least 8 row blocks the ntn workgroups that read one A row block are
+  // given ids that share an XCD (its L2); fewer row blocks keep the plain order (the other mapping would leave XCDs idle)
+  int tn, tm;
+  if (ntm >= 8) { tn = (blockIdx.x >> 3) % ntn; tm = ((blockIdx.x >> 3) / ntn) * 8 + (blockIdx.x & 7); }
+  else { tn = blockIdx.x % ntn; tm = blockIdx.x / ntn; }
+  if (tm >= ntm) return;
+  const int m0 = tm * BM, n0 = tn * BN;
+  A += (long)blockIdx.y * sA; B += (long)blockIdx.y * sB; C += (long)blockIdx.y * sC;
+  const int kbeg = blockIdx.z * kper;
+  const int kend = min(K, kbeg + kper);
+  const int nk = (kend - kbeg + 15) / 16;
+
+  // ---- staging: per-lane source pointers and wave-uniform LDS destinations.
+  // K-contiguous: a piece = 16 rows x 64 B, lane = (row lane>>2, slot lane&3); wave w stages pieces w, w+4, ... (A: 16, B: 2 NTW*2).
+  // Row-contiguous: A piece = one k row (256 floats), wave w stages k = w, w+4, w+8, w+12; B piece = 256 floats of [k][BN].
+  const int rl = lane >> 2, sq = (lane & 3) ^ ((rl >> 2) & 3);   // K-contiguous: row within the piece, source quad of this lane
+  const float* asrc;
+  if (!AKM) asrc = A + (long)(m0 + 16 * wave + rl) * lda + 4 * sq;
+  else asrc = A + (m0 + 4 * lane);
+  const bool a_in = AKM ? (m0 + 4 * lane < M) : true;
+  const float* bsrc;
+  int bk0 = 0;                                                   // row-contiguous B: first k (within the step) of this lane
+  if (!BKM) bsrc = B + (long)(n0 + 16 * wave + rl) * ldb + 4 * sq;
+  else {
+    bsrc = B + n0 + (NTW == 2 ? 4 * (lane & 31) : 4 * (lane & 15));
+    bk0 = NTW == 2 ? 2 * wave + (lane >> 5) : 4 * wave + (lane >> 4);
+  }
+  const bool b_in = BKM ? (n0 + (NTW == 2 ? 4 * (lane & 31) : 4 * (lane & 15)) < N) : true;
+  auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
+    const int k0 = kbeg + kt * 16;
+    float* ad = abuf + buf * ASZ;
+    float* bd = bbuf + buf * BSZ;
 #pragma unroll
-  for (int a = 0; a < 2; a++)
+    for (int t = 0; t < 4; t++) {
+      if (!AKM) {
+        const bool ok = (m0 + 16 * (wave + 4 * t) + rl < M) && (k0 + 4 * sq < kend);
+        glds16_opaque(ok ? asrc + (long)(64 * t) * lda + k0 : g_zero_page_g, ad + (wave + 4 * t) * 256);
+      } else {
+        const int k = k0 + wave + 4 * t;
+        glds16_opaque((a_in && k < kend) ? asrc + (long)k * lda : g_zero_page_g, ad + (wave + 4 * t) * BM);
+      }
+    }
 #pragma unroll
-    for (int b = 0; b < 2; b++)
+    for (int t = 0; t < NTW; t++) {
+      if (!BKM) {
+        const bool ok = (n0 + 16 * (wave + 4 * t) + rl < N) && (k0 + 4 * sq < kend);
+        glds16_opaque(ok ? bsrc + (long)(64 * t) * ldb + k0 : g_zero_page_g, bd + (wave + 4 * t) * 256);
+      } else {
+        const int k = k0 + bk0 + 8 * t;
+        glds16_opaque((b_in && k < kend) ? bsrc + (long)k * ldb : g_zero_page_g,
+                      bd + (NTW == 2 ? (2 * wave + 8 * t) * BN : 4 * wave * BN));
+      }
+    }
+  };
+  // fragment offsets (floats) of half-step kk = 0, 1 for the K-contiguous layout: row j of a 32-row tile, quad 2kk+h swizzled
+  const int swz = (j >> 2) & 3;
+  const int fo0 = j * 16 + (((0 + h) ^ swz) << 2), fo1 = j * 16 + (((2 + h) ^ swz) << 2);
+
+  f32x16 acc[4][NTW];
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int n = n0 + wn * 64 + b * 32 + j;
-        if (m < M && n < N) {
-          float v = acc[a][b][r];
-          if (direct) v = apply_epi(v, m, n, epi);
-          out[(long)m * ldc + n] = v;
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < NTW; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  if (nk > 0) stage(0, 0);
+  for (int kt = 0; kt < nk; kt++) {
+    // step kt has landed (this wave's pieces: vmcnt(0); the others': the barrier), and nobody still reads the other buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    const float* la = abuf + (kt & 1) * ASZ;
+    const float* lb = bbuf + (kt & 1) * BSZ;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      float af[4][4], bf[NTW][4];
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        if (!AKM) {
+          const f32x4 v = *(const f32x4*)(la + (wm * 128 + a * 32) * 16 + (kk ? fo1 : fo0));
+          af[a][0] = v[0]; af[a][1] = v[1]; af[a][2] = v[2]; af[a][3] = v[3];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) af[a][e] = la[(8 * kk + 4 * h + e) * BM + wm * 128 + a * 32 + j];
         }
       }
+#pragma unroll
+      for (int b = 0; b < NTW; b++) {
+        if (!BKM) {
+          const f32x4 v = *(const f32x4*)(lb + (wn * 32 * NTW + b * 32) * 16 + (kk ? fo1 : fo0));
+          bf[b][0] = v[0]; bf[b][1] = v[1]; bf[b][2] = v[2]; bf[b][3] = v[3];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) bf[b][e] = lb[(8 * kk + 4 * h + e) * BN + wn * 32 * NTW + b * 32 + j];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < NTW; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][e], bf[b][e], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  float* out = direct ? C : C + (long)blockIdx.z * M * ldc;   // split-K slab [z][M][ldc]
+  gemm_store_tiles<4, NTW>(acc, out, ldc, m0 + wm * 128, n0 + wn * 32 * NTW, m0 + BM, n0 + BN, M, N, epi, direct, j, h);
 }
 
 __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ ws, int splits, float* __restrict__ C, long ldc,
@@ -240,6 +417,7 @@ static int pick_mode(const float* P, long rs, long ks, int K) {
   return LD_KSCALAR;   // fully general strides
 }
 
+static int g_gemm_force_general = 0;                  // tests / A-B: route everything through the general kernel
 static thread_local const float* g_fuse_a2 = nullptr;
 static thread_local const uint8_t* g_fuse_amask = nullptr;
 static thread_local float g_fuse_ascale = 1.f;
@@ -253,9 +431,7 @@ static gemm_kern_t gemm_table[3][3] = {
 
 extern "C" {
 
-// workspace bytes needed for the split-K slabs of this problem (0 when no split is used)
-long lctvqa_gemm_workspace_bytes(int M, int N, int K) {
-  int tiles = cdiv(M, 128) * cdiv(N, 128);
+static int plan_splits(int tiles, int K) {
   int splits = 1;
   if (tiles < 192) {
     splits = 512 / tiles;
@@ -265,7 +441,61 @@ long lctvqa_gemm_workspace_bytes(int M, int N, int K) {
     if (splits > cap) splits = cap;
     if (splits < 1) splits = 1;
   }
+  return splits;
+}
+static int dma_bn(int N) { return N > 64 ? 128 : 64; }
+
+// workspace bytes needed for the split-K slabs of this problem (0 when no split is used): enough for either kernel
+long lctvqa_gemm_workspace_bytes(int M, int N, int K) {
+  int s1 = plan_splits(cdiv(M, 128) * cdiv(N, 128), K);
+  int s2 = plan_splits(cdiv(M, 256) * cdiv(N, dma_bn(N)), K);
+  int splits = s1 > s2 ? s1 : s2;
   return splits > 1 ? (long)splits * M * N * (long)sizeof(float) : 0;
+}
+
+typedef void (*gemm_dma_kern_t)(const float*, long, const float*, long, float*, long, int, int, int, int, GemmEpi, int, long, long,
+                                long);
+static gemm_dma_kern_t gemm_dma_table[2][2][2] = {
+    {{gemm_f32_dma_kernel<false, false, 1>, gemm_f32_dma_kernel<false, false, 2>},
+     {gemm_f32_dma_kernel<false, true, 1>, gemm_f32_dma_kernel<false, true, 2>}},
+    {{gemm_f32_dma_kernel<true, false, 1>, gemm_f32_dma_kernel<true, false, 2>},
+     {gemm_f32_dma_kernel<true, true, 1>, gemm_f32_dma_kernel<true, true, 2>}}};
+
+// operand layout the LDS-DMA kernel can stage: 0 = K-contiguous, 1 = row-contiguous, -1 = neither
+static int dma_layout(const float* P, long rs, long ks, int rows, int K) {
+  if (((uintptr_t)P & 15) != 0 || K % 4 != 0) return -1;
+  if (ks == 1 && rs % 4 == 0) return 0;
+  if (rs == 1 && ks % 4 == 0 && rows % 4 == 0) return 1;
+  return -1;
+}
+
+static int launch_gemm_dma(const float* A, long lda, int akm, const float* B, long ldb, int bkm, float* C, long ldc, int M, int N,
+                           int K, const GemmEpi& epi, float* workspace, long workspace_bytes, int batch, long sA, long sB, long sC,
+                           hipStream_t st) {
+  const int BN = dma_bn(N);
+  const int ntm = cdiv(M, 256), ntn = cdiv(N, BN);
+  int splits = batch > 1 ? 1 : plan_splits(ntm * ntn, K);
+  if (splits > 1) {
+    long cap = workspace ? workspace_bytes / ((long)M * N * (long)sizeof(float)) : 0;
+    if (cap < splits) splits = cap < 1 ? 1 : (int)cap;           // degrade, still correct
+  }
+  int kper = ((cdiv(K, splits) + 15) / 16) * 16;
+  splits = cdiv(K, kper);
+  gemm_dma_kern_t k = gemm_dma_table[akm][bkm][BN == 128];
+  const size_t lds = (size_t)(2 * 256 * 16 + 2 * BN * 16) * sizeof(float);
+  dim3 grid(ntm >= 8 ? ((ntm + 7) / 8) * 8 * ntn : ntm * ntn, batch, splits);
+  if (splits == 1) {
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K, kper, epi, 1, sA, sB, sC);
+    return lct_check_launch("gemm_f32_dma");
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, workspace, (long)N, M, N, K, kper, epi, 0, 0L, 0L, 0L);
+  int rc = lct_check_launch("gemm_f32_dma(splitk)");
+  if (rc) return rc;
+  long total = (long)M * N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, splits, C, ldc, M, N, epi);
+  return lct_check_launch("gemm_splitk_reduce");
 }
 
 // relu_ab: bit 0 = apply ReLU to A elements as they are loaded, bit 1 = to B elements (PC-DARTS ReLU->Conv1x1
@@ -283,10 +513,15 @@ int lctvqa_gemm_f32_ex(const float* A, long a_ms, long a_ks, const float* B, lon
     relu_ab &= 3;
     LCT_REQUIRE(a_ks == 1, "fused fusion-head prologue needs a K-contiguous A operand");
   }
+  if (!epi.a2 && relu_ab == 0 && !g_gemm_force_general) {
+    const int la = dma_layout(A, a_ms, a_ks, M, K), lb = dma_layout(B, b_ns, b_ks, N, K);
+    if (la >= 0 && lb >= 0)
+      return launch_gemm_dma(A, la ? a_ks : a_ms, la, B, lb ? b_ks : b_ns, lb, C, ldc, M, N, K, epi, workspace, workspace_bytes, 1, 0, 0,
+                             0, st);
+  }
   int tiles = cdiv(M, 128) * cdiv(N, 128);
-  long need = lctvqa_gemm_workspace_bytes(M, N, K);
-  int splits = need ? (int)(need / ((long)M * N * sizeof(float))) : 1;
-  if (splits > 1 && (workspace == nullptr || workspace_bytes < need)) splits = 1;   // degrade, still correct
+  int splits = plan_splits(tiles, K);
+  if (splits > 1 && (workspace == nullptr || workspace_bytes < (long)splits * M * N * (long)sizeof(float))) splits = 1;   // degrade, still correct
   int kper = ((cdiv(K, splits) + 15) / 16) * 16;
   splits = cdiv(K, kper);
   int am = pick_mode(A, a_ms, a_ks, K), bm = pick_mode(B, b_ns, b_ks, K);
@@ -320,6 +555,20 @@ int lctvqa_gemm_f32(const float* A, long a_ms, long a_ks, const float* B, long b
                     void* stream) {
   return lctvqa_gemm_f32_ex(A, a_ms, a_ks, B, b_ns, b_ks, C, ldc, M, N, K, bias, addend, ld_add, act, mask, ld_mask, mask_scale,
                             workspace, workspace_bytes, 0, stream);
+}
+
+// 1: every product runs on the general (VGPR-staged) kernel, 0: the LDS-DMA kernel where the operand layouts allow (default)
+int lctvqa_gemm_force_general(int on) { int old = g_gemm_force_general; g_gemm_force_general = on ? 1 : 0; return old; }
+
+// C[b] = epi(A[b] . B[b]^T) for b < batch: K-contiguous operands (A[b]: M x K, row stride lda; B[b]: N x K, row stride ldb), 16-byte
+// aligned, K % 4 == 0, element strides sA, sB, sC between the batch members.
+int lctvqa_gemm_f32_batched_nt(const float* A, long lda, long sA, const float* B, long ldb, long sB, float* C, long ldc, long sC,
+                               int batch, int M, int N, int K, const float* bias, int act, void* stream) {
+  LCT_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "gemm_f32_batched_nt: bad shape %d %d %d x%d", M, N, K, batch);
+  LCT_REQUIRE(dma_layout(A, lda, 1, M, K) == 0 && dma_layout(B, ldb, 1, N, K) == 0 && sA % 4 == 0 && sB % 4 == 0,
+              "gemm_f32_batched_nt: operands must be 16-byte aligned and K-contiguous with K %% 4 == 0");
+  GemmEpi epi{nullptr, nullptr, 1.f, bias, nullptr, 0, nullptr, 0, 1.f, act};
+  return launch_gemm_dma(A, lda, 0, B, ldb, 0, C, ldc, M, N, K, epi, nullptr, 0, batch, sA, sB, sC, (hipStream_t)stream);
 }
 
 long lctvqa_colsum_scratch_elems(int M, int N) { return (long)colsum_splits(M, N) * N; }

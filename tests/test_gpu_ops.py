@@ -180,6 +180,46 @@ def test_gemm_linear_fwd_bwd(ops, M, N, K):
     assert rel_err(ops.colsum(dyd), dy.sum(0)) < 2e-5
 
 
+@pytest.mark.parametrize('M,N,K', [(516, 200, 72), (1000, 64, 256), (260, 132, 20), (8, 8, 8), (3136, 256, 64), (64, 1024, 50176)])
+def test_gemm_dma_kernel_all_layouts(ops, hip_lib, M, N, K):
+    """The LDS-DMA GEMM (K- and row-contiguous operands, ragged tiles, K tails, split-K) against fp64 and against the
+    general kernel on the same operands."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    Bm = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    add = torch.randn(M, N, generator=g).to(DEV)
+    mask = (torch.rand(M, N, generator=g) > 0.3).to(DEV, torch.uint8)
+    ref = A.double() @ Bm.double().t()
+    At, Bt = A.t().contiguous(), Bm.t().contiguous()           # row-contiguous (k-major) copies: X(r,k) = Xt[k][r]
+    for (a, a_ms, a_ks) in ((A, K, 1), (At, 1, M)):
+        for (b, b_ns, b_ks) in ((Bm, K, 1), (Bt, 1, N)):
+            outs = []
+            for force in (0, 1):
+                old = hip_lib.raw('gemm_force_general')(force)
+                try:
+                    outs.append(ops.gemm(a, a_ms, a_ks, b, b_ns, b_ks, M, N, K))
+                finally:
+                    hip_lib.raw('gemm_force_general')(old)
+            for o in outs:
+                assert rel_err(o, ref) < 2e-5, (a_ks, b_ks)
+    full = ops.gemm(A, K, 1, Bm, K, 1, M, N, K, bias, add, ops.ACT_RELU, mask, 1.5)
+    want = torch.relu(ref + bias.double() + add.double()) * mask.double() * 1.5
+    assert rel_err(full, want) < 2e-5
+
+
+def test_gemm_batched_nt(hip_lib):
+    g = torch.Generator().manual_seed(11)
+    nb, M, N, K = 5, 300, 96, 40
+    A = torch.randn(nb, M, K, generator=g).to(DEV)
+    Bm = torch.randn(nb, N, K, generator=g).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    C = torch.full((nb, M, N), float('nan'), device=DEV)
+    hip_lib('gemm_f32_batched_nt', A, K, M * K, Bm, K, N * K, C, N, M * N, nb, M, N, K, bias, 1)
+    want = torch.relu(torch.bmm(A.double(), Bm.double().transpose(1, 2)) + bias.double())
+    assert rel_err(C, want) < 2e-5
+
+
 def test_gemm_epilogue_and_autograd(ops):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(33, 70, generator=g)
