@@ -299,9 +299,12 @@ def main():
         # LCT stage 1 (EF model) + stage 2 (pseudo QA from EF.generate, W trained on real + pseudo tests)
         from lct_vqa_amd.basic_vqa import models_lct
         torch.manual_seed(11)
-        ef = models_lct.VqaModel(pretrained=True, **DIMS).to(dev).train()
+        # --train-encoder: the reference's --no_pretrain_enc run (config.py:71-72,93; models_lct.py:62-63): the examiner's VGG19 is
+        # trained, so every step adds its full backward (dgrad + weight gradients) and generate sees the updated trunk
+        ef = models_lct.VqaModel(pretrained=not args.train_encoder, **DIMS).to(dev).train()
         ef.qst_encoder.max_length = 14
-        ef.img_encoder.model.cache_packed_weights = True        # pretrained=True: frozen trunk (models_lct.py:62-63 under no_grad)
+        if not args.train_encoder:
+            ef.img_encoder.model.cache_packed_weights = True    # pretrained=True: frozen trunk (models_lct.py:62-63 under no_grad)
         ef_opt = FusedAdam(ef.trainable_parameters(), lr=config.LEARNING_RATE, flatten=True)
         ef_red = parallel.FlatGradReducer(ef_opt.flat['params'], ef_opt.flat_grad, scale_fn=parallel.hip_scale) if world > 1 else None
         w_step = step
@@ -314,7 +317,7 @@ def main():
             if convs is not None:
                 conv, conv_w = convs
             else:
-                conv, conv_w = (ef.img_encoder.conv_features(img) if args.lct_share_trunk else None), None
+                conv, conv_w = (ef.img_encoder.conv_features(img) if args.lct_share_trunk and not args.train_encoder else None), None
             l1 = ef._loss(img, qst, lab, conv)
             l1.backward()
             if ef_red is not None:
@@ -432,7 +435,7 @@ def main():
             st.synchronize()
         barrier()
         dt = time.perf_counter() - t0
-    elif args.workload == 'lct' and args.lct_share_trunk and not args.no_pipeline:
+    elif args.workload == 'lct' and args.lct_share_trunk and not args.no_pipeline and not args.train_encoder:
         # Both trunks of the LCT step are frozen (examiner: pretrained, W: by construction), so their convolutional parts for
         # batch i+1 run on a second HIP stream while stage 1 / generate / stage 2 of batch i run on the main stream -- the
         # schedule of the W workload above.  Every timed step still contains both trunk passes and all the head work.
@@ -552,7 +555,7 @@ def main():
     out = {
         'metric': ('image-question pairs/sec (train step) at 224x224, seq=14, 3129-way' if args.workload == 'w' else
                    ('image-question pairs/sec (ResNet-152+GRU train step, %s trunk) at 224x224, seq=14, 3129-way' % ('trainable' if args.train_encoder else 'frozen')) if args.workload == 'resnet_gru' else
-                   'image-question pairs/sec (LCT stage1+stage2 step: EF + generate + W soft loss) at 224x224, seq=14, 3129-way')
+                   'image-question pairs/sec (LCT stage1+stage2 step: EF + generate + W soft loss%s) at 224x224, seq=14, 3129-way' % (', examiner trunk TRAINED' if args.train_encoder else ''))
                   + (' [bf16 frozen trunk, fp32 accumulate, fp32 heads: NOT the headline fp32 metric]' if args.dtype == 'bf16' else ''),
         'value': round(value, 2),
         'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
@@ -565,10 +568,10 @@ def main():
                                 + ' + GRU + fusion head, fp32 train step (fwd+CE+bwd+clip+Adam), batch %d per GPU, 224x224x3, 14 tokens, 3129 answers, '
                                   "QV=17858: BASELINE configs[2]'s model shape on one GPU; the reference has no ResNet / GRU" % B)
                                if args.workload == 'resnet_gru' else
-                               ('basic_vqa LCT stage-1 + stage-2 step fp32 (experiment.py:216-268): examiner (models_lct, frozen '
-                                'pretrained VGG19) fwd+loss+bwd+clip+Adam, examiner.generate (14 tokens), W soft-loss '
+                               ('basic_vqa LCT stage-1 + stage-2 step fp32 (experiment.py:216-268): examiner (models_lct, %s'
+                                ') fwd+loss+bwd+clip+Adam, examiner.generate (14 tokens), W soft-loss '
                                 'fwd+bwd+clip+Adam; batch %d per GPU, 224x224x3, QV=17858, A=3129; frozen-trunk conv features '
-                                'evaluated %s' % (B, 'once per model and batch (examiner: shared by stage 1 and generate; W: '
+                                'evaluated %s' % ('VGG19 trained from scratch: --no_pretrain_enc' if args.train_encoder else 'frozen pretrained VGG19', B, 'once per model and batch (examiner: shared by stage 1 and generate; W: '
                                                      'shared by its two forwards)' if args.lct_share_trunk else
                                                   'per call for the examiner, once for W')),
                    'global_batch': world * B, 'seq_len': 14, 'parallelism': f'dp{world}',

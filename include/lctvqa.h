@@ -79,6 +79,13 @@ int lctvqa_adaptive_avgpool7_flatten_bwd(const float* dy, float* dx_nhwc, int B,
 long lctvqa_conv3x3_wgrad_scratch_elems(int B, int H, int W, int Cin, int Cout);
 int lctvqa_conv3x3_wgrad_nhwc(const float* x, const float* dz, float* dw_oihw, float* scratch, int B, int H, int W, int Cin,
                               int Cout, void* stream);
+/* the same gradient in the Winograd domain, F(3x3,4x4): a quarter of the multiply-adds as 36 batched fp32 GEMMs over the tile axis
+ * (models_lct.py:62-63 trainable VGG19 trunk; the ResNet bottleneck's 3x3).  _supported: 1 where it beats the direct kernel (Cin, Cout
+ * >= 128 and one of them >= 256, map at least 3/4 of its 4x4 tile grid, >= 256 tiles); workspace in floats. */
+int lctvqa_conv3x3_wino4_wgrad_supported(int B, int H, int W, int Cin, int Cout);
+long lctvqa_conv3x3_wino4_wgrad_workspace_elems(int B, int H, int W, int Cin, int Cout);
+int lctvqa_conv3x3_wino4_wgrad(const float* x, const float* dz, float* dw_oihw, float* workspace, long workspace_elems, int B, int H,
+                               int W, int Cin, int Cout, void* stream);
 long lctvqa_conv3x3_first_wgrad_scratch_elems(int B, int H, int W, int Cout);
 int lctvqa_conv3x3_first_wgrad(const float* x_nchw, const float* dz_nhwc, float* dw, float* db, float* scratch, int B, int H,
                                int W, int Cout, void* stream);
@@ -103,8 +110,11 @@ int lctvqa_gemm_f32_ex(const float* A, long a_ms, long a_ks, const float* B, lon
  * general VGPR-staged kernel.  lctvqa_gemm_force_general(1) routes every product through the general kernel (A/B, tests);
  * returns the previous setting. */
 int lctvqa_gemm_force_general(int on);
-/* C[b] = act(A[b] . B[b]^T + bias) for b < batch: K-contiguous operands, element strides sA, sB, sC between batch members (the
- * per-(xi,nu) products of a Winograd convolution whose transforms run as separate kernels; nn.Linear over a stack of inputs) */
+/* C[b] = act(A[b] . B[b]^T + bias) for b < batch on the LDS-DMA kernel: operands K-contiguous (X(r,k) = X[r*rs + k]) or row-contiguous
+ * (X(r,k) = X[k*ks + r]), 16-byte aligned, K % 4 == 0; element strides sA, sB, sC between batch members (the per-(xi,nu) products of the
+ * Winograd-domain weight gradient; nn.Linear over a stack of inputs).  _nt: both operands K-contiguous. */
+int lctvqa_gemm_f32_batched(const float* A, long a_ms, long a_ks, long sA, const float* B, long b_ns, long b_ks, long sB, float* C,
+                            long ldc, long sC, int batch, int M, int N, int K, const float* bias, int act, void* stream);
 int lctvqa_gemm_f32_batched_nt(const float* A, long lda, long sA, const float* B, long ldb, long sB, float* C, long ldc, long sC,
                                int batch, int M, int N, int K, const float* bias, int act, void* stream);
 /* fusion head, first half (models.py:96-100) in ONE GEMM launch: the pointwise mul+tanh+dropout(mask1) is applied to the A

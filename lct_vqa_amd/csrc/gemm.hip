@@ -560,15 +560,24 @@ int lctvqa_gemm_f32(const float* A, long a_ms, long a_ks, const float* B, long b
 // 1: every product runs on the general (VGPR-staged) kernel, 0: the LDS-DMA kernel where the operand layouts allow (default)
 int lctvqa_gemm_force_general(int on) { int old = g_gemm_force_general; g_gemm_force_general = on ? 1 : 0; return old; }
 
-// C[b] = epi(A[b] . B[b]^T) for b < batch: K-contiguous operands (A[b]: M x K, row stride lda; B[b]: N x K, row stride ldb), 16-byte
-// aligned, K % 4 == 0, element strides sA, sB, sC between the batch members.
+// C[b] = act(A[b] . B[b]^T + bias) for b < batch, operands in either layout the LDS-DMA kernel stages (K-contiguous: X(r,k) =
+// X[r*rs + k]; row-contiguous: X(r,k) = X[k*ks + r]; 16-byte aligned, K % 4 == 0, rows % 4 == 0 for a row-contiguous operand),
+// element strides sA, sB, sC between the batch members.
+int lctvqa_gemm_f32_batched(const float* A, long a_ms, long a_ks, long sA, const float* B, long b_ns, long b_ks, long sB, float* C,
+                            long ldc, long sC, int batch, int M, int N, int K, const float* bias, int act, void* stream) {
+  LCT_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "gemm_f32_batched: bad shape %d %d %d x%d", M, N, K, batch);
+  const int la = dma_layout(A, a_ms, a_ks, M, K), lb = dma_layout(B, b_ns, b_ks, N, K);
+  LCT_REQUIRE(la >= 0 && lb >= 0 && sA % 4 == 0 && sB % 4 == 0,
+              "gemm_f32_batched: operands must be 16-byte aligned, K- or row-contiguous, K %% 4 == 0 (rows %% 4 == 0 when row-contiguous)");
+  GemmEpi epi{nullptr, nullptr, 1.f, bias, nullptr, 0, nullptr, 0, 1.f, act};
+  return launch_gemm_dma(A, la ? a_ks : a_ms, la, B, lb ? b_ks : b_ns, lb, C, ldc, M, N, K, epi, nullptr, 0, batch, sA, sB, sC,
+                         (hipStream_t)stream);
+}
+
+// the K-contiguous special case (nn.Linear over a stack of inputs)
 int lctvqa_gemm_f32_batched_nt(const float* A, long lda, long sA, const float* B, long ldb, long sB, float* C, long ldc, long sC,
                                int batch, int M, int N, int K, const float* bias, int act, void* stream) {
-  LCT_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "gemm_f32_batched_nt: bad shape %d %d %d x%d", M, N, K, batch);
-  LCT_REQUIRE(dma_layout(A, lda, 1, M, K) == 0 && dma_layout(B, ldb, 1, N, K) == 0 && sA % 4 == 0 && sB % 4 == 0,
-              "gemm_f32_batched_nt: operands must be 16-byte aligned and K-contiguous with K %% 4 == 0");
-  GemmEpi epi{nullptr, nullptr, 1.f, bias, nullptr, 0, nullptr, 0, 1.f, act};
-  return launch_gemm_dma(A, lda, 0, B, ldb, 0, C, ldc, M, N, K, epi, nullptr, 0, batch, sA, sB, sC, (hipStream_t)stream);
+  return lctvqa_gemm_f32_batched(A, lda, 1, sA, B, ldb, 1, sB, C, ldc, sC, batch, M, N, K, bias, act, stream);
 }
 
 long lctvqa_colsum_scratch_elems(int M, int N) { return (long)colsum_splits(M, N) * N; }

@@ -941,6 +941,33 @@ def vgg_trunk_forward(image, convs, fcs, train, conv_feature=None, cache=False, 
     return x
 
 
+_wgrad_algo = os.environ.get('LCTVQA_WGRAD_ALGO', 'winograd')
+
+
+def set_wgrad_algo(name):
+    """'winograd' (default: F(3x3,4x4) in the transformed domain where lctvqa_conv3x3_wino4_wgrad_supported says it pays, the
+    direct MFMA kernel elsewhere) or 'direct'."""
+    global _wgrad_algo
+    if name not in ('winograd', 'direct'):
+        raise ValueError(name)
+    _wgrad_algo = name
+
+
+def conv3x3_weight_grad(x_in, dz, B, H, W, Cin, Cout):
+    """dW [Cout,Cin,3,3] of conv3x3(padding=1) from its NHWC input and the NHWC gradient of its output."""
+    dev = x_in.device
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=dev)
+    if _wgrad_algo == 'winograd' and lib.query('conv3x3_wino4_wgrad_supported', B, H, W, Cin, Cout):
+        n = lib.query('conv3x3_wino4_wgrad_workspace_elems', B, H, W, Cin, Cout)
+        ws = _workspace(4 * n, dev)
+        lib('conv3x3_wino4_wgrad', x_in, dz, dw, ws, ws.numel(), B, H, W, Cin, Cout)
+        return dw
+    ns = lib.query('conv3x3_wgrad_scratch_elems', B, H, W, Cin, Cout)
+    scratch = torch.empty(max(ns, 1), dtype=torch.float32, device=dev)
+    lib('conv3x3_wgrad_nhwc', x_in, dz, dw, scratch, B, H, W, Cin, Cout)
+    return dw
+
+
 class VggFeaturesFn(torch.autograd.Function):
     """Trainable vgg19.features + avgpool + flatten (reference models_lct.py:62-63, pretrained=False).
     Backward per block: fused ReLU/MaxPool backward -> bias grad (column sum) -> wgrad (MFMA, pixels = K)
@@ -996,11 +1023,7 @@ class VggFeaturesFn(torch.autograd.Function):
                 x_in = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
                 lib('maxpool2x2_nhwc', acts[li - 1], x_in, B, Hp, Wp, Cin)
             grads[2 * li + 1] = colsum(dz.reshape(B * H * W, Cout))
-            dw = torch.empty_like(w)
-            ns = lib.query('conv3x3_wgrad_scratch_elems', B, H, W, Cin, Cout)
-            scratch = torch.empty(max(ns, 1), dtype=torch.float32, device=dev)
-            lib('conv3x3_wgrad_nhwc', x_in, dz, dw, scratch, B, H, W, Cin, Cout)
-            grads[2 * li] = dw
+            grads[2 * li] = conv3x3_weight_grad(x_in, dz, B, H, W, Cin, Cout)
             # dgrad: conv3x3(dz) with W'[ci][co] = flip(W[co][ci])
             dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
             wv = _wino_variant(B, H, W, Cout, Cin, 0)

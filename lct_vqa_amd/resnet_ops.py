@@ -81,10 +81,7 @@ class Conv3x3Fn(torch.autograd.Function):
             if small:
                 dw = _wgrad_small_map(x, dz, w)
             else:
-                dw = torch.empty_like(w)
-                ns = lib.query('conv3x3_wgrad_scratch_elems', B, H, W, Cin, Cout)
-                scratch = torch.empty(max(ns, 1), dtype=torch.float32, device=dev)
-                lib('conv3x3_wgrad_nhwc', x, dz, dw, scratch, B, H, W, Cin, Cout)
+                dw = ops.conv3x3_weight_grad(x, dz, B, H, W, Cin, Cout)
         if ctx.needs_input_grad[0]:
             if ops._small_map(B, H, W, Cout, Cin):
                 dx = ops._conv3x3_small_map(dz, _dgrad_weights(w), None, B, H, W, relu=0)

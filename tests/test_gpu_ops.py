@@ -220,6 +220,34 @@ def test_gemm_batched_nt(hip_lib):
     assert rel_err(C, want) < 2e-5
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(16, 14, 14, 256, 256), (6, 28, 28, 128, 256), (2, 56, 56, 256, 128), (17, 15, 13, 128, 256),
+                                            (64, 8, 8, 512, 512)])
+def test_conv3x3_weight_grad_winograd(ops, hip_lib, B, H, W, Cin, Cout):
+    """F(3x3,4x4) weight gradient (transforms + 36 batched GEMMs + finish) against fp64 and against the direct MFMA kernel."""
+    assert hip_lib.query('conv3x3_wino4_wgrad_supported', B, H, W, Cin, Cout)
+    g = torch.Generator().manual_seed(B * H + Cin)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    dz = torch.randn(B, H, W, Cout, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (Cout, Cin, 3, 3), dz.permute(0, 3, 1, 2).double(), padding=1)
+    xd, dzd = x.to(DEV), dz.to(DEV)
+    got = {}
+    for algo in ('winograd', 'direct'):
+        ops.set_wgrad_algo(algo)
+        try:
+            got[algo] = ops.conv3x3_weight_grad(xd, dzd, B, H, W, Cin, Cout)
+        finally:
+            ops.set_wgrad_algo('winograd')
+    assert rel_err(got['direct'], ref) < 2e-5
+    assert rel_err(got['winograd'], ref) < 1e-4                  # the 6x6 transforms cost about one decimal digit (as in the forward pass)
+
+
+def test_conv3x3_weight_grad_winograd_scope(hip_lib):
+    q = lambda *a: hip_lib.query('conv3x3_wino4_wgrad_supported', *a)
+    assert not q(256, 224, 224, 64, 64) and not q(256, 112, 112, 64, 128) and not q(256, 28, 28, 128, 128)   # narrow layers: direct kernel
+    assert q(256, 56, 56, 256, 256) and q(256, 28, 28, 512, 512) and q(256, 14, 14, 512, 512) and q(256, 14, 14, 256, 256)
+    assert not q(1, 6, 6, 512, 512)                                            # too few tiles
+
+
 def test_gemm_epilogue_and_autograd(ops):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(33, 70, generator=g)
