@@ -713,25 +713,19 @@ def clear_pack_cache():
     _pack_cache.clear()
 
 
-_tap_major = {}
-
-
-def _conv3x3_small_map(cur, w, b, B, H, W, relu=1):
+def _conv3x3_small_map(cur, w, b, B, H, W, relu=1, cache=False):
     """conv3x3 + bias + ReLU on a map too small for the tiled kernels (the 7x7 maps of a ResNet's last stage): the map is
     zero-padded into a bordered (H+2) x (W+2) grid on which a tap is a constant ROW SHIFT, so the convolution is nine fp32 MFMA
     GEMMs over all grid rows accumulating into one buffer (border rows compute garbage that is cropped away).  (H+2)(W+2)/(HW)
-    times the FLOPs of the layer (1.65x at 7x7), a few hundred microseconds instead of the scalar fallback kernel."""
+    times the FLOPs of the layer (1.65x at 7x7), a few hundred microseconds instead of the scalar fallback kernel.
+    The tap-major copy of the weights [3][3][Cout][Cin] is re-made on every call unless ``cache`` (frozen trunks only: the same
+    rules as every other packed copy, `_packed_weights`)."""
     dev = cur.device
     Cout, Cin = w.shape[0], w.shape[1]
     Hg, Wg = H + 2, W + 2
     rows, slack = B * Hg * Wg, Wg + 1
-    key = (w.data_ptr(), w._version, tuple(w.shape))
-    wt = _tap_major.get(id(w))
-    if wt is None or wt[0] != key:                             # [3][3][Cout][Cin]: every tap a K-contiguous matrix
-        if len(_tap_major) > 256:
-            _tap_major.clear()
-        wt = _tap_major[id(w)] = (key, w.detach().permute(2, 3, 0, 1).contiguous())
-    wt = wt[1]
+    wt = _packed_weights(w, 'tap_major', 9 * Cout * Cin,
+                         lambda dst: dst.view(3, 3, Cout, Cin).copy_(w.detach().permute(2, 3, 0, 1)), cache).view(3, 3, Cout, Cin)
     grid = torch.zeros((rows + 2 * slack, Cin), dtype=torch.float32, device=dev)     # slack rows: the shifted reads of the first / last rows
     lib('copy_window_nhwc', cur, grid[slack:], B, H, W, Hg, Wg, Cin, 0, 0, 1, 1, H, W, 0)
     acc = torch.empty((rows, Cout), dtype=torch.float32, device=dev)
@@ -766,7 +760,7 @@ def _conv_block(cur, w, b, B, H, W, pool, cache=False, relu=1):
         return out
     mfma = lib.query('conv3x3_uses_mfma', B, H, W, Cin, Cout, pool)
     if not mfma and not pool and H * W <= 256 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 64:
-        return _conv3x3_small_map(cur, w, b, B, H, W, relu)
+        return _conv3x3_small_map(cur, w, b, B, H, W, relu, cache)
     wp = tmp = None
     if mfma:
         wp = _packed_weights(w, 'direct', Cout * Cin * 9, lambda dst: lib('conv3x3_pack_weights', w, dst, Cout, Cin), cache)

@@ -513,6 +513,22 @@ def _torch_trunk(m, x):
     return h
 
 
+def test_small_map_conv_sees_weight_updates_behind_autograd(ops):
+    """The shifted-GEMM convolution of small maps keeps no copy of a trainable weight between calls: the optimizer's kernel and the
+    architects' `p.data.add_` change parameters without touching the version counter (architect_lct.py:194-207)."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cin, Cout = 4, 7, 7, 64, 64
+    x = torch.randn(B, H, W, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    ref = lambda: F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    assert rel_err(ops._conv3x3_small_map(x, w, b, B, H, W, relu=0), ref()) < 2e-5
+    v = w._version
+    w.data.mul_(-1.5)                                             # what FusedAdam / bilevel.virtual_step do
+    assert w._version == v
+    assert rel_err(ops._conv3x3_small_map(x, w, b, B, H, W, relu=0), ref()) < 2e-5
+
+
 def test_frozen_trunk_packed_weight_cache_follows_weight_updates(ops):
     """A trunk that opted in (VGG.cache_packed_weights) packs its conv weights once (ops._packed_weights); an in-place
     update or a load_state_dict of the parameters must still be seen by the next forward."""
