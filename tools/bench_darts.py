@@ -18,6 +18,7 @@ def main():
     ap.add_argument('--iters', type=int, default=3)
     ap.add_argument('--graph', action='store_true', help='also capture the encoder forward+backward into one HIP graph and time replays')
     ap.add_argument('--vqa', action='store_true', help='also time a darts_vqa weight step and an Architect step')
+    ap.add_argument('--lct', action='store_true', help='also time the three stages of a basic_vqa LCT search iteration (ArchitectLct.step, stage 1, stage 2)')
     args = ap.parse_args()
     from lct_vqa_amd.basic_vqa import config
     config.DEVICE = torch.device('cuda')
@@ -66,6 +67,8 @@ def main():
             del out, g
         del net
         darts_vqa_step(args)
+    if args.lct:
+        lct_search_iteration(args)
 
 
 def darts_vqa_step(args):
@@ -104,6 +107,56 @@ def darts_vqa_step(args):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.iters
         print(f'darts_vqa {name} B={B} {S}x{S}: {dt * 1e3:.1f} ms  ({B / dt:.1f} pairs/s)')
+
+
+def lct_search_iteration(args):
+    """BASELINE configs[3] with the search encoder, fp32, one GPU: the three stages of experiment.py:199-257 through the factories --
+    ArchitectLct.step (3-level: unrolled examiner and W, generated tests, finite-difference Hessian-vector products), stage 1
+    (examiner step), stage 2 (generate + W soft-loss step)."""
+    import types
+    from lct_vqa_amd.basic_vqa import architect_factory, config, model_factory
+    from lct_vqa_amd import ops
+    config.DEVICE = torch.device('cuda')
+    config.ARCH_TYPE = 'darts'
+    config.SKIP_STAGE2 = False
+    ds = types.SimpleNamespace(qst_vocab=types.SimpleNamespace(vocab_size=17858), ans_vocab=types.SimpleNamespace(vocab_size=3129))
+    torch.manual_seed(10)
+    ef = model_factory.get_ef_model(ds).to('cuda').train()
+    w = model_factory.get_w_model(ds).to('cuda').train()
+    ef.qst_encoder.max_length = 14
+    ef_opt, w_opt = model_factory.get_ef_optimizer(ef), model_factory.get_w_optimizer(w)
+    arch = architect_factory.get_architect(ef, w, ef_opt, w_opt)
+    B, S = args.batch, args.size
+    g = torch.Generator().manual_seed(10)
+    img = torch.randn(B, 3, S, S, generator=g).cuda()
+    qst = torch.randint(17858, (B, 14), generator=g); qst[:, 0] = 2
+    qst = qst.cuda()
+    lab = torch.randint(3129, (B,), generator=g).cuda()
+
+    def stage1():
+        ef_opt.zero_grad()
+        ef._loss(img, qst, lab).backward()
+        torch.nn.utils.clip_grad_norm_(ef.parameters(), config.GRAD_CLIP)
+        ef_opt.step()
+
+    def stage2():
+        with torch.no_grad():
+            pq, pa = ef.generate(img)
+            pa = ops.softmax_rows(pa, 1.0)
+        w_opt.zero_grad()
+        w._soft_loss(img, qst, lab, pq, pa).backward()
+        torch.nn.utils.clip_grad_norm_(w.parameters(), config.GRAD_CLIP)
+        w_opt.step()
+
+    stage3 = lambda: arch.step(img, qst, lab, img, qst, lab, config.LEARNING_RATE, config.LEARNING_RATE)
+    for name, fn in (('stage 3 ArchitectLct.step', stage3), ('stage 1 examiner step', stage1), ('stage 2 generate + W step', stage2)):
+        for it in range(args.iters + 1):
+            if it == 1:
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.iters
+        print(f'LCT search {name} B={B} {S}x{S}: {dt * 1e3:.1f} ms  ({B / dt:.1f} pairs/s)')
 
 
 if __name__ == '__main__':
