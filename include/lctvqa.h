@@ -337,6 +337,10 @@ int lctvqa_image_u8_nhwc_to_f32_nchw(const uint8_t* x, float* y, int B, int H, i
 int lctvqa_grad_norm(const float* g, long n, float* scratch /* >=1024 floats */, float* total_norm_out, void* stream);
 int lctvqa_adam_step(float* p, const float* g, float* m, float* v, long n, const float* total_norm /* or NULL */,
                      float max_norm, float lr, float b1, float b2, float eps, int step, float weight_decay, void* stream);
+/* one launch copying a whole list of tensors (the architects' twin models: load_state_dict / _construct_model_from_theta per unrolled
+ * model, pcdarts/architect_lct.py:142-155, architect.py:80-95 - 2151 tensors for the PC-DARTS examiner): table in HBM = n_chunks x
+ * {src pointer, dst pointer, byte count} (three 8-byte words each), chunks of at most 64 KiB, built once by the caller */
+int lctvqa_multi_copy(const void* table, int n_chunks, void* stream);
 int lctvqa_axpy(float a, const float* x, float* y, long n, void* stream);
 int lctvqa_scale(float a, float* y, long n, void* stream);
 /* y = x * a[0], scalar read from device memory (grad_output of a scalar loss; no host sync) */

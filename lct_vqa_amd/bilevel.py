@@ -70,6 +70,42 @@ def shift_(params, direction, alpha):
     torch._foreach_add_([p.data for p in params], list(direction), alpha=alpha)
 
 
+_CHUNK = 64 * 1024
+
+
+def copy_tensors(dst, src, cache=None, key=None):
+    """dst[i] <- src[i] for two lists of same-shaped, same-dtype tensors.  Contiguous tensors on a ROCm device go through ONE
+    launch of ``lctvqa_multi_copy`` (torch's multi-tensor copy falls back to one copy kernel per tensor here: 2151 launches for a
+    PC-DARTS examiner's state_dict); the chunk table lives in HBM and is kept in ``cache[key]`` while every address stays the
+    same.  Anything else (CPU tensors, strided views) takes ``torch._foreach_copy_``."""
+    dst, src = list(dst), list(src)
+    if not dst:
+        return
+    fast = all(a.is_cuda and b.is_cuda and a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.shape == b.shape
+               for a, b in zip(dst, src))
+    if not fast:
+        for flt in (True, False):                                # one multi-tensor copy per dtype family
+            d = [t for t in dst if t.is_floating_point() == flt]
+            s = [t for t in src if t.is_floating_point() == flt]
+            if d:
+                torch._foreach_copy_(d, s)
+        return
+    from ._lib import lib
+    sig = tuple((a.data_ptr(), b.data_ptr(), a.numel() * a.element_size()) for a, b in zip(dst, src))
+    ent = cache.get(key) if (cache is not None and key is not None) else None
+    if ent is None or ent[0] != sig:
+        rows = []
+        for (dp, sp, nbytes) in sig:
+            for off in range(0, nbytes, _CHUNK):
+                rows.append((sp + off, dp + off, min(_CHUNK, nbytes - off)))
+        table = torch.tensor(rows, dtype=torch.int64).to(dst[0].device)
+        ent = (sig, table, len(rows))
+        if cache is not None and key is not None:
+            cache[key] = ent
+    if ent[2]:
+        lib('multi_copy', ent[1], ent[2])
+
+
 def virtual_step(model, g, lr, cache=None, key='twin'):
     """An independent copy of ``model`` (its own ``new()``: same class, same device, architecture parameters included)
     whose parameters are theta - lr * g; buffers are copied as they are.
@@ -92,16 +128,14 @@ def virtual_step(model, g, lr, cache=None, key='twin'):
             cache[key] = twin
     else:
         with torch.no_grad():
-            for flt in (True, False):                            # one multi-tensor copy per dtype family
-                d = [t for t in dst.values() if t.is_floating_point() == flt]
-                s = [t for t in src.values() if t.is_floating_point() == flt]
-                if d:
-                    torch._foreach_copy_(d, s)
+            d, s_ = list(dst.values()), list(src.values())
             if hasattr(model, 'arch_parameters'):
                 try:
-                    torch._foreach_copy_([a.data for a in twin.arch_parameters()], [a.data for a in model.arch_parameters()])
+                    d += [a.data for a in twin.arch_parameters()]
+                    s_ += [a.data for a in model.arch_parameters()]
                 except AttributeError:                           # a model without a search encoder
                     pass
+            copy_tensors(d, s_, cache, ('copy-table', key))
     shift_(list(twin.parameters()), g, -lr)
     return twin
 

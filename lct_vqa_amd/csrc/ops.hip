@@ -1192,3 +1192,31 @@ extern "C" int lctvqa_gru_cell_bwd(const float* dh_rec, const float* dh_ext, con
                      dxp, dhp, dh_carry, B, H);
   return lct_check_launch("gru_cell_bwd");
 }
+
+// ---- multi-tensor copy: one launch for a whole state_dict (the architects' twin models: `_construct_model_from_theta` /
+// `load_state_dict` per unrolled model, reference pcdarts/architect_lct.py:142-155, architect.py:80-95, 2151 tensors for the
+// PC-DARTS examiner).  The caller cuts the tensors into chunks of at most 64 KiB; table = [n][3] x 8 bytes (src, dst, bytes) in HBM.
+__global__ __launch_bounds__(256) void multi_copy_kernel(const unsigned long* __restrict__ table, int n) {
+  for (int c = blockIdx.x; c < n; c += gridDim.x) {
+    const char* s = (const char*)table[3 * c];
+    char* d = (char*)table[3 * c + 1];
+    const long bytes = (long)table[3 * c + 2];
+    if ((((unsigned long)s | (unsigned long)d | (unsigned long)bytes) & 15) == 0) {
+      const f32x4* s4 = (const f32x4*)s;
+      f32x4* d4 = (f32x4*)d;
+      for (long i = threadIdx.x; i < (bytes >> 4); i += blockDim.x) d4[i] = s4[i];
+    } else if ((((unsigned long)s | (unsigned long)d | (unsigned long)bytes) & 3) == 0) {
+      const float* s1 = (const float*)s;
+      float* d1 = (float*)d;
+      for (long i = threadIdx.x; i < (bytes >> 2); i += blockDim.x) d1[i] = s1[i];
+    } else {
+      for (long i = threadIdx.x; i < bytes; i += blockDim.x) d[i] = s[i];
+    }
+  }
+}
+extern "C" int lctvqa_multi_copy(const void* table, int n_chunks, void* stream) {
+  LCT_REQUIRE(table != nullptr && n_chunks > 0, "multi_copy: empty table");
+  const int blocks = n_chunks < 4096 ? n_chunks : 4096;
+  hipLaunchKernelGGL(multi_copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned long*)table, n_chunks);
+  return lct_check_launch("multi_copy");
+}

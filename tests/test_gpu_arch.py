@@ -218,3 +218,31 @@ def test_ef_darts_model_and_lct_architect(hip_lib):
     finally:
         config.ARCH_TYPE = 'fixed'
         config.ARCH_WEIGHT_DECAY = 1e-3
+
+
+def test_multi_tensor_copy_of_a_state_dict(hip_lib):
+    """bilevel.copy_tensors: one launch for a list of tensors of mixed dtype, size and alignment (what a twin's refill copies),
+    the chunk table re-used while the addresses stay and re-made when one moves."""
+    from lct_vqa_amd import bilevel
+    g = torch.Generator().manual_seed(3)
+    arena = torch.randn(1000, generator=g).to(DEV)
+    src = [torch.randn(300, 257, generator=g).to(DEV),            # 308 KB: five chunks, the last one ragged
+           torch.randn(3, generator=g).to(DEV),                   # 12 bytes
+           torch.randint(0, 1 << 40, (1,), generator=g).to(DEV),  # int64 num_batches_tracked
+           arena[4:104].view(10, 10),                             # a 16-byte aligned arena view
+           arena[105:112],                                        # a 4-byte aligned one
+           torch.randn(64, 3, 3, 3, generator=g).to(DEV)]
+    dst = [torch.full_like(t, 7) for t in src]
+    cache = {}
+    bilevel.copy_tensors(dst, src, cache, 'k')
+    assert all(torch.equal(a, b) for a, b in zip(dst, src))
+    table = cache['k'][1]
+    for t in src:
+        t.mul_(3) if t.is_floating_point() else t.add_(5)
+    bilevel.copy_tensors(dst, src, cache, 'k')
+    assert cache['k'][1] is table and all(torch.equal(a, b) for a, b in zip(dst, src))
+    dst[1] = torch.zeros(3, device=DEV)                           # another address: the table is rebuilt
+    bilevel.copy_tensors(dst, src, cache, 'k')
+    assert cache['k'][1] is not table and all(torch.equal(a, b) for a, b in zip(dst, src))
+    bilevel.copy_tensors(dst[:2], src[:2])                        # no cache: a throw-away table
+    assert torch.equal(dst[0], src[0])
