@@ -22,6 +22,11 @@ namespace {
 
 __device__ __attribute__((aligned(64))) float g_zero_page_bf16[64];
 
+// 1: epilogue through a per-wave LDS tile, 16-byte stores of consecutive channels; 0: 2-byte stores straight from the accumulators
+#ifndef BF16_EPI_LDS
+#define BF16_EPI_LDS 1
+#endif
+
 __device__ __forceinline__ unsigned short f2bf(float v) {
   const __bf16 b = (__bf16)v;                                   // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
   return __builtin_bit_cast(unsigned short, b);
@@ -184,6 +189,91 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const unsigned sho
   }
 
   // ---- epilogue: bias + ReLU (+ in-register 2x2 max pool), bf16 NHWC store ----
+#if BF16_EPI_LDS
+  // Each 32-pixel x (32*NT2)-channel block of a wave goes through a private fp32 LDS tile (the operand buffers are free: the loop
+  // ended on a barrier) so that a lane stores 16 bytes of consecutive channels of ONE pixel: 64..128-byte row segments per store
+  // instruction instead of 2-byte scatters (32 store instructions per block became 2-4; a Cin = 64 layer spent a third of its time here).
+  {
+    typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    constexpr int TC = 32 * NT2, TS = TC + 1;                      // tile columns, padded row stride (floats)
+    float* T = smem + wave * 32 * TS;
+    const int co0 = (n_tile * NP + wn * NT2) * 32;
+    if (!POOL) {
+      const int trow = lane >> 1, tcol = (lane & 1) * (TC / 2);     // this lane's pixel row and first channel of the read-back
+      float bvv[TC / 2];
+#pragma unroll
+      for (int e = 0; e < TC / 2; e++) bvv[e] = bias ? bias[co0 + tcol + e] : 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+#pragma unroll
+        for (int nn = 0; nn < NT2; nn++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) T[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + nn * 32 + j] = acc[m][nn][r];
+        int ty, tx;
+        subtile_pixel<SH, SW, TW>(wm * MT + m, trow, ty, tx);
+        const int R = R0 + ty;
+        unsigned short* dst = y + ((long)R * W + x0 + tx) * Cout + co0 + tcol;
+#pragma unroll
+        for (int c8 = 0; c8 < TC / 16; c8++) {
+          us8 ov;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            float v = T[trow * TS + tcol + 8 * c8 + e] + bvv[8 * c8 + e];
+            if (relu) v = fmaxf(v, 0.f);
+            ov[e] = f2bf(v);
+          }
+          if (R < Rtot) *(us8*)(dst + 8 * c8) = ov;
+        }
+      }
+    } else {
+      const int Ho = H >> 1, Wo = W >> 1;
+      constexpr int CW = TC / 8;                                   // channels per lane of the read-back: 8 pooled pixels x 8 lanes
+      const int px = lane >> 3, tcol = (lane & 7) * CW;
+      float bvv[CW];
+#pragma unroll
+      for (int e = 0; e < CW; e++) bvv[e] = bias ? bias[co0 + tcol + e] : 0.f;
+      const int rr = 2 * (px & 1) + 16 * ((px >> 1) & 1) + 4 * (px >> 2);    // row of the (0,0) pixel of pooled pixel px = (h, ap, bp)
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+#pragma unroll
+        for (int nn = 0; nn < NT2; nn++)
+#pragma unroll
+          for (int ap = 0; ap < 2; ap++)
+#pragma unroll
+            for (int bp = 0; bp < 2; bp++) {
+              const int r00 = 8 * ap + 2 * bp;                     // reg of (dy=0,dx=0): a = 2ap, b = 2bp
+              T[(4 * h + 2 * ap + bp) * TS + nn * 32 + j] =
+                  fmaxf(fmaxf(acc[m][nn][r00], acc[m][nn][r00 + 1]), fmaxf(acc[m][nn][r00 + 4], acc[m][nn][r00 + 5]));
+            }
+        int ty, tx;
+        subtile_pixel<SH, SW, TW>(wm * MT + m, rr, ty, tx);
+        const int R = R0 + ty;
+        const int n = R / H, yy = R % H;
+        unsigned short* dst = y + (((long)n * Ho + (yy >> 1)) * Wo + ((x0 + tx) >> 1)) * Cout + co0 + tcol;
+        if (CW == 8) {
+          us8 ov;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            float v = T[px * TS + tcol + e] + bvv[e];
+            if (relu) v = fmaxf(v, 0.f);
+            ov[e] = f2bf(v);
+          }
+          if (R < Rtot) *(us8*)dst = ov;
+        } else {
+          us4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            float v = T[px * TS + tcol + e] + bvv[e];
+            if (relu) v = fmaxf(v, 0.f);
+            ov[e] = f2bf(v);
+          }
+          if (R < Rtot) *(us4*)dst = ov;
+        }
+      }
+    }
+  }
+#else
 #pragma unroll
   for (int nn = 0; nn < NT2; nn++) {
     const int co = (n_tile * NP + wn * NT2 + nn) * 32 + j;
@@ -229,6 +319,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const unsigned sho
       }
     }
   }
+#endif
 }
 
 // first layer (Cin = 3): fp32 NCHW image -> bf16 NHWC, bias + ReLU.  HBM-write bound; lane = output channel, 8 pixels of
