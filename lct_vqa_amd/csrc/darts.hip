@@ -547,6 +547,29 @@ __global__ void pool3x3_fwd_kernel(const float* __restrict__ x, float* __restric
     y[o] = kind ? a / (float)cnt : a;
   }
 }
+// the same, four channels per thread (16-byte loads and stores; C % 4 == 0)
+__global__ void pool3x3_fwd_vec_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C4, int s, int Ho,
+                                       int Wo, int kind) {
+  GRID_STRIDE(o, (long)B * Ho * Wo * C4) {
+    int c = o % C4; long q = o / C4; int ox = q % Wo; int oy = (q / Wo) % Ho; int n = q / ((long)Wo * Ho);
+    f32x4 a = kind ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int cnt = 0;
+    for (int ky = 0; ky < 3; ky++) {
+      int iy = oy * s - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; kx++) {
+        int ix = ox * s - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        const f32x4 v = *(const f32x4*)(x + ((((long)n * H + iy) * W + ix) * C4 + c) * 4);
+        if (kind) a += v;
+        else { a[0] = fmaxf(a[0], v[0]); a[1] = fmaxf(a[1], v[1]); a[2] = fmaxf(a[2], v[2]); a[3] = fmaxf(a[3], v[3]); }
+        cnt++;
+      }
+    }
+    if (kind) a = a / (float)cnt;
+    *(f32x4*)(y + o * 4) = a;
+  }
+}
 // thread per INPUT element: gathers the gradient of every window that selected it (max: first maximal element in
 // scan order, like PyTorch) or covers it (avg)
 __global__ void pool3x3_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int B,
@@ -1086,8 +1109,12 @@ int lctvqa_pwconv_wgrad_small(const float* dy, const float* x, float* dw, float*
 
 int lctvqa_pool3x3_fwd(const float* x, float* y, int B, int H, int W, int C, int stride, int kind, void* stream) {
   int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-  hipLaunchKernelGGL(pool3x3_fwd_kernel, dim3(gs_blocks((long)B * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C,
-                     stride, Ho, Wo, kind);
+  if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
+    hipLaunchKernelGGL(pool3x3_fwd_vec_kernel, dim3(gs_blocks((long)B * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W,
+                       C / 4, stride, Ho, Wo, kind);
+  else
+    hipLaunchKernelGGL(pool3x3_fwd_kernel, dim3(gs_blocks((long)B * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C,
+                       stride, Ho, Wo, kind);
   return lct_check_launch("pool3x3_fwd");
 }
 int lctvqa_pool3x3_bwd(const float* dy, const float* x, float* dx, int B, int H, int W, int C, int stride, int kind, void* stream) {

@@ -163,25 +163,34 @@ __global__ void cvt_bf16_f32_kernel(const unsigned short* __restrict__ x, float*
   }
 }
 // MaxPool2d(3, stride 2, padding 1) on bf16 NHWC
-__global__ void maxpool3x3_s2_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int B, int H, int W, int C,
+// thread = (output pixel, 8 channels): nine 16-byte loads, one 16-byte store (C % 8 == 0)
+__global__ void maxpool3x3_s2_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int B, int H, int W, int C8,
                                           int Ho, int Wo) {
-  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < (long)B * Ho * Wo * C; o += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(o % C);
-    long q = o / C;
+  typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < (long)B * Ho * Wo * C8; o += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(o % C8);
+    long q = o / C8;
     const int ox = (int)(q % Wo); q /= Wo;
     const int oy = (int)(q % Ho);
     const long n = q / Ho;
-    float a = -INFINITY;
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) a[e] = -INFINITY;
     for (int ky = 0; ky < 3; ky++) {
       const int iy = 2 * oy - 1 + ky;
       if (iy < 0 || iy >= H) continue;
       for (int kx = 0; kx < 3; kx++) {
         const int ix = 2 * ox - 1 + kx;
         if (ix < 0 || ix >= W) continue;
-        a = fmaxf(a, bf2f(x[((n * H + iy) * W + ix) * C + c]));
+        const us8 v = *(const us8*)(x + (((n * H + iy) * W + ix) * C8 + c) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) a[e] = fmaxf(a[e], bf2f(v[e]));
       }
     }
-    y[o] = f2bf(a);
+    us8 r;
+#pragma unroll
+    for (int e = 0; e < 8; e++) r[e] = f2bf(a[e]);
+    *(us8*)(y + o * 8) = r;
   }
 }
 // y[n][oy][ox][:] = x[n][2oy][2ox][:]  (bf16 NHWC, 16-byte vectors: C % 8 == 0)
@@ -254,9 +263,10 @@ int lctvqa_cvt_bf16_to_f32(const void* x, float* y, long n, void* stream) {
   return lct_check_launch("cvt_bf16_to_f32");
 }
 int lctvqa_maxpool3x3_s2_bf16(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+  LCT_REQUIRE(C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, "maxpool3x3_s2_bf16: need C %% 8 == 0 and 16-byte aligned tensors");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  long nb = ((long)B * Ho * Wo * C + 255) / 256; if (nb > 16384) nb = 16384;
-  hipLaunchKernelGGL(maxpool3x3_s2_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)y, B, H, W, C, Ho, Wo);
+  long nb = ((long)B * Ho * Wo * (C / 8) + 255) / 256; if (nb > 16384) nb = 16384;
+  hipLaunchKernelGGL(maxpool3x3_s2_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)y, B, H, W, C / 8, Ho, Wo);
   return lct_check_launch("maxpool3x3_s2_bf16");
 }
 int lctvqa_subsample2_bf16(const void* x, void* y, int B, int H, int W, int C, void* stream) {
