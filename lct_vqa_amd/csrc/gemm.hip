@@ -379,8 +379,15 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ ws, int spli
   long total = (long)M * N;
   for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
     int n = o % N, m = o / N;
-    float v = 0.f;
-    for (int s = 0; s < splits; s++) v += ws[(long)s * total + o];
+    // four slabs per iteration: independent loads in flight (one at a time made a 32-way split 32 dependent HBM latencies)
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int s = 0;
+    for (; s + 3 < splits; s += 4) {
+      const float* p = ws + (long)s * total + o;
+      v0 += p[0]; v1 += p[total]; v2 += p[2 * total]; v3 += p[3 * total];
+    }
+    for (; s < splits; s++) v0 += ws[(long)s * total + o];
+    const float v = (v0 + v1) + (v2 + v3);
     C[(long)m * ldc + n] = apply_epi(v, m, n, epi);
   }
 }
