@@ -402,7 +402,15 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
   float a = 0.f;
   if (n < N)
-    for (int m = r0 + w; m < r1; m += 4) a += X[(long)m * ld + n];
+  {
+    float a1 = 0.f, a2 = 0.f, a3 = 0.f;                           // four rows per iteration: independent loads in flight
+    int m = r0 + w;
+    for (; m + 12 < r1; m += 16) {
+      a += X[(long)m * ld + n]; a1 += X[(long)(m + 4) * ld + n]; a2 += X[(long)(m + 8) * ld + n]; a3 += X[(long)(m + 12) * ld + n];
+    }
+    for (; m < r1; m += 4) a += X[(long)m * ld + n];
+    a = (a + a1) + (a2 + a3);
+  }
   red[w][threadIdx.x & 63] = a;
   __syncthreads();
   if (w == 0 && n < N) part[(long)blockIdx.y * N + n] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
