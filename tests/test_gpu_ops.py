@@ -180,7 +180,8 @@ def test_gemm_linear_fwd_bwd(ops, M, N, K):
     assert rel_err(ops.colsum(dyd), dy.sum(0)) < 2e-5
 
 
-@pytest.mark.parametrize('M,N,K', [(516, 200, 72), (1000, 64, 256), (260, 132, 20), (8, 8, 8), (3136, 256, 64), (64, 1024, 50176)])
+@pytest.mark.parametrize('M,N,K', [(516, 200, 72), (1000, 64, 256), (260, 132, 20), (8, 8, 8), (1, 3, 4), (257, 65, 4), (3136, 256, 64),
+                                   (64, 1024, 50176)])
 def test_gemm_dma_kernel_all_layouts(ops, hip_lib, M, N, K):
     """The LDS-DMA GEMM (K- and row-contiguous operands, ragged tiles, K tails, split-K) against fp64 and against the
     general kernel on the same operands."""
