@@ -565,9 +565,18 @@ __global__ __launch_bounds__(1024) void edge_bwd_coef_kernel(const float* __rest
   const int ngrp = 1024 / ncol > 7 ? 7 : 1024 / ncol;            // 7 row groups at Cq = 4..16
   const int g = threadIdx.x / ncol, col = threadIdx.x % ncol;
   if (g < ngrp) {
-    double a = 0.0;
-#pragma unroll 4
-    for (int b = g; b < nblk; b += ngrp) a += (double)part[(long)b * ncol + col];
+    // sixteen independent loads in flight per thread (this single workgroup is latency-bound: up to 1536 partial rows / 7 groups)
+    double a = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int b = g;
+    for (; b + 15 * ngrp < nblk; b += 16 * ngrp) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) v[u] = part[(long)(b + u * ngrp) * ncol + col];
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) { a += (double)v[u]; a1 += (double)v[u + 1]; a2 += (double)v[u + 2]; a3 += (double)v[u + 3]; }
+    }
+    for (; b < nblk; b += ngrp) a += (double)part[(long)b * ncol + col];
+    a = (a + a1) + (a2 + a3);
     grp[g][col] = a;
   }
   __syncthreads();
