@@ -106,8 +106,8 @@ int lctvqa_gemm_f32_ex(const float* A, long a_ms, long a_ks, const float* B, lon
                        const uint8_t* mask, long ld_mask, float mask_scale, float* workspace, long workspace_bytes,
                        int relu_ab, void* stream);
 /* Both entry points above run on the LDS-DMA kernel (256 x 128 x 16 tiles, operands HBM -> LDS by global_load_lds) whenever both
- * operands are 16-byte aligned and K- or row-contiguous with K % 4 == 0 and no operand ReLU is asked for; everything else takes the
- * general VGPR-staged kernel.  lctvqa_gemm_force_general(1) routes every product through the general kernel (A/B, tests);
+ * operands are 16-byte aligned and K- or row-contiguous with K % 4 == 0 (operand ReLU included: applied to the fragments); everything
+ * else takes the general VGPR-staged kernel.  lctvqa_gemm_force_general(1) routes every product through the general kernel (A/B, tests);
  * returns the previous setting. */
 int lctvqa_gemm_force_general(int on);
 /* C[b] = act(A[b] . B[b]^T + bias) for b < batch on the LDS-DMA kernel: operands K-contiguous (X(r,k) = X[r*rs + k]) or row-contiguous

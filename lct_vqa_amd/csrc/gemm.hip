@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same product for operands the LDS-DMA can stage directly (16-byte aligned, K- or row-contiguous, no fused A prologue):
+// The same product for operands the LDS-DMA can stage directly (16-byte aligned, K- or row-contiguous, no fused A prologue; an
+// operand ReLU is applied to the fragments after their LDS read):
 // 256 x (64*NTW) x 16 tile, 4 waves (2 x 2), wave = 4 x NTW v_mfma_f32_32x32x2_f32 tiles (128 x 32*NTW outputs), both operand
 // tiles HBM -> LDS by global_load_lds (16 B per lane, no VGPR hop, no address VALU in the loop), double buffered with one
 // barrier per K step of 16 while the next step's 6 DMA instructions per wave are in flight.
@@ -253,7 +254,7 @@ __device__ __attribute__((aligned(64))) float g_zero_page_g[64];
 template <bool AKM, bool BKM, int NTW>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
                                                               long ldb, float* __restrict__ C, long ldc, int M, int N, int K,
-                                                              int kper, GemmEpi epi, int direct, long sA, long sB, long sC) {
+                                                              int kper, GemmEpi epi, int direct, long sA, long sB, long sC, int relu_ab) {
   constexpr int BM = 256, BN = 64 * NTW;
   constexpr int ASZ = BM * 16, BSZ = BN * 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -359,6 +360,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __res
 #pragma unroll
           for (int e = 0; e < 4; e++) bf[b][e] = lb[(8 * kk + 4 * h + e) * BN + wn * 32 * NTW + b * 32 + j];
         }
+      }
+      if (relu_ab & 1) {                                           // operand ReLU (PC-DARTS ReLU -> Conv1x1 blocks) on the fragments
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) af[a][e] = fmaxf(af[a][e], 0.f);
+      }
+      if (relu_ab & 2) {
+#pragma unroll
+        for (int b = 0; b < NTW; b++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) bf[b][e] = fmaxf(bf[b][e], 0.f);
       }
 #pragma unroll
       for (int e = 0; e < 4; e++)
@@ -469,7 +482,7 @@ long lctvqa_gemm_workspace_bytes(int M, int N, int K) {
 }
 
 typedef void (*gemm_dma_kern_t)(const float*, long, const float*, long, float*, long, int, int, int, int, GemmEpi, int, long, long,
-                                long);
+                                long, int);
 static gemm_dma_kern_t gemm_dma_table[2][2][2] = {
     {{gemm_f32_dma_kernel<false, false, 1>, gemm_f32_dma_kernel<false, false, 2>},
      {gemm_f32_dma_kernel<false, true, 1>, gemm_f32_dma_kernel<false, true, 2>}},
@@ -486,7 +499,7 @@ static int dma_layout(const float* P, long rs, long ks, int rows, int K) {
 
 static int launch_gemm_dma(const float* A, long lda, int akm, const float* B, long ldb, int bkm, float* C, long ldc, int M, int N,
                            int K, const GemmEpi& epi, float* workspace, long workspace_bytes, int batch, long sA, long sB, long sC,
-                           hipStream_t st) {
+                           hipStream_t st, int relu_ab = 0) {
   const int BN = dma_bn(N);
   const int ntm = cdiv(M, 256), ntn = cdiv(N, BN);
   int splits = batch > 1 ? 1 : plan_splits(ntm * ntn, K);
@@ -500,10 +513,10 @@ static int launch_gemm_dma(const float* A, long lda, int akm, const float* B, lo
   const size_t lds = (size_t)(2 * 256 * 16 + 2 * BN * 16) * sizeof(float);
   dim3 grid(ntm >= 8 ? ((ntm + 7) / 8) * 8 * ntn : ntm * ntn, batch, splits);
   if (splits == 1) {
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K, kper, epi, 1, sA, sB, sC);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K, kper, epi, 1, sA, sB, sC, relu_ab);
     return lct_check_launch("gemm_f32_dma");
   }
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, workspace, (long)N, M, N, K, kper, epi, 0, 0L, 0L, 0L);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, workspace, (long)N, M, N, K, kper, epi, 0, 0L, 0L, 0L, relu_ab);
   int rc = lct_check_launch("gemm_f32_dma(splitk)");
   if (rc) return rc;
   long total = (long)M * N;
@@ -528,11 +541,11 @@ int lctvqa_gemm_f32_ex(const float* A, long a_ms, long a_ks, const float* B, lon
     relu_ab &= 3;
     LCT_REQUIRE(a_ks == 1, "fused fusion-head prologue needs a K-contiguous A operand");
   }
-  if (!epi.a2 && relu_ab == 0 && !g_gemm_force_general) {
+  if (!epi.a2 && !g_gemm_force_general) {
     const int la = dma_layout(A, a_ms, a_ks, M, K), lb = dma_layout(B, b_ns, b_ks, N, K);
     if (la >= 0 && lb >= 0)
       return launch_gemm_dma(A, la ? a_ks : a_ms, la, B, lb ? b_ks : b_ns, lb, C, ldc, M, N, K, epi, workspace, workspace_bytes, 1, 0, 0,
-                             0, st);
+                             0, st, relu_ab);
   }
   int tiles = cdiv(M, 128) * cdiv(N, 128);
   int splits = plan_splits(tiles, K);
