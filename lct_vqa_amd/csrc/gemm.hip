@@ -428,12 +428,32 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   __syncthreads();
   if (w == 0 && n < N) part[(long)blockIdx.y * N + n] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ void colsum_finish_kernel(const float* __restrict__ part, int S, int N, float* __restrict__ out) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// stage 2: workgroup = 64 columns x 16 row groups; a group sums its parts eight loads at a time, then the groups in fixed order
+// (one thread per column walking up to 2048 parts was a chain of 2048 dependent HBM latencies: ~1 ms for a 64-channel bias gradient)
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ part, int S, int N, float* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
   float a = 0.f;
-  for (int s = 0; s < S; s++) a += part[(long)s * N + n];
-  out[n] = a;
+  if (n < N) {
+    float v[8];
+    int s = g;
+    for (; s + 7 * 16 < S; s += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = part[(long)(s + 16 * u) * N + n];
+#pragma unroll
+      for (int u = 0; u < 8; u++) a += v[u];
+    }
+    for (; s < S; s += 16) a += part[(long)s * N + n];
+  }
+  red[g][c] = a;
+  __syncthreads();
+  if (g == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += red[k][c];
+    out[n] = t;
+  }
 }
 
 static int pick_mode(const float* P, long rs, long ks, int K) {
@@ -631,7 +651,7 @@ int lctvqa_colsum_f32(const float* X, long ld, int M, int N, float* out, float* 
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), S), dim3(256), 0, (hipStream_t)stream, X, ld, M, N, rows_per, scratch);
   int rc = lct_check_launch("colsum_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, scratch, S, N, out);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(N, 64)), dim3(1024), 0, (hipStream_t)stream, scratch, S, N, out);
   return lct_check_launch("colsum_finish");
 }
 
