@@ -197,9 +197,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
 
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nsplit, long n, float* __restrict__ out) {
   for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
-    float a = 0.f;
-    for (int s = 0; s < nsplit; s++) a += slab[(long)s * n + o];
-    out[o] = a;
+    float a = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;                 // four slabs per iteration: independent loads in flight
+    int s = 0;
+    for (; s + 3 < nsplit; s += 4) {
+      const float* p = slab + (long)s * n + o;
+      a += p[0]; a1 += p[n]; a2 += p[2 * n]; a3 += p[3 * n];
+    }
+    for (; s < nsplit; s++) a += slab[(long)s * n + o];
+    out[o] = (a + a1) + (a2 + a3);
   }
 }
 

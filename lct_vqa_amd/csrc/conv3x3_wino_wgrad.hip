@@ -162,9 +162,11 @@ __global__ __launch_bounds__(256) void wino4_wgrad_finish(const float* __restric
 #pragma unroll
       for (int nu = 0; nu < 6; nu++) {
         const float* p = M + ((long)(xi * 6 + nu) * S) * total + o;
-        float a = 0.f;
-        for (int s = 0; s < S; s++) a += p[(long)s * total];
-        m[nu] = a;
+        float a = 0.f, a1 = 0.f;                                  // two slices per iteration (36 planes already give 36 loads in flight)
+        int s = 0;
+        for (; s + 1 < S; s += 2) { a += p[(long)s * total]; a1 += p[(long)(s + 1) * total]; }
+        if (s < S) a += p[(long)s * total];
+        m[nu] = a + a1;
       }
       r[xi][0] = m[0] + m[1] + m[2] + m[3] + m[4];
       r[xi][1] = (m[1] - m[2]) + 2.f * (m[3] - m[4]);
