@@ -306,6 +306,11 @@ int lctvqa_subsample2_bf16(const void* x, void* y, int B, int H, int W, int C, v
 int lctvqa_global_avgpool_bf16(const void* x, float* y, int B, int HW, int C, void* stream);
 int lctvqa_conv7x7_s2_stem_bf16(const float* x_nchw, const float* w_oihw, const float* bias, void* y_nhwc_bf16, int B, int H, int W, int relu,
                                 void* stream);
+/* the same stem on the matrix cores (implicit GEMM, K = 3 x 7 rows x 8, v_mfma_f32_32x32x16_bf16): image and weights rounded to bf16,
+ * fp32 accumulation; _supported: even H, W and at most 128 output pixels per row */
+int lctvqa_conv7x7_s2_stem_bf16_mfma_supported(int B, int H, int W);
+int lctvqa_conv7x7_s2_stem_bf16_mfma(const float* x_nchw, const float* w_oihw, const float* shift, void* y_nhwc_bf16, int B, int H, int W,
+                                     int relu, void* stream);
 
 /* One PC-DARTS MixedOp edge as fused tile kernels (model_search.py:22-55 + the seven live primitives of operations.py:4-20
  * on x[..., :C/4], their BatchNorms, the alpha-weighted sum, bypass, channel shuffle and the beta-weighted accumulation

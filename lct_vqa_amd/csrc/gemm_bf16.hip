@@ -216,6 +216,89 @@ __global__ void global_avgpool_bf16_kernel(const unsigned short* __restrict__ x,
   }
 }
 
+
+// ---- ResNet stem on the matrix cores: Conv2d(3,64,7,stride 2,padding 3) + shift + ReLU, fp32 NCHW image -> bf16 NHWC.
+// Implicit GEMM with K = 3 x 7 rows x 8 (kx 0..6 and one zero) = 168, padded to 11 k16-steps: k16-step s feeds rows (c,ky) = 2s
+// (lanes 0..31) and 2s+1 (lanes 32..63) of v_mfma_f32_32x32x16_bf16, a lane's 8 k values are the 8 consecutive input pixels
+// 2ox-3 .. 2ox+4 of that row (four ds_read_b32 of the bf16 row image in LDS).  Workgroup = 4 waves = 4 output rows x up to 128
+// output pixels x 64 channels; the 13 input rows and the weights (as B fragments [22 rows][64 co][8]) are staged once per workgroup.
+// (The VALU form, resnet.hip conv7x7_s2_stem_kernel, spends 1.9 ms on the 60 GFLOP of a B=256 batch; this one is bound by its
+// 0.41 GB of output.)  Image and weights are rounded to bf16 (the VALU form multiplies in fp32 and rounds only its output).
+constexpr int STEM_ROWS = 4, STEM_NR = 2 * STEM_ROWS + 5, STEM_RL = 272;
+__global__ __launch_bounds__(256, 2) void conv7x7_s2_stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                      const float* __restrict__ shift, unsigned short* __restrict__ y,
+                                                                      int B, int H, int W, int relu) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* xin = (unsigned short*)smem_raw;                          // [3][STEM_NR][STEM_RL] bf16, index j <-> ix = j - 3
+  unsigned short* wB = xin + 3 * STEM_NR * STEM_RL;                          // [22][64][8] bf16
+  float* Tall = (float*)(wB + 22 * 64 * 8);                                 // [4 waves][32][65] fp32
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int gpr = (Ho + STEM_ROWS - 1) / STEM_ROWS;
+  const int n = blockIdx.x / gpr, oy0 = (blockIdx.x % gpr) * STEM_ROWS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 3 * STEM_NR * STEM_RL; i += 256) {
+    const int j = i % STEM_RL, rr = (i / STEM_RL) % STEM_NR, c = i / (STEM_RL * STEM_NR);
+    const int iy = 2 * oy0 - 3 + rr, ix = j - 3;
+    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    xin[i] = f2bf(ok ? x[(((long)n * 3 + c) * H + iy) * W + ix] : 0.f);
+  }
+  for (int i = tid; i < 22 * 64 * 8; i += 256) {
+    const int kx = i & 7, co = (i >> 3) & 63, row = i >> 9;
+    const int c = row / 7, ky = row % 7;
+    wB[i] = f2bf((row < 21 && kx < 7) ? w[((co * 3 + c) * 7 + ky) * 7 + kx] : 0.f);
+  }
+  __syncthreads();
+  const int j = lane & 31, h = lane >> 5;
+  const int ox = 32 * wave + j;
+  float* T = Tall + wave * 32 * 65;
+  const int trow = lane >> 1, tcol = (lane & 1) * 32;
+  float sh[32];
+#pragma unroll
+  for (int e = 0; e < 32; e++) sh[e] = shift ? shift[tcol + e] : 0.f;
+  for (int oyl = 0; oyl < STEM_ROWS; oyl++) {
+    const int oy = oy0 + oyl;
+    if (oy >= Ho) break;                                                    // uniform
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 11; s++) {
+      const int row = 2 * s + h, rowc = row < 21 ? row : 20;               // row 21 does not exist: its weights are zero
+      const int c = rowc / 7, ky = rowc % 7;
+      const unsigned int* ap = (const unsigned int*)(xin + (c * STEM_NR + 2 * oyl + ky) * STEM_RL + 2 * ox);
+      const u32x4 av = {ap[0], ap[1], ap[2], ap[3]};
+      const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const bf16x8 b = __builtin_bit_cast(bf16x8, *(const u32x4*)(wB + ((row * 64) + 32 * t + j) * 8));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+      }
+    }
+    // 32 pixels x 64 channels through the wave's LDS tile: 16-byte stores of consecutive channels
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) T[((r & 3) + 8 * (r >> 2) + 4 * h) * 65 + t * 32 + j] = acc[t][r];
+    const int oxs = 32 * wave + trow;
+    unsigned short* dst = y + ((((long)n * Ho + oy) * Wo + oxs) * 64 + tcol);
+#pragma unroll
+    for (int c8 = 0; c8 < 4; c8++) {
+      us8 ov;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float v = T[trow * 65 + tcol + 8 * c8 + e] + sh[8 * c8 + e];
+        if (relu) v = fmaxf(v, 0.f);
+        ov[e] = f2bf(v);
+      }
+      if (oxs < Wo) *(us8*)(dst + 8 * c8) = ov;
+    }
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -279,6 +362,23 @@ int lctvqa_global_avgpool_bf16(const void* x, float* y, int B, int HW, int C, vo
   long nb = ((long)B * C + 255) / 256; if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(global_avgpool_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, y, B, HW, C);
   return lct_check_launch("global_avgpool_bf16");
+}
+
+// 1 when the matrix-core stem takes this image size (even H, W; at most 128 output pixels per row)
+int lctvqa_conv7x7_s2_stem_bf16_mfma_supported(int B, int H, int W) {
+  return (B > 0 && H >= 8 && W >= 8 && H % 2 == 0 && W % 2 == 0 && W / 2 <= 128) ? 1 : 0;
+}
+int lctvqa_conv7x7_s2_stem_bf16_mfma(const float* x_nchw, const float* w_oihw /* [64][3][7][7] */, const float* shift, void* y_nhwc_bf16,
+                                     int B, int H, int W, int relu, void* stream) {
+  LCT_REQUIRE(lctvqa_conv7x7_s2_stem_bf16_mfma_supported(B, H, W), "conv7x7_s2_stem_bf16_mfma: unsupported image size %d x %d", H, W);
+  LCT_REQUIRE(((uintptr_t)y_nhwc_bf16 & 15) == 0, "conv7x7_s2_stem_bf16_mfma: output must be 16-byte aligned");
+  const size_t lds = (size_t)(3 * STEM_NR * STEM_RL + 22 * 64 * 8) * 2 + (size_t)4 * 32 * 65 * 4;
+  auto k = conv7x7_s2_stem_mfma_kernel;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int Ho = H / 2;
+  hipLaunchKernelGGL(k, dim3(B * ((Ho + STEM_ROWS - 1) / STEM_ROWS)), dim3(256), lds, (hipStream_t)stream, x_nchw, w_oihw, shift,
+                     (unsigned short*)y_nhwc_bf16, B, H, W, relu);
+  return lct_check_launch("conv7x7_s2_stem_bf16_mfma");
 }
 
 }  // extern "C"

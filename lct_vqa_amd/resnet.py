@@ -193,7 +193,10 @@ class ResNet152Trunk(nn.Module):
         wf, shift = self._fold(self.conv1, self.bn1)
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         x = torch.empty((B, Ho, Wo, 64), dtype=torch.bfloat16, device=dev)
-        lib('conv7x7_s2_stem_bf16', image, wf, shift, x, B, H, W, 1)
+        if lib.query('conv7x7_s2_stem_bf16_mfma_supported', B, H, W):     # matrix cores: bf16 image and weights, fp32 accumulation
+            lib('conv7x7_s2_stem_bf16_mfma', image, wf, shift, x, B, H, W, 1)
+        else:
+            lib('conv7x7_s2_stem_bf16', image, wf, shift, x, B, H, W, 1)
         Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
         y = torch.empty((B, Hp, Wp, 64), dtype=torch.bfloat16, device=dev)
         lib('maxpool3x3_s2_bf16', x, y, B, Ho, Wo, 64)

@@ -42,6 +42,29 @@ def test_stem_fold_and_pool_kernels(hip_lib):
     assert rel_err(out, x.mean(dim=(1, 2))) < 1e-6
 
 
+@pytest.mark.parametrize('B,H,W', [(2, 38, 50), (3, 224, 224), (1, 8, 256), (2, 30, 8)])
+def test_stem_on_matrix_cores_bf16(hip_lib, B, H, W):
+    """conv7x7/s2 stem as an implicit GEMM on bf16 MFMA: against torch on the SAME bf16-rounded image and weights (fp32
+    accumulation; the output's own rounding to bf16 is the tolerance), ragged widths, bottom rows of a 4-row group, borders."""
+    import torch.nn.functional as F
+    lib = hip_lib
+    assert lib.query('conv7x7_s2_stem_bf16_mfma_supported', B, H, W)
+    g = torch.Generator().manual_seed(H + W)
+    img = torch.randn(B, 3, H, W, generator=g).to(DEV)
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).to(DEV)
+    shift = torch.randn(64, generator=g).to(DEV)
+    Ho, Wo = H // 2, W // 2
+    for relu in (1, 0):
+        y = torch.full((B, Ho, Wo, 64), float('nan'), dtype=torch.bfloat16, device=DEV)
+        lib('conv7x7_s2_stem_bf16_mfma', img, w, shift, y, B, H, W, relu)
+        ref = F.conv2d(img.bfloat16().double(), w.bfloat16().double(), shift.double(), stride=2, padding=3)
+        if relu:
+            ref = F.relu(ref)
+        got = y.double().permute(0, 3, 1, 2)
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() <= 6e-3 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize('size', [64, 96, 224])
 def test_resnet152_trunk_vs_oracle(hip_lib, size):
     from oracle import resnet_oracle                            # checker only
