@@ -265,6 +265,9 @@ int lctvqa_conv3x3_bf16_nhwc(const void* x_bf16, const void* w_packed, const flo
                              int Cout, int relu, int pool, void* stream);
 int lctvqa_conv3x3_first_nchw_bf16(const float* x_nchw, const float* w_oihw, const float* bias, void* y_nhwc_bf16, int B, int H, int W,
                                    int Cout, int relu, void* stream);
+/* the same layer on the matrix cores for Cout = 64 (implicit GEMM, K = 9 (c,ky) rows x 8): image and weights rounded to bf16 */
+int lctvqa_conv3x3_first_nchw_bf16_mfma(const float* x_nchw, const float* w_oihw, const float* bias, void* y_nhwc, int B, int H, int W,
+                                        int relu, void* stream);
 int lctvqa_adaptive_avgpool7_flatten_bf16(const void* x_nhwc_bf16, float* y, int B, int H, int W, int C, void* stream);
 
 /* ---- frozen ResNet-152 trunk (BASELINE.json configs[2]; not in the reference): what the VGG / GEMM

@@ -200,30 +200,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const unsigned sho
     float* T = smem + wave * 32 * TS;
     const int co0 = (n_tile * NP + wn * NT2) * 32;
     if (!POOL) {
-      const int trow = lane >> 1, tcol = (lane & 1) * (TC / 2);     // this lane's pixel row and first channel of the read-back
-      float bvv[TC / 2];
+      constexpr int LPP = TC / 8, PPI = 64 / LPP;                  // lanes per pixel (16 B each), pixels per store instruction
+      const int tq = lane % LPP, tp = lane / LPP;                  // a store instruction writes PPI whole 64..128-byte pixel rows
+      float bvv[8];
 #pragma unroll
-      for (int e = 0; e < TC / 2; e++) bvv[e] = bias ? bias[co0 + tcol + e] : 0.f;
+      for (int e = 0; e < 8; e++) bvv[e] = bias ? bias[co0 + 8 * tq + e] : 0.f;
 #pragma unroll
       for (int m = 0; m < MT; m++) {
 #pragma unroll
         for (int nn = 0; nn < NT2; nn++)
 #pragma unroll
           for (int r = 0; r < 16; r++) T[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + nn * 32 + j] = acc[m][nn][r];
-        int ty, tx;
-        subtile_pixel<SH, SW, TW>(wm * MT + m, trow, ty, tx);
-        const int R = R0 + ty;
-        unsigned short* dst = y + ((long)R * W + x0 + tx) * Cout + co0 + tcol;
 #pragma unroll
-        for (int c8 = 0; c8 < TC / 16; c8++) {
+        for (int c = 0; c < 32 / PPI; c++) {
+          const int pr = tp + PPI * c;
+          int ty, tx;
+          subtile_pixel<SH, SW, TW>(wm * MT + m, pr, ty, tx);
+          const int R = R0 + ty;
           us8 ov;
 #pragma unroll
           for (int e = 0; e < 8; e++) {
-            float v = T[trow * TS + tcol + 8 * c8 + e] + bvv[8 * c8 + e];
+            float v = T[pr * TS + 8 * tq + e] + bvv[e];
             if (relu) v = fmaxf(v, 0.f);
             ov[e] = f2bf(v);
           }
-          if (R < Rtot) *(us8*)(dst + 8 * c8) = ov;
+          if (R < Rtot) *(us8*)(y + ((long)R * W + x0 + tx) * Cout + co0 + 8 * tq) = ov;
         }
       }
     } else {
@@ -371,6 +372,97 @@ __global__ __launch_bounds__(256) void conv3x3_first_bf16_kernel(const float* __
   }
 }
 
+// The first layer on the matrix cores: implicit GEMM with K = 9 rows (c,ky) x 8 (kx 0..2, five zeros) padded to 5 k16-steps -- the
+// MFMA work is a rounding error (62 % of it multiplies zeros), what counts is that it leaves the VALU form's 27 FMAs per output behind
+// (0.88 ms, compute-bound) for the 1.65 GB of bf16 output.  A lane's eight k values are eight consecutive pixels of a bf16 row image in
+// LDS; two copies of every row, one shifted by a pixel, keep the window of an odd output column 4-byte aligned.  Workgroup = 4 waves =
+// 4 output rows x 128 columns x 64 channels.  Image and weights are rounded to bf16 (the VALU form rounds only its output).
+constexpr int F1_ROWS = 4, F1_NR = F1_ROWS + 2, F1_RL = 136;
+__global__ __launch_bounds__(256, 2) void conv3x3_first_bf16_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                         const float* __restrict__ bias, unsigned short* __restrict__ y,
+                                                                         int B, int H, int W, int relu) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* xin = (unsigned short*)smem_raw;                          // [2 copies][3][F1_NR][F1_RL]: copy k, index j <-> ix = ox0 + j - 1 + k
+  unsigned short* wB = xin + 2 * 3 * F1_NR * F1_RL;                          // [10 rows][64 co][8]
+  float* Tall = (float*)(wB + 10 * 64 * 8);                                 // [4 waves][32][65]
+  const int gx = (W + 127) / 128, gy = (H + F1_ROWS - 1) / F1_ROWS;
+  const int xh = blockIdx.x % gx, yb = (blockIdx.x / gx) % gy, n = blockIdx.x / (gx * gy);
+  const int ox0 = 128 * xh, oy0 = F1_ROWS * yb;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // every load of the staging is issued before the first LDS store (39 + 20 per thread: one dependent round trip instead of ~8)
+  constexpr int NXI = (2 * 3 * F1_NR * F1_RL + 255) / 256, NWI = (10 * 64 * 8) / 256;
+  float xv[NXI], wv[NWI];
+#pragma unroll
+  for (int k = 0; k < NXI; k++) {
+    const int i = tid + 256 * k;
+    const int j = i % F1_RL, rr = (i / F1_RL) % F1_NR, c = (i / (F1_RL * F1_NR)) % 3, cp = i / (F1_RL * F1_NR * 3);
+    const int iy = oy0 - 1 + rr, ix = ox0 + j - 1 + cp;
+    const bool ok = i < 2 * 3 * F1_NR * F1_RL && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    xv[k] = ok ? x[(((long)n * 3 + c) * H + iy) * W + ix] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < NWI; k++) {
+    const int i = tid + 256 * k;
+    const int kx = i & 7, co = (i >> 3) & 63, row = i >> 9;
+    wv[k] = (row < 9 && kx < 3) ? w[(co * 9 + row) * 3 + kx] : 0.f;          // w[co][c][ky][kx], row = c*3 + ky
+  }
+#pragma unroll
+  for (int k = 0; k < NXI; k++)
+    if (tid + 256 * k < 2 * 3 * F1_NR * F1_RL) xin[tid + 256 * k] = f2bf(xv[k]);
+#pragma unroll
+  for (int k = 0; k < NWI; k++) wB[tid + 256 * k] = f2bf(wv[k]);
+  __syncthreads();
+  const int j = lane & 31, h = lane >> 5;
+  const int lx = 32 * wave + j;
+  const int cpy = lx & 1, jst = lx - cpy;                                    // odd columns read the shifted copy one slot earlier
+  float* T = Tall + wave * 32 * 65;
+  const int tq = lane & 7, tp = lane >> 3;                                   // read-back: 8 lanes x 16 B = the 128 bytes of one pixel
+  float bvv[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) bvv[e] = bias ? bias[8 * tq + e] : 0.f;
+  for (int oyl = 0; oyl < F1_ROWS; oyl++) {
+    const int oy = oy0 + oyl;
+    if (oy >= H) break;                                                      // uniform
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+      const int row = 2 * s + h, rowc = row < 9 ? row : 8;                   // row 9 does not exist: its weights are zero
+      const int c = rowc / 3, ky = rowc % 3;
+      const unsigned int* ap = (const unsigned int*)(xin + ((cpy * 3 + c) * F1_NR + oyl + ky) * F1_RL + jst);
+      const u32x4 av = {ap[0], ap[1], ap[2], ap[3]};
+      const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const bf16x8 b = __builtin_bit_cast(bf16x8, *(const u32x4*)(wB + ((row * 64) + 32 * t + j) * 8));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) T[((r & 3) + 8 * (r >> 2) + 4 * h) * 65 + t * 32 + j] = acc[t][r];
+#pragma unroll
+    for (int c8 = 0; c8 < 4; c8++) {                                        // a store instruction = 8 whole pixels (8 x 128 B)
+      const int pr = tp + 8 * c8, oxs = ox0 + 32 * wave + pr;
+      us8 ov;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float v = T[pr * 65 + 8 * tq + e] + bvv[e];
+        if (relu) v = fmaxf(v, 0.f);
+        ov[e] = f2bf(v);
+      }
+      if (oxs < W) *(us8*)(y + ((((long)n * H + oy) * W + oxs) * 64 + 8 * tq)) = ov;
+    }
+  }
+}
+
 // AdaptiveAvgPool2d((7,7)) + flatten in NCHW order: bf16 NHWC [B,H,W,C] -> fp32 [B, C*49]
 __global__ void adaptive_avgpool7_flatten_bf16_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
   const long total = (long)B * C * 49;
@@ -506,6 +598,20 @@ int lctvqa_conv3x3_first_nchw_bf16(const float* x_nchw, const float* w_oihw, con
   hipLaunchKernelGGL(conv3x3_first_bf16_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, x_nchw, w_oihw, bias,
                      (unsigned short*)y_nhwc, B, H, W, Cout, relu);
   return lct_check_launch("conv3x3_first_bf16");
+}
+
+// the first layer on the matrix cores (Cout = 64 only): image and weights rounded to bf16, fp32 accumulation
+int lctvqa_conv3x3_first_nchw_bf16_mfma(const float* x_nchw, const float* w_oihw /* [64][3][3][3] */, const float* bias, void* y_nhwc,
+                                        int B, int H, int W, int relu, void* stream) {
+  LCT_REQUIRE(B > 0 && H > 0 && W > 0, "conv3x3_first_bf16_mfma: bad shape");
+  LCT_REQUIRE(((uintptr_t)y_nhwc & 15) == 0, "conv3x3_first_bf16_mfma: output must be 16-byte aligned");
+  const size_t lds = (size_t)(2 * 3 * F1_NR * F1_RL + 10 * 64 * 8) * 2 + (size_t)4 * 32 * 65 * 4;
+  auto k = conv3x3_first_bf16_mfma_kernel;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const long grid = (long)B * ((H + F1_ROWS - 1) / F1_ROWS) * ((W + 127) / 128);
+  LCT_REQUIRE(grid < (1L << 31), "conv3x3_first_bf16_mfma: grid too large");
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, x_nchw, w_oihw, bias, (unsigned short*)y_nhwc, B, H, W, relu);
+  return lct_check_launch("conv3x3_first_bf16_mfma");
 }
 
 int lctvqa_adaptive_avgpool7_flatten_bf16(const void* x_nhwc, float* y, int B, int H, int W, int C, void* stream) {

@@ -846,7 +846,9 @@ def _vgg_features_forward_bf16(image, plan, cache):
         Cout, Cin = w.shape[0], w.shape[1]
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=dev)
-        if li == 0:
+        if li == 0 and Cout == 64:                           # matrix cores: bf16 image and weights, fp32 accumulation
+            lib('conv3x3_first_nchw_bf16_mfma', image, w, b, out, B, H, W, 1)
+        elif li == 0:
             lib('conv3x3_first_nchw_bf16', image, w, b, out, B, H, W, Cout, 1)
         else:
             wp = _packed_weights(w, 'bf16', Cout * Cin * 9, lambda dst: lib('conv3x3_bf16_pack_weights', w, dst, Cout, Cin), cache,

@@ -62,6 +62,26 @@ def test_first_layer_and_avgpool_bf16(hip_lib):
     assert rel_err(flat, ref) < 1e-6
 
 
+@pytest.mark.parametrize('B,H,W', [(3, 40, 36), (2, 224, 224), (1, 5, 131), (2, 7, 37)])
+def test_first_layer_on_matrix_cores_bf16(hip_lib, B, H, W):
+    """conv1_1 as an implicit GEMM on bf16 MFMA against torch on the SAME bf16-rounded image and weights; widths that are odd, not a
+    multiple of 32, and wider than one 128-column workgroup; heights that are not a multiple of the 4-row group."""
+    lib = hip_lib
+    g = torch.Generator().manual_seed(H * W)
+    img = torch.randn(B, 3, H, W, generator=g).to(DEV)
+    w = (torch.randn(64, 3, 3, 3, generator=g) * 0.3).to(DEV)
+    b = (torch.randn(64, generator=g) * 0.1).to(DEV)
+    for relu in (1, 0):
+        y = torch.full((B, H, W, 64), float('nan'), dtype=torch.bfloat16, device=DEV)
+        lib('conv3x3_first_nchw_bf16_mfma', img, w, b, y, B, H, W, relu)
+        ref = F.conv2d(img.bfloat16().double(), w.bfloat16().double(), b.double(), padding=1)
+        if relu:
+            ref = F.relu(ref)
+        got = y.double().permute(0, 3, 1, 2)
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() <= 6e-3 * ref.abs().max().item()
+
+
 def test_w_model_bf16_trunk_against_reference_logits(hip_lib):
     """BASELINE configs[1]'s model at B=4 with the trunk in bf16 against the reference's fp32 logits (golden w_full_b4.pt).
     Tolerance: 3e-2 of the largest logit (16 layers of bf16 activations, 2^-9 relative rounding each; measured ~6e-3);
