@@ -94,13 +94,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
   const int NCH = Cin / 8;
   const int PLIVE = (TH + 2 + G) * RS;
 
-  // ---- raw patch staging: piece pc = quad * AROUNDS + round, this wave takes pc = wave, wave + 8, ...
+  // ---- raw patch staging, this wave takes pieces pc = wave, wave + 8, ...
+  // RAWPX: raw[pixel][8 channels]; a piece = 32 halo pixels x both channel quads: lane = (pixel lane>>1, quad lane&1) reads 32
+  // contiguous bytes per pixel with its neighbour, so a DMA instruction touches 32 cache lines instead of 64 (-2..-4 % on the 56x56
+  // and 28x28 layers; same-process A/B).  Planar raw[quad][pixel][4] (piece = quad * AROUNDS + round, 64 pixels of one quad) is kept
+  // for the 32x16-pixel patch, whose transform reads lose more to the 32-byte pixel stride than its DMA gains (+1..2 %).
+  constexpr bool RAWPX = !(TY == 8 && TX == 4);
   int aoff[NPC], pdst[NPC];
 #pragma unroll
   for (int k = 0; k < NPC; k++) {
     const int pc = wave + 8 * k;
-    const int q = pc / AROUNDS, r = pc % AROUNDS;
-    const int p = r * 64 + lane;
+    const int r = pc % AROUNDS;
+    const int q = RAWPX ? (lane & 1) : pc / AROUNDS;
+    const int p = RAWPX ? pc * 32 + (lane >> 1) : r * 64 + lane;
     const int hr = p / RS, hx = p % RS;
     const int xx = x0 - 1 + hx;
     int yv = y0 - 1 + hr;
@@ -108,7 +114,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
     while (yv > Hp) { yv -= (Hp + 1); n++; }
     const bool ok = (p < PLIVE) && (yv >= 0) && (yv < H) && (n < Btot) && (xx >= 0) && (xx < W);
     aoff[k] = ok ? (((n * H + yv) * W + xx) * Cin + q * 4) : -1;
-    pdst[k] = (pc < 2 * AROUNDS && r * 64 < PLIVE) ? (q * PLANE + r * 256) : -1;      // wave-uniform
+    if (RAWPX) pdst[k] = (pc < 2 * AROUNDS && pc * 32 < PLIVE) ? pc * 256 : -1;     // wave-uniform
+    else pdst[k] = (pc < 2 * AROUNDS && r * 64 < PLIVE) ? ((pc / AROUNDS) * PLANE + r * 256) : -1;
   }
   auto stage_raw = [&](int chunk, float* dst) __attribute__((always_inline)) {
 #pragma unroll
@@ -122,26 +129,27 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
 
   // ---- input transform: thread = (tile tt, channel quad tc), wave = output column nu (waves 6, 7: none)
   const int tt = lane & 31, tc = lane >> 5;
-  int tbase = tc * PLANE;
+  constexpr int PXS = RAWPX ? 8 : 4;                            // floats between neighbouring pixels of the raw patch
+  int tbase = RAWPX ? tc * 4 : tc * PLANE;
   if (tt < NTILE) {
     const int ty = tt / TX, tx = tt % TX;
     const int g = min((y0 + 4 * ty) / Hp, G);                    // image boundaries (= shared zero rows) above this tile;
                                                                 // tiles past the last image (never stored) stay inside the patch
-    tbase = tc * PLANE + ((4 * ty + g) * RS + 4 * tx) * 4;
+    tbase += ((4 * ty + g) * RS + 4 * tx) * PXS;
   }
   const int vwoff = tc * 128 + tt * 4;                          // + (xi*6+nu)*256
   f32x4 Tc[6];                                                  // (d B)[y][nu], y = 0..5
   // row yy of the 6x6 patch: the pixels column NU of d B needs, combined with that column of B (= row of B^T).  Load and
   // combine sit in one slice: the LDS latency in between is covered by the SIMD's other wave.
   auto trow = [&](const float* rw, int yy, int nu) __attribute__((always_inline)) {
-    const float* p0 = rw + tbase + yy * RS * 4;
+    const float* p0 = rw + tbase + yy * RS * PXS;
     f32x4 r;
     if (nu == 0 || nu == 5) {                                                   // 4 d0 - 5 d2 + d4  |  4 d1 - 5 d3 + d5
-      const float* p = p0 + (nu == 0 ? 0 : 4);
-      const f32x4 l0 = *(const f32x4*)(p), l1 = *(const f32x4*)(p + 8), l2 = *(const f32x4*)(p + 16);
+      const float* p = p0 + (nu == 0 ? 0 : PXS);
+      const f32x4 l0 = *(const f32x4*)(p), l1 = *(const f32x4*)(p + 2 * PXS), l2 = *(const f32x4*)(p + 4 * PXS);
       r = 4.f * l0 - 5.f * l1 + l2;
     } else {
-      const f32x4 l0 = *(const f32x4*)(p0 + 4), l1 = *(const f32x4*)(p0 + 8), l2 = *(const f32x4*)(p0 + 12), l3 = *(const f32x4*)(p0 + 16);
+      const f32x4 l0 = *(const f32x4*)(p0 + PXS), l1 = *(const f32x4*)(p0 + 2 * PXS), l2 = *(const f32x4*)(p0 + 3 * PXS), l3 = *(const f32x4*)(p0 + 4 * PXS);
       if (nu == 1) r = (l3 - 4.f * l1) + (l2 - 4.f * l0);                       // (d4 - 4 d2) + (d3 - 4 d1)
       else if (nu == 2) r = (l3 - 4.f * l1) - (l2 - 4.f * l0);
       else if (nu == 3) r = (l3 - l1) + 2.f * (l2 - l0);                        // (d4 - d2) + 2 (d3 - d1)
