@@ -49,10 +49,11 @@ def parse():
                     help='run the frozen trunk of a batch as this many sub-batches on streams of their own (pipelined mode).  2 is '
                          '1.4 %% faster (tails of one part filled by the other); default 1 because overlapping conv kernels make the '
                          'per-launch durations behind the roofline fields meaningless')
-    ap.add_argument('--head-after', type=int, default=8,
+    ap.add_argument('--head-after', type=int, default=None,
                     help='pipelined mode: hold the head of batch i until the trunk of batch i+1 has launched past conv layer N '
-                         '(1..16; 0 = start it as soon as its own trunk is done).  Default 8 = after conv3_4: the head shares the chip with the '
-                         '28x28 layers; 0.8 %% faster than 0, 12 and later leave it too little time')
+                         '(1..16; 0 = start it as soon as its own trunk is done).  Default 8 = after conv3_4 (fp32): the head shares the chip with the '
+                         '28x28 layers; 0.8 %% faster than 0, 12 and later leave it too little time; 4 = after conv2_2 with the bf16 trunk '
+                         '(11.78 vs 11.90 ms/step)')
     ap.add_argument('--classifier-with-head', action='store_true',
                     help='pipelined mode: the trunk stream runs vgg19.features + avgpool only; the classifier (fc6, fc7 + dropouts) runs with '
                          'the head on the main stream (same work per step, other stream)')
@@ -74,7 +75,10 @@ def parse():
                     help="--workload resnet_gru: train the ResNet-152 trunk too (batch-statistics BatchNorm, full backward) instead of the frozen trunk")
     ap.add_argument('--conv-algo', default=None, choices=['winograd', 'winograd2', 'direct'],
                     help='trunk convolution algorithm (default: LCTVQA_CONV_ALGO or winograd = F(4x4,3x3) / F(2x2,3x3) / direct by shape; all fp32)')
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.head_after is None:
+        args.head_after = 4 if args.dtype == 'bf16' else 8
+    return args
 
 
 def host_threads():
