@@ -40,23 +40,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const unsigned short*
   const long m0 = (long)m_tile * BM;
   const int n0 = n_tile * BN;
   const int S = K / 32;
-  long aoff[4];                                                 // element offset of this lane's rows of plane `wave` (or -1)
+  // Operand tiles in LDS as rows of 64 B (32 bf16 = four 16-byte slots), the slot XOR-swizzled by (row>>2)&3 (conflict-free
+  // ds_read_b128 of 32 consecutive rows).  The DMA writes LDS linearly, so the swizzle is applied to the source: lane = (row lane>>2,
+  // slot lane&3) fetches slot (lane&3) ^ ((row>>2)&3); the four lanes of a row cover its 64 contiguous bytes and an instruction
+  // touches 16 cache lines (the planar form -- lane = row, one 16-byte slot per instruction -- touched 64).
+  const int rl = lane >> 2, sq = (lane & 3) ^ ((rl >> 2) & 3);
+  long aoff[4];                                                 // element offset of this lane's slot in rows 16 (wave + 4 r) + rl (or -1)
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const long row = m0 + r * 64 + lane;
-    aoff[r] = row < M ? row * lda + wave * 8 : -1;
+    const long row = m0 + 16 * (wave + 4 * r) + rl;
+    aoff[r] = row < M ? row * lda + sq * 8 : -1;
   }
   long boff[NT2];
 #pragma unroll
-  for (int r = 0; r < NT2; r++) boff[r] = (long)(n0 + r * 64 + lane) * ldb + wave * 8;
+  for (int r = 0; r < NT2; r++) boff[r] = (long)(n0 + 16 * (wave + 4 * r) + rl) * ldb + sq * 8;
   auto stage = [&](int s, float* ad, float* bd) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const float* src = aoff[r] >= 0 ? (const float*)(A + aoff[r] + (long)s * 32) : g_zero_page_gb;
-      glds16(src, ad + wave * APL + r * 256);
+      glds16(src, ad + (wave + 4 * r) * 256);
     }
 #pragma unroll
-    for (int r = 0; r < NT2; r++) glds16((const float*)(B + boff[r] + (long)s * 32), bd + wave * BPL + r * 256);
+    for (int r = 0; r < NT2; r++) glds16((const float*)(B + boff[r] + (long)s * 32), bd + (wave + 4 * r) * 256);
   };
   f32x16 acc[MT][NT2];
 #pragma unroll
@@ -68,8 +73,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const unsigned short*
   stage(0, abuf, bbuf);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const int abase = h * APL + (wm * MT * 32 + j) * 4;
-  const int bbase = h * BPL + (wn * NT2 * 32 + j) * 4;
+  const int swz = (j >> 2) & 3;
+  const int fo[2] = {((0 + h) ^ swz) << 2, ((2 + h) ^ swz) << 2};  // swizzled slot of half-step kk = 0, 1 (floats)
+  const int abase = (wm * MT * 32 + j) * 16;
+  const int bbase = (wn * NT2 * 32 + j) * 16;
   for (int s = 0; s < S; s++) {
     if (s + 1 < S) stage(s + 1, abuf + ((s + 1) & 1) * ASZ, bbuf + ((s + 1) & 1) * BSZ);
     const float* ab = abuf + (s & 1) * ASZ + abase;
@@ -78,10 +85,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const unsigned short*
     for (int kk = 0; kk < 2; kk++) {
       bf16x8 bf[NT2];
 #pragma unroll
-      for (int nn = 0; nn < NT2; nn++) bf[nn] = __builtin_bit_cast(bf16x8, *(const f32x4*)(bb + kk * 2 * BPL + nn * 128));
+      for (int nn = 0; nn < NT2; nn++) bf[nn] = __builtin_bit_cast(bf16x8, *(const f32x4*)(bb + nn * 512 + fo[kk]));
 #pragma unroll
       for (int m = 0; m < MT; m++) {
-        const bf16x8 af = __builtin_bit_cast(bf16x8, *(const f32x4*)(ab + kk * 2 * APL + m * 128));
+        const bf16x8 af = __builtin_bit_cast(bf16x8, *(const f32x4*)(ab + m * 512 + fo[kk]));
 #pragma unroll
         for (int nn = 0; nn < NT2; nn++) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nn], acc[m][nn], 0, 0, 0);
       }
