@@ -26,6 +26,10 @@ __device__ __attribute__((aligned(64))) float g_zero_page_bf16[64];
 #ifndef BF16_EPI_LDS
 #define BF16_EPI_LDS 1
 #endif
+// 1: halo patch staged pixel-major with swizzled 16-byte slots (16 cache lines per DMA instruction); 0: planar, one octet plane per wave
+#ifndef BF16_HALO_PX
+#define BF16_HALO_PX 1
+#endif
 
 __device__ __forceinline__ unsigned short f2bf(float v) {
   const __bf16 b = (__bf16)v;                                   // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
@@ -105,18 +109,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const unsigned sho
   const int S = NCH * 9;
   const int PLIVE = (TH + 2 + G) * TWP;
 
-  int aoff[AROUNDS];                                  // element offset of this lane's 16-B slot of halo pixel r*64 + lane (plane = wave)
+  // Halo patch in LDS, two forms.  HPX (the 256-pixel patches, MT = 4): [pixel][four 16-byte slots of 8 channels], the slot XOR-swizzled
+  // by (pixel>>2)&3 (conflict-free ds_read_b128 of consecutive pixels).  The DMA writes LDS linearly, so the swizzle is applied to the
+  // source: a piece = 16 pixels x 4 slots, lane = (pixel lane>>2, slot lane&3) fetches channel octet (lane&3) ^ ((pixel>>2)&3): the four
+  // lanes of a pixel read its 64 contiguous bytes and an instruction touches 16 cache lines (-3 ... -12 % per layer).  Planar (the
+  // 224-pixel patches, MT = 7: lane = pixel, one octet plane per wave, 64 lines per instruction): their 63 per-tap fragment offsets
+  // would not fit the register file beside 112 accumulators (measured: 50 spilled VGPRs, +25 %).
+  constexpr bool HPX = BF16_HALO_PX && MT <= 4;
+  int aoff[AROUNDS];                                  // element offset of this lane's 16-byte slot in round r (or -1)
 #pragma unroll
   for (int r = 0; r < AROUNDS; r++) {
-    const int p = r * 64 + lane;
+    const int p = HPX ? (wave + 4 * r) * 16 + (lane >> 2) : r * 64 + lane;
+    const int sq = HPX ? ((lane & 3) ^ ((p >> 2) & 3)) : wave;
     const int hr = p / TWP, hx = p % TWP;
     const int xx = x0 - 1 + hx;
     int yv = y0 - 1 + hr;
     int n = n0img;
     while (yv > H) { yv -= (H + 1); n++; }
     const bool ok = (p < PLIVE) && (hx < TW + 2) && (yv >= 0) && (yv < H) && (n < Btot) && (xx >= 0) && (xx < W);
-    aoff[r] = ok ? (((n * H + yv) * W + xx) * Cin + wave * 8) : -1;
+    aoff[r] = ok ? (((n * H + yv) * W + xx) * Cin + sq * 8) : -1;
   }
+  // LDS float offset of this lane's fragment of sub-tile m: HPX: afr[m][tap] for half-step kk = 0 (kk = 1: the same offset ^ 8);
+  // planar: base[m] + tap and plane offsets that are immediates
+  int afr[HPX ? MT : 1][9];
   int base[MT];
 #pragma unroll
   for (int m = 0; m < MT; m++) {
@@ -125,6 +140,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const unsigned sho
     const int yy = y0 + ty;
     const int g = (yy >= H) + (yy >= 2 * H);
     base[m] = ((ty + g) * TWP + tx) * 4 + h * PLANE;
+    if (HPX) {
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const int P = (ty + g + t / 3) * TWP + tx + t % 3;
+        afr[HPX ? m : 0][t] = P * 16 + ((h ^ ((P >> 2) & 3)) << 2);
+      }
+    }
   }
   const int bbase = (wn * NT2) * 512 + h * 128 + j * 4;
   const unsigned short* wsrc = wp + (long)(n_tile * NP) * S * 1024;      // [NP pieces][S][1024 bf16]
@@ -132,9 +154,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const unsigned sho
   auto stage_a = [&](int chunk, float* dst) {
 #pragma unroll
     for (int r = 0; r < AROUNDS; r++) {
-      if (r * 64 < PLIVE) {
+      if (HPX ? ((wave + 4 * r) * 16 < PLIVE) : (r * 64 < PLIVE)) {                   // wave-uniform
         const float* src = (aoff[r] >= 0) ? (const float*)(x + (long)aoff[r] + chunk * 32) : g_zero_page_bf16;
-        glds16(src, dst + wave * PLANE + r * 256);
+        glds16(src, HPX ? dst + (wave + 4 * r) * 256 : dst + wave * PLANE + r * 256);
       }
     }
   };
@@ -178,7 +200,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const unsigned sho
         for (int nn = 0; nn < NT2; nn++) bf[nn] = __builtin_bit_cast(bf16x8, *(const f32x4*)(wb + nn * 512 + kk * 256));
 #pragma unroll
         for (int m = 0; m < MT; m++) {
-          const bf16x8 af = __builtin_bit_cast(bf16x8, *(const f32x4*)(ab + base[m] + tapoff + kk * 2 * PLANE));
+          const bf16x8 af = __builtin_bit_cast(bf16x8, *(const f32x4*)(HPX ? ab + (afr[HPX ? m : 0][tap] ^ (kk ? 8 : 0))
+                                                                           : ab + base[m] + tapoff + kk * 2 * PLANE));
 #pragma unroll
           for (int nn = 0; nn < NT2; nn++) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nn], acc[m][nn], 0, 0, 0);
         }
