@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict_
   const long row = blockIdx.x;
   const float* x = logits + row * ld;
   float mx = -INFINITY;
+#pragma unroll 8
   for (int e = threadIdx.x; e < N; e += blockDim.x) mx = fmaxf(mx, x[e]);
   mx = wave_max(mx);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict_
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   __syncthreads();
   float se = 0.f, st = 0.f, stx = 0.f;
+#pragma unroll 4
   for (int e = threadIdx.x; e < N; e += blockDim.x) {
     float v = x[e];
     se += expf(v - mx);
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict_
   if (kind == 0) { lab = labels[row]; if (lab < 0 || lab >= N) lab = 0; }
   if (threadIdx.x == 0) row_loss[row] = (kind == 0) ? (lse - x[lab]) : (st * lse - stx);
   if (dlogits) {
+#pragma unroll 4
     for (int e = threadIdx.x; e < N; e += blockDim.x) {
       float p = expf(x[e] - lse);
       float g = (kind == 0) ? (p - (e == lab ? 1.f : 0.f)) : (p * st - target[row * ldt + e]);
@@ -279,8 +282,18 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
   const long row = blockIdx.x;
   float best = -INFINITY;
   int idx = 0x7fffffff;
-  for (int e = threadIdx.x; e < N; e += blockDim.x) {
-    float v = x[row * ld + e];
+  const float* xr = x + row * ld;
+  int e = threadIdx.x;
+  for (; e + 7 * 256 < N; e += 8 * 256) {                       // eight loads in flight, compared in index order (a 17 858-wide row was
+    float v[8];                                                  // a chain of 70 dependent HBM latencies per thread)
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = xr[e + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (v[u] > best || (v[u] == best && e + 256 * u < idx)) { best = v[u]; idx = e + 256 * u; }
+  }
+  for (; e < N; e += 256) {
+    float v = xr[e];
     if (v > best || (v == best && e < idx)) { best = v; idx = e; }
   }
 #pragma unroll
