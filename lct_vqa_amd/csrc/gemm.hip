@@ -31,8 +31,19 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, long rs, 
     r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
   } else if (MODE == LD_KSCALAR) {
     const int row = row0 + (tid >> 1), k = k0 + (tid & 1) * 8;
+    if (ks == 1 && (rs & 1) == 0 && (kend & 1) == 0 && ((uintptr_t)P & 7) == 0) {
+      // K-contiguous rows that are only 8-byte aligned (row length even, not a multiple of 4: QV = 17 858): four 8-byte loads
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int i = 0; i < 8; i++) r[i] = (row < nrows && k + i < kend) ? P[(long)row * rs + (long)(k + i) * ks] : 0.f;
+      for (int i = 0; i < 8; i += 2) {
+        f32x2 v = {0.f, 0.f};
+        if (row < nrows && k + i < kend) v = *(const f32x2*)(P + (long)row * rs + k + i);
+        r[i] = v[0]; r[i + 1] = v[1];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) r[i] = (row < nrows && k + i < kend) ? P[(long)row * rs + (long)(k + i) * ks] : 0.f;
+    }
   } else {
     const int k = k0 + (tid >> 4);
 #pragma unroll
