@@ -11,6 +11,7 @@ class Architect(object):
         self.model, self.args = model, args
         self.exp_zero_grad = 6 if args.qst_only else 0
         self.optimizer = bilevel.arch_optimizer(model.arch_parameters(), args.arch_learn_rate, args.arch_wt_decay)
+        self.trace = None      # set to a dict to have the next step leave its intermediates there (parity tests)
         self._twins = {}       # the virtual-step twins of the previous step, re-used (bilevel.virtual_step)
 
     def step(self, img_train, qst_train, label_train, img_valid, qst_valid, label_valid, eta, network_optimizer=None,
@@ -41,4 +42,6 @@ class Architect(object):
         dalpha, v = g[:len(ahead_alphas)], g[len(ahead_alphas):]
         implicit = bilevel.fd_grad(weights, v, lambda: bilevel.grads(self._train_loss(model, img_train, qst_train, label_train),
                                                                     model.arch_parameters()))
+        if self.trace is not None:
+            self.trace.update(dalpha_direct=dalpha, v=v, implicit=implicit)
         return [d - eta * i for d, i in zip(dalpha, implicit)]

@@ -152,10 +152,11 @@ def lct_qst_encoder(question, img_feat, P, num_layers=1, prefix='qst_encoder.',
     return qf, qst_out
 
 
-def lct_generate_tokens(img_feat, P, max_length=30, prefix='qst_encoder.', tok_head='fc2'):
+def lct_generate_tokens(img_feat, P, max_length=30, prefix='qst_encoder.', tok_head='fc2', margins=None):
     """basic_vqa/models_lct.py:124-157 (QstEncoder.generate), deterministic=True.
     Step-0 input = tanh(embedding(2)); later inputs = embedding(pred) WITHOUT tanh
-    (models_lct.py:137-138 vs :153-154)."""
+    (models_lct.py:137-138 vs :153-154).  ``margins``: a list that receives the [B] top-2 gap of every step's logits
+    (fixture generation: how decisive each greedy choice was)."""
     B = img_feat.shape[0]
     H = P[prefix + 'lstm.weight_hh_l0'].shape[1]
     emb = P[prefix + 'word2vec.weight']
@@ -172,6 +173,9 @@ def lct_generate_tokens(img_feat, P, max_length=30, prefix='qst_encoder.', tok_h
         h = torch.sigmoid(o) * torch.tanh(c)
         prob = F.linear(torch.tanh(h), P[f'{prefix}{tok_head}.weight'], P[f'{prefix}{tok_head}.bias'])
         pred = torch.argmax(prob, 1)
+        if margins is not None:
+            top2 = prob.topk(2, dim=1).values
+            margins.append(top2[:, 0] - top2[:, 1])
         toks[:, t] = pred
         cur = emb[pred]
     return toks

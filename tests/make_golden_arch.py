@@ -294,23 +294,63 @@ def main(mode):
         for a in m.arch_parameters():
             a.data.copy_(torch.randn_like(a) * 0.3)
         no_dropout(m.train())
-        img, qst, lab = data(30, 2, 50, 40)
-        vimg, vqst, vlab = data(31, 2, 50, 40)
+        start = {k: v.clone() for k, v in m.state_dict().items()}
+        arch0 = [a.detach().clone() for a in m.arch_parameters()]
+
+        def reset():
+            m.load_state_dict(start)
+            for a, r0 in zip(m.arch_parameters(), arch0):
+                a.data.copy_(r0)
+                a.grad = None
+            m.zero_grad()
+
+        # same reasoning as basic_two_level: keep the first pair of batches at which the reference's own finite-difference
+        # term is the same under r * (1 + k * 1e-6), k = -4 ... 4, in BOTH modes (qst_only False / True)
+        for seed in range(30, 80, 2):
+            img, qst, lab = data(seed, 2, 50, 40)
+            vimg, vqst, vlab = data(seed + 1, 2, 50, 40)
+            spread = 0.0
+            for qst_only in (False, True):
+                reset()
+                probe = Architect(m, types.SimpleNamespace(arch_learn_rate=6e-4, arch_wt_decay=1e-3, qst_only=qst_only))
+                unrolled = probe._compute_unrolled_model(img, qst, lab, 1e-3, None)
+                unrolled._loss(vimg, vqst, vlab, qst_only).backward()
+                vec = [p.grad.data if p.grad is not None else torch.zeros_like(p) for p in unrolled.parameters()]
+                base = probe._hessian_vector_product(vec, img, qst, lab)
+                spread = max([spread] + [float((a - b).abs().max() / b.abs().max()) for k in range(-4, 5)
+                                         for a, b in zip(probe._hessian_vector_product(vec, img, qst, lab, r=1e-2 * (1 + k * 1e-6)), base)])
+            print('data seeds', seed, seed + 1, 'spread of the reference HVP under r * (1 +- 4e-6):', spread, flush=True)
+            if spread < 5e-4:
+                break
+        else:
+            raise SystemExit('no stable probe point found')
+        reset()
         out = {'dims': dims, 'seed': 10, 'state': small(m.state_dict()), 'arch': [a.detach().clone() for a in m.arch_parameters()],
-               'train': (img, qst, lab), 'valid': (vimg, vqst, vlab)}
+               'train': (img, qst, lab), 'valid': (vimg, vqst, vlab), 'data_seeds': (seed, seed + 1), 'hvp_self_spread': spread}
         ans, qo = m(img, qst)
         out.update(ans=ans.detach(), qst_out=qo.detach())
+
+        class Traced(Architect):
+            def _hessian_vector_product(self, vector, *a, **k):
+                self.tr['dalpha_direct'] = [p.grad.detach().clone() for p in self.unrolled.arch_parameters()]
+                res = super()._hessian_vector_product(vector, *a, **k)
+                self.tr['implicit'] = [g.detach().clone() for g in res]
+                return res
+
+            def _compute_unrolled_model(self, *a, **k):
+                self.unrolled = super()._compute_unrolled_model(*a, **k)
+                return self.unrolled
+
         for qst_only in (False, True):
-            m.load_state_dict({**m.state_dict(), **out['state']})
-            for a, r in zip(m.arch_parameters(), out['arch']):
-                a.data.copy_(r)
-                a.grad = None
+            reset()
             args = types.SimpleNamespace(arch_learn_rate=6e-4, arch_wt_decay=1e-3, qst_only=qst_only)
-            arch = Architect(m, args)
+            arch = Traced(m, args)
+            arch.tr = {}
             out[f'state_before_step_{int(qst_only)}'] = small(m.state_dict())
             arch.optimizer.zero_grad()
             arch._backward_step_unrolled(img, qst, lab, vimg, vqst, vlab, 1e-3, None)
             out[f'arch_grads_{int(qst_only)}'] = [a.grad.detach().clone() for a in m.arch_parameters()]
+            out[f'trace_{int(qst_only)}'] = dict(arch.tr)
             arch.optimizer.step()
             out[f'arch_after_{int(qst_only)}'] = [a.detach().clone() for a in m.arch_parameters()]
         torch.save(out, os.path.join(GOLD, 'arch_vqa.pt'))

@@ -1,0 +1,146 @@
+"""The fused MixedOp edge kernels (lct_vqa_amd/csrc/mixed_edge.hip) against the CPU oracle (oracle/darts_oracle._mixed_op =
+reference basic_vqa/pcdarts/model_search.py:22-55 with the edge's beta scale and node sum of :87), NOT against the
+per-primitive HIP path: at the map sizes the darts_vqa encoder runs at 224x224 input (224 / 112 / 56 pixels, C = 16 / 32 / 64,
+both strides) and at ragged multi-tile maps (tile rows and columns that are not multiples of the 8x32 / 8x16 tile, horizontal
+and vertical halo seams between tiles, the persistent multi-tile loop), in train and eval mode, with and without a running
+node sum.  Checked: output, running statistics, dx, d alpha, d beta, d prev and every weight gradient."""
+import pytest
+import torch
+
+from _util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+TOL = 1e-4
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).cpu()
+
+
+# (C, stride, B, H, W): the encoder's own edges at a 224x224 image (cell 0: C=16 @224; cell 1: C=32, 224->112 on the reduction
+# edges and 112 inside; cell 2: C=64, 112->56 and 56; cell 3: C=64 @56), then ragged maps several tiles wide and high
+ENCODER_SHAPES = [(16, 1, 1, 224, 224), (32, 2, 1, 224, 224), (32, 1, 2, 112, 112), (64, 2, 1, 112, 112), (64, 1, 2, 56, 56)]
+RAGGED_SHAPES = [(16, 1, 2, 40, 72), (16, 2, 2, 40, 72), (32, 1, 2, 20, 68), (32, 2, 1, 20, 68), (64, 1, 1, 18, 50), (64, 2, 2, 36, 44),
+                 (16, 1, 1, 9, 33), (64, 1, 3, 7, 7)]
+
+
+def _case(hip_lib, C, stride, B, H, W, training, with_prev, seed):
+    from lct_vqa_amd import darts_ops as D
+    from lct_vqa_amd.basic_vqa import config
+    from lct_vqa_amd.basic_vqa.pcdarts import model_search as MS
+    from oracle import darts_oracle as DO
+    config.DEVICE = torch.device(DEV)
+    assert D.FUSED_EDGE and hip_lib.query('mixed_edge_supported', B, H, W, C, stride), 'the fused kernels must take this shape'
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    op = MS.MixedOp(C, stride)
+    for m in op.modules():                                        # non-trivial running statistics (the eval case reads them)
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.3, generator=g)
+            m.running_var.uniform_(0.5, 1.5, generator=g)
+    P = {'e.' + k: v.detach().clone() for k, v in op.state_dict().items()}
+    names = [n for n, _ in op.named_parameters()]
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.softmax(torch.randn(8, generator=g), 0)
+    beta = torch.rand(1, generator=g) + 0.5
+    Ho, Wo = H // stride, W // stride
+    prev = torch.randn(B, C, Ho, Wo, generator=g) if with_prev else None
+    gout = torch.randn(B, C, Ho, Wo, generator=g)
+
+    # oracle (CPU, torch autograd over the restated reference arithmetic)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), beta.clone().requires_grad_()
+    Pg = {k: (v.clone().requires_grad_(True) if k[2:] in names else v) for k, v in P.items()}
+    pr = prev.clone().requires_grad_() if with_prev else None
+    ns = {}
+    ref = br * DO._mixed_op(xr, wr, Pg, 'e', stride, training, ns)
+    if with_prev:
+        ref = pr + ref
+    ins = [xr, wr, br] + ([pr] if with_prev else []) + [Pg['e.' + n] for n in names]
+    gref = torch.autograd.grad(ref, ins, gout)
+
+    # HIP: one MixedEdgeFn node
+    mod = op.to(DEV).train(training)
+    xd, wd, bd = nhwc(x).requires_grad_(), w.to(DEV).requires_grad_(), beta.to(DEV).requires_grad_()
+    pd = nhwc(prev).requires_grad_() if with_prev else None
+    node = pd * 1.0 if with_prev else None                       # non-leaf: the edge accumulates into it in place
+    y = mod(xd, wd, node, bd)
+    assert type(y.grad_fn).__name__.startswith('MixedEdgeFn'), type(y.grad_fn).__name__
+    gins = [xd, wd, bd] + ([pd] if with_prev else []) + [p for _, p in mod.named_parameters()]
+    ghip = torch.autograd.grad(y, gins, nhwc(gout))
+
+    bad = {}
+    e = rel_err(nchw(y), ref)
+    if not e < TOL:
+        bad['out'] = e
+    labels = ['dx', 'dalpha', 'dbeta'] + (['dprev'] if with_prev else []) + names
+    for lab, a, r in zip(labels, ghip, gref):
+        a = nchw(a) if a.dim() == 4 and lab in ('dx', 'dprev') else a.cpu()
+        e = rel_err(a.reshape(r.shape), r)
+        if not e < TOL:
+            bad[lab] = e
+    # 'none' (position 0) carries no gradient in either implementation beyond the mul(0.) of the oracle: d alpha[0] = 0
+    if training:
+        sd = mod.state_dict()
+        for k, v in ns.items():
+            e = rel_err(sd[k[2:]], v)
+            if not e < 1e-5:
+                bad['buf ' + k] = e
+        for k, v in sd.items():
+            if k.endswith('num_batches_tracked'):
+                assert int(v) == 1, k
+    else:
+        sd = mod.state_dict()
+        for k, v in P.items():
+            if v.is_floating_point():
+                assert torch.equal(sd[k[2:]].cpu(), v), k           # eval mode leaves every buffer and parameter alone
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('C,stride,B,H,W', ENCODER_SHAPES)
+def test_fused_edge_at_encoder_shapes_vs_oracle(hip_lib, C, stride, B, H, W):
+    _case(hip_lib, C, stride, B, H, W, True, True, 100 + C + stride)
+    _case(hip_lib, C, stride, B, H, W, False, False, 200 + C + stride)
+
+
+@pytest.mark.parametrize('C,stride,B,H,W', RAGGED_SHAPES)
+@pytest.mark.parametrize('training,with_prev', [(True, False), (True, True), (False, True)])
+def test_fused_edge_at_ragged_multi_tile_maps_vs_oracle(hip_lib, C, stride, B, H, W, training, with_prev):
+    _case(hip_lib, C, stride, B, H, W, training, with_prev, 300 + C + stride + H)
+
+
+def test_fused_edge_gradient_through_a_strided_slice_of_the_cell_output(hip_lib):
+    """The node's gradient normally arrives as a channel slice of the cell's concatenated output (rows ldd apart): the
+    kernels take it by stride.  Two edges feeding one node, the node concatenated with another tensor, against the oracle."""
+    from lct_vqa_amd.basic_vqa import config
+    from lct_vqa_amd.basic_vqa.pcdarts import model_search as MS
+    from oracle import darts_oracle as DO
+    config.DEVICE = torch.device(DEV)
+    g = torch.Generator().manual_seed(7)
+    torch.manual_seed(7)
+    C, B, H, W = 32, 2, 24, 40
+    e0, e1 = MS.MixedOp(C, 1), MS.MixedOp(C, 1)
+    P = {f'a.{k}': v.detach().clone() for k, v in e0.state_dict().items()}
+    P.update({f'b.{k}': v.detach().clone() for k, v in e1.state_dict().items()})
+    x0, x1 = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    other = torch.randn(B, C, H, W, generator=g)
+    w0, w1 = torch.softmax(torch.randn(8, generator=g), 0), torch.softmax(torch.randn(8, generator=g), 0)
+    b = torch.softmax(torch.randn(2, generator=g), 0)
+    gout = torch.randn(B, 2 * C, H, W, generator=g)
+    xr0, xr1 = x0.clone().requires_grad_(), x1.clone().requires_grad_()
+    ns = {}
+    node = b[0] * DO._mixed_op(xr0, w0, P, 'a', 1, True, ns) + b[1] * DO._mixed_op(xr1, w1, P, 'b', 1, True, ns)
+    ref = torch.cat([other, node], 1)
+    g0, g1 = torch.autograd.grad(ref, [xr0, xr1], gout)
+    e0, e1 = e0.to(DEV).train(), e1.to(DEV).train()
+    xd0, xd1 = nhwc(x0).requires_grad_(), nhwc(x1).requires_grad_()
+    nd = e0(xd0, w0.to(DEV), None, b[0:1].to(DEV))
+    nd = e1(xd1, w1.to(DEV), nd, b[1:2].to(DEV))
+    out = torch.cat([nhwc(other), nd], 3)
+    assert rel_err(nchw(out), ref) < TOL
+    d0, d1 = torch.autograd.grad(out, [xd0, xd1], nhwc(gout))
+    assert rel_err(nchw(d0), g0) < TOL and rel_err(nchw(d1), g1) < TOL

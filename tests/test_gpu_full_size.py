@@ -110,3 +110,87 @@ def test_full_size_conv_layers_agree_across_algorithms_and_are_linear(hip_lib, H
     lhs = run('wino4', 0.5 * x + z, 0, 0, None)
     rhs = 0.5 * run('wino4', x, 0, 0, None) + run('wino4', z, 0, 0, None)
     assert rel_err(lhs, rhs) < 1e-4                               # three F(4x4,3x3) evaluations, each within 3e-5
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3]'s examiner (EF) model at its own size against the REFERENCE's run (tests/golden/ef_full_b4.pt, made by
+# tests/make_golden_full.py from reference basic_vqa/models_lct.py:200-257): B=4, 224x224, T=14, QV=17 858, A=3129.
+def _ef_full(hip_lib):
+    from _util import load, checksum, close_sum
+    from lct_vqa_amd.basic_vqa import models_lct, config
+    config.DEVICE = torch.device(DEV)
+    config.ARCH_TYPE = 'fixed'
+    fx = load('ef_full_b4.pt')
+    torch.manual_seed(fx['seed'])
+    m = models_lct.VqaModel(pretrained=True, **fx['dims'])
+    for k, v in m.state_dict().items():                           # seed-for-seed the reference's initial parameters
+        assert close_sum(checksum(v), fx['param_checksums'][k]), k
+    torch.manual_seed(fx['data_seed'])
+    img = torch.randn(fx['B'], 3, 224, 224)
+    assert close_sum(checksum(img), fx['image_checksum'])
+    return fx, m.to(DEV).eval(), img.to(DEV)
+
+
+def _check_ef_outputs(fx, ans, qo, tol, margin_gate):
+    from _util import checksum
+    assert rel_err(ans, fx['eval_ans']) < tol
+    assert torch.equal(ans.argmax(1).cpu(), fx['ans_argmax'])     # smallest top-2 gap of the fixture: 0.12 of the largest logit
+    assert qo.shape == (fx['B'], fx['T'], fx['dims']['qst_vocab_size'])
+    amax = fx['qst_out_absmax']
+    assert (qo[:, :, ::97].cpu() - fx['qst_out_sample']).abs().max().item() < tol * amax
+    assert (qo.max(2).values.cpu() - fx['qst_out_rowmax']).abs().max().item() < tol * amax
+    cs, ref = checksum(qo), fx['qst_out_checksum']
+    assert abs(cs[1] - ref[1]) < tol * ref[1]                      # sum |.| over all 1 000 048 logits
+    # per-token argmax wherever the reference's own top-2 gap exceeds the stated gate (9 of the 56 positions have gaps
+    # below 1e-3 -- down to 3e-5 -- of logits of size 0.09: ties at fp32 resolution are not parity failures)
+    decisive = fx['qst_out_top2_margin'] > margin_gate
+    assert decisive.float().mean() > 0.5
+    assert torch.equal(qo.argmax(2).cpu()[decisive], fx['qst_out_argmax'][decisive])
+
+
+def test_ef_full_b4_against_reference_goldens(hip_lib):
+    """fp32: logits <= 1e-3 (north_star), answer argmax and the 30 greedy ids per sample bit-exact, loss, gradient checksums."""
+    from _util import checksum
+    fx, m, img = _ef_full(hip_lib)
+    qst, lab = fx['question'].to(DEV), fx['label'].to(DEV)
+    with torch.no_grad():
+        ans, qo = m(img, qst)
+        gq, ga = m.generate(img)
+    _check_ef_outputs(fx, ans, qo, 1e-3, 1e-4 * fx['qst_out_absmax'])
+    assert torch.equal(gq.cpu(), fx['gen_qst'])                    # smallest greedy top-2 gap 3.4e-4 = 3.7e-3 of the logits
+    assert rel_err(ga, fx['gen_ans']) < 1e-3
+    loss = m._loss(img, qst, lab)
+    assert rel_err(loss, fx['loss']) < 1e-5
+    named = list(m.named_parameters())
+    grads = torch.autograd.grad(loss, [p for _, p in named], allow_unused=True)
+    assert sum(g is None for g in grads) == fx['num_none_grads'] == 36
+    for (k, _), g in zip(named, grads):
+        if g is None:
+            continue
+        cs, ref = checksum(g), fx['grad_checksums'][k]
+        assert abs(cs[1] - ref[1]) < 1e-3 * ref[1], k              # sum |g|
+        assert abs(cs[0] - ref[0]) < 1e-3 * ref[1], k              # sum g, on the scale of sum |g|
+        assert abs(float(g.abs().max()) - fx['grad_absmax'][k]) < 1e-3 * fx['grad_absmax'][k], k
+
+
+def test_ef_full_b4_bf16_against_reference_goldens(hip_lib):
+    """The same fixture under set_compute_dtype('bf16') (BASELINE configs[3] is a bf16 configuration; the reference is fp32
+    only, so its fp32 outputs are the target).  Tolerance 3e-2 of the largest logit (bf16 activations / operands, fp32
+    accumulation; the token head's K = 512 products of bf16-rounded operands carry 2^-9 relative error each), identical
+    answer argmax, identical per-token argmax where the reference's top-2 gap exceeds that tolerance, and the reference's
+    generated ids (the greedy decode always runs in fp32: it emits integers)."""
+    from lct_vqa_amd import ops
+    fx, m, img = _ef_full(hip_lib)
+    qst, lab = fx['question'].to(DEV), fx['label'].to(DEV)
+    prev = ops.set_compute_dtype('bf16')
+    try:
+        with torch.no_grad():
+            ans, qo = m(img, qst)
+            gq, ga = m.generate(img)
+        loss = m._loss(img, qst, lab)
+    finally:
+        ops.set_compute_dtype(prev)
+    _check_ef_outputs(fx, ans, qo, 3e-2, 3e-2 * fx['qst_out_absmax'])
+    assert torch.equal(gq.cpu(), fx['gen_qst'])
+    assert rel_err(ga, fx['gen_ans']) < 3e-2
+    assert rel_err(loss, fx['loss']) < 1e-3

@@ -85,3 +85,29 @@ def test_darts_oracle_against_reference_network():
         assert rel_err(a, fx['param_grads'][n]) < 1e-4, n
     for k, v in fx['running_after'].items():
         assert rel_err(ns[k], v) < 1e-6, k
+
+
+def test_ef_full_b4_oracle_against_reference():
+    """BASELINE configs[3]'s examiner model at full size (tests/make_golden_full.py ran reference models_lct.VqaModel):
+    the oracle on the same seeded parameters and inputs."""
+    fx = load('ef_full_b4.pt')
+    from lct_vqa_amd.basic_vqa import models_lct, config
+    from _util import checksum, close_sum
+    config.ARCH_TYPE = 'fixed'
+    config.DEVICE = torch.device('cpu')
+    torch.manual_seed(fx['seed'])
+    m = models_lct.VqaModel(pretrained=True, **fx['dims'])
+    P = {k: v.detach() for k, v in m.state_dict().items()}
+    assert set(P) == set(fx['param_checksums'])
+    for k, cs in fx['param_checksums'].items():
+        assert close_sum(checksum(P[k]), cs), k
+    torch.manual_seed(fx['data_seed'])
+    img = torch.randn(fx['B'], 3, 224, 224)
+    assert close_sum(checksum(img), fx['image_checksum'])
+    with torch.no_grad():
+        ans, qo = O.ef_model_forward(img, fx['question'], P, None, True)
+        gq, ga = O.ef_generate(img, P, None, True, fx['gen_qst'].shape[1])
+    assert rel_err(ans, fx['eval_ans']) < 1e-5 and torch.equal(ans.argmax(1), fx['ans_argmax'])
+    assert torch.equal(qo.argmax(2), fx['qst_out_argmax'])
+    assert (qo[:, :, ::97] - fx['qst_out_sample']).abs().max() < 1e-5 * fx['qst_out_absmax']
+    assert torch.equal(gq, fx['gen_qst']) and rel_err(ga, fx['gen_ans']) < 1e-5
