@@ -144,3 +144,125 @@ def test_fused_edge_gradient_through_a_strided_slice_of_the_cell_output(hip_lib)
     assert rel_err(nchw(out), ref) < TOL
     d0, d1 = torch.autograd.grad(out, [xd0, xd1], nhwc(gout))
     assert rel_err(nchw(d0), g0) < TOL and rel_err(nchw(d1), g1) < TOL
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4] at its own image size: the PC-DARTS search network and the darts_vqa model at 224x224
+def test_search_network_at_224_vs_oracle(hip_lib):
+    """Network(16, 512, 4) (reference model_search.py:94-181) on a 224x224 batch of 2 against the CPU oracle (itself pinned to
+    the reference's Network by tests/golden/darts_net.pt): eval output, train-mode output, alpha / beta gradients, the
+    gradients of a spread of weights from every cell, and every BatchNorm running statistic.  All 56 edges run the fused
+    kernels on maps of 224 / 112 / 56 pixels."""
+    from lct_vqa_amd import darts_ops as D
+    from lct_vqa_amd.basic_vqa import config
+    from lct_vqa_amd.basic_vqa.pcdarts.model_search import Network
+    from oracle import darts_oracle as DO
+    config.DEVICE = torch.device(DEV)
+    assert D.FUSED_EDGE
+    g = torch.Generator().manual_seed(11)
+    torch.manual_seed(11)
+    net = Network(16, 512, 4)
+    for a in net.arch_parameters():
+        a.data.copy_(0.3 * torch.randn(a.shape, generator=g))
+    for n, b in net.named_buffers():
+        if n.endswith('running_mean'):
+            b.normal_(0, 0.1, generator=g)
+        elif n.endswith('running_var'):
+            b.uniform_(0.5, 1.5, generator=g)
+    P = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    arch = [a.detach().cpu().clone() for a in net.arch_parameters()]
+    img = torch.randn(2, 3, 224, 224, generator=g)
+    wgt = torch.randn(2, 256 * 49, generator=g)
+    names = ['stem.0.weight', 'stem.1.weight', 'cells.0.preprocess1.op.1.weight', 'cells.0._ops.0._ops.4.op.1.weight',
+             'cells.0._ops.13._ops.7.op.2.weight', 'cells.1.preprocess0.op.1.weight', 'cells.1._ops.0._ops.3.conv_1.weight',
+             'cells.1._ops.1._ops.5.op.5.weight', 'cells.1._ops.9._ops.6.op.1.weight', 'cells.2.preprocess0.conv_2.weight',
+             'cells.2._ops.2._ops.4.op.6.weight', 'cells.2._ops.6._ops.5.op.2.weight', 'cells.3.preprocess0.conv_1.weight',
+             'cells.3._ops.5._ops.7.op.1.weight', 'cells.3._ops.13._ops.4.op.2.weight']
+    assert all(n in P for n in names)
+    ref_ev = DO.network_forward(img, P, arch, False)
+    Pg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in P.items()}
+    ag = [a.clone().requires_grad_(True) for a in arch]
+    ns = {}
+    ref_tr = DO.network_forward(img, Pg, ag, True, ns)
+    ref_g = torch.autograd.grad((ref_tr * wgt).sum(), ag + [Pg[n] for n in names])
+
+    net = net.to(DEV)
+    for a, r in zip(net.arch_parameters(), arch):
+        a.data.copy_(r)
+    net.eval()
+    with torch.no_grad():
+        ev = net(img.to(DEV))
+        ev2 = net(img.to(DEV))
+        one = net(img[1:2].to(DEV).contiguous())
+    assert rel_err(ev, ref_ev) < 1e-4
+    assert torch.equal(ev, ev2)                                   # deterministic
+    assert rel_err(one, ev[1:2]) < 1e-5                           # eval mode: a sample does not depend on its batch
+    net.train()
+    tr = net(img.to(DEV))
+    assert rel_err(tr, ref_tr) < 1e-4
+    pd = dict(net.named_parameters())
+    got = torch.autograd.grad((tr * wgt.to(DEV)).sum(), list(net.arch_parameters()) + [pd[n] for n in names])
+    for a, r in zip(got[:4], ref_g[:4]):
+        assert rel_err(a, r) < 1e-3
+    for n, a, r in zip(names, got[4:], ref_g[4:]):
+        assert rel_err(a, r) < 1e-3, n
+    sd = net.state_dict()
+    for k, v in ns.items():
+        assert rel_err(sd[k], v) < 1e-4, k
+
+
+def test_darts_vqa_model_at_224(hip_lib):
+    """darts_vqa VqaModel(img_encoder_type='darts') (reference darts_vqa/vqa_model.py:286-364) at BASELINE configs[4]'s
+    shapes, B=2: against the oracle's encoder + LCT question encoder + fusion head on the same parameters (eval mode), a
+    deterministic train-mode loss and gradients, the fused edge kernels equal to the per-primitive kernels at this size, and
+    a gradient for every parameter."""
+    from lct_vqa_amd import darts_ops as D, ops
+    from lct_vqa_amd.darts_vqa import config, vqa_model
+    from lct_vqa_amd.basic_vqa import config as bconfig
+    from oracle import darts_oracle as DO, vqa_oracle as O
+    config.DEVICE = bconfig.DEVICE = torch.device(DEV)
+    dims = dict(embed_size=512, qst_vocab_size=17858, ans_vocab_size=3129, word_embed_size=300, num_layers=1, hidden_size=512)
+    g = torch.Generator().manual_seed(12)
+    torch.manual_seed(12)
+    m = vqa_model.VqaModel(img_encoder_type='darts', **dims)
+    for a in m.arch_parameters():
+        a.data.copy_(0.3 * torch.randn(a.shape, generator=g))
+    P = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    arch = [a.detach().cpu().clone() for a in m.arch_parameters()]
+    img = torch.randn(2, 3, 224, 224, generator=g)
+    qst = torch.randint(0, dims['qst_vocab_size'], (2, 14), generator=g)
+    qst[:, 0] = 2
+    lab = torch.randint(0, dims['ans_vocab_size'], (2,), generator=g)
+    with torch.no_grad():                                         # oracle: vqa_model.py:48-66, 103-122 (fc1 = token head), 340-349
+        feat = DO.network_forward(img, P, arch, False, prefix='img_encoder.darts.')
+        f = torch.nn.functional.linear(feat, P['img_encoder.fc.weight'], P['img_encoder.fc.bias'])
+        f = f / f.norm(p=2, dim=1, keepdim=True)
+        qf, qo_ref = O.lct_qst_encoder(qst, f, P, feat_head='fc2', tok_head='fc1')
+        ans_ref = O.fusion_head(f, qf, P)
+    m = m.to(DEV)
+    for a, r in zip(m.arch_parameters(), arch):
+        a.data.copy_(r)
+    m.eval()
+    with torch.no_grad():
+        ans, qo = m(img.to(DEV), qst.to(DEV))
+    assert rel_err(ans, ans_ref) < 1e-3 and rel_err(qo, qo_ref) < 1e-3
+    assert torch.equal(ans.argmax(1).cpu(), ans_ref.argmax(1))
+    m.train()
+    params = list(m.parameters()) + list(m.arch_parameters())
+    res = {}
+    for fused in (True, True, False):
+        prev = D.set_fused_edge(fused)
+        try:
+            with ops.dropout_disabled():
+                loss = m._loss(img.to(DEV), qst.to(DEV), lab.to(DEV))
+            gr = torch.autograd.grad(loss, params, allow_unused=True)
+        finally:
+            D.set_fused_edge(prev)
+        assert all(x is not None for x in gr)
+        res.setdefault(fused, []).append((loss.detach(), gr))
+    (l0, g0), (l1, g1) = res[True]
+    assert torch.equal(l0, l1) and all(torch.equal(a, b) for a, b in zip(g0, g1))      # deterministic, gradients included
+    lp, gp = res[False][0]
+    assert rel_err(l0, lp) < 1e-5
+    for a, b in zip(g0, gp):
+        assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + 1e-12
