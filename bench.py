@@ -272,6 +272,7 @@ def main():
     if args.workload == 'resnet_gru':
         from lct_vqa_amd.basic_vqa import models_ext
         model = models_ext.VqaModelResNetGRU(pretrained=not args.train_encoder, **DIMS).to(dev).train()
+        model.img_encoder.model.cache_folded_weights = not args.train_encoder    # frozen trunk: nothing ever writes its tensors
     else:
         model = models.VqaModel(**DIMS).to(dev).train()
     opt = FusedAdam(model.trainable_parameters(), lr=config.LEARNING_RATE, flatten=True)

@@ -54,7 +54,15 @@ class ResNet152Trunk(nn.Module):
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
-        self._folded = {}                                        # id(conv) -> (versions, w', shift): the trunk is frozen
+        # id(conv) -> (versions, w', shift), kept only on request (``cache_folded_weights``, the analogue of
+        # vgg.VGG.cache_packed_weights; bench.py sets it for its frozen trunk).  By default every no_grad forward re-folds:
+        # what changes a trunk's tensors between two of them -- the flat-arena optimizer's kernel, bn_wide_fwd's
+        # running-statistics update, the architects' lctvqa_multi_copy refills -- writes through raw pointers and never moves
+        # a version counter, so a trainable trunk evaluated under no_grad (the driver's validation pass between training
+        # epochs, experiment.py:150-176, 292-303) would otherwise be served the first validation's weights for ever.
+        self.cache_folded_weights = False
+        self._folded = {}
+        self._cache_ok = False
 
     def _make_layer(self, planes, blocks, stride):
         down = None
@@ -70,7 +78,7 @@ class ResNet152Trunk(nn.Module):
         key = id(conv)
         ver = (conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
                conv.weight.data_ptr())
-        hit = self._folded.get(key)
+        hit = self._folded.get(key) if self._cache_ok else None
         if hit is not None and hit[0] == ver:
             return hit[1], hit[2]
         w = ops._chk(conv.weight)
@@ -78,7 +86,8 @@ class ResNet152Trunk(nn.Module):
         wf = torch.empty_like(w)
         shift = torch.empty(Cout, dtype=torch.float32, device=w.device)
         lib('fold_bn', w, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), Cout, w.numel() // Cout, wf, shift)
-        self._folded[key] = (ver, wf, shift)
+        if self._cache_ok:
+            self._folded[key] = (ver, wf, shift)
         return wf, shift
 
     def _conv1x1(self, x, conv, bn, relu, identity=None):
@@ -96,8 +105,8 @@ class ResNet152Trunk(nn.Module):
     def _conv3x3(self, x, conv, bn, stride):
         B, H, W, _ = x.shape
         wf, shift = self._fold(conv, bn)
-        y = ops._conv_block(x, wf, shift, B, H, W, 0, cache=True)  # conv + shift + ReLU at stride 1 (the folded weights are
-                                                                   # this trunk's own frozen tensors: their packed form is kept)
+        # conv + shift + ReLU at stride 1; the packed form of the folded weights is kept only with the folded weights themselves
+        y = ops._conv_block(x, wf, shift, B, H, W, 0, cache=self._cache_ok)
         return y if stride == 1 else self._subsample(y)
 
     @staticmethod
@@ -141,7 +150,7 @@ class ResNet152Trunk(nn.Module):
         """(bf16 weights, fp32 shift) of a folded convolution: [Cout][Cin] rows for the GEMM, or the 3x3 kernel's packed layout."""
         wf, shift = self._fold(conv, bn)
         key = ('bf16', id(conv), packed3x3)
-        hit = self._folded.get(key)
+        hit = self._folded.get(key) if self._cache_ok else None
         if hit is not None and hit[0] is wf:
             return hit[1], shift
         Cout, Cin = wf.shape[0], wf.shape[1]
@@ -150,7 +159,8 @@ class ResNet152Trunk(nn.Module):
             lib('conv3x3_bf16_pack_weights', wf, wb, Cout, Cin)
         else:
             lib('cvt_f32_to_bf16', wf, wb, wf.numel())
-        self._folded[key] = (wf, wb)
+        if self._cache_ok:
+            self._folded[key] = (wf, wb)
         return wb, shift
 
     def _b_conv1x1(self, x, conv, bn, relu, identity=None):
@@ -222,8 +232,12 @@ class ResNet152Trunk(nn.Module):
         return feat
 
     def forward(self, image):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        trainable = any(p.requires_grad for p in self.parameters())
+        if torch.is_grad_enabled() and trainable:
             return self._forward_trainable(image)
+        self._cache_ok = bool(self.cache_folded_weights)
+        if not self._cache_ok and self._folded:
+            self._folded.clear()
         if ops.get_compute_dtype() == 'bf16' and image.shape[1] == 3:
             with torch.no_grad():
                 return self._forward_frozen_bf16(image)

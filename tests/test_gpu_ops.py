@@ -583,3 +583,57 @@ def test_gru_fwd_bwd_vs_torch(ops):
         got = torch.autograd.grad((od * 0.3).sum() + (hd * hd).sum(), [xd] + pd)
         for a, r in zip(got, ref):
             assert rel_err(a, r) < 1e-4
+
+
+def test_factory_optimizer_builds_its_arena_on_the_first_step(ops):
+    """plugin.adam (what model_factory.get_*_optimizer / factory.get_optimizer return) in the reference driver's order
+    (experiment.py:59-62 optimizers first, :120-123 ``.to(DEVICE)`` afterwards, :216-227 zero_grad / backward /
+    ``nn.utils.clip_grad_norm_`` / step): the flat arena appears at the first step and holds exactly the parameters that carry
+    a gradient, a step is ONE launch plan entry, parameters that get a gradient later are still updated, ``model.zero_grad()``
+    (gradients set to None behind the optimizer's back) is survived, and every parameter follows torch.optim.Adam."""
+    import torch.nn as nn
+    from lct_vqa_amd import plugin
+    torch.manual_seed(3)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.frozen = nn.Linear(6, 6)           # under no_grad in forward: never gets a gradient (the W model's VGG19)
+            self.a, self.b = nn.Linear(6, 7), nn.Linear(7, 5)
+            self.late = nn.Linear(5, 3)             # only reached from the third iteration on
+
+        def forward(self, x, use_late):
+            with torch.no_grad():
+                x = self.frozen(x)
+            y = self.b(torch.tanh(self.a(x)))
+            return self.late(y).sum() + y.sum() if use_late else y.square().sum()
+
+    net, ref = Net(), Net()
+    ref.load_state_dict(net.state_dict())
+    opt = plugin.adam(net, 1e-2)                   # on CPU parameters, like the driver
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    net = net.to(DEV)
+    assert opt.flat is None
+    for it in range(5):
+        x = torch.randn(4, 6)
+        if it == 3:
+            net.zero_grad()                         # sets every .grad to None behind the optimizer's back
+        else:
+            opt.zero_grad()
+        ropt.zero_grad()
+        net(x.to(DEV), it >= 2).backward()
+        ref(x, it >= 2).backward()
+        nn.utils.clip_grad_norm_(net.parameters(), 5)
+        nn.utils.clip_grad_norm_(ref.parameters(), 5)
+        if opt.flat is not None:
+            opt._reclaim()
+            assert len(opt._plan()) == 1            # one adam_step launch for the arena
+        opt.step()
+        ropt.step()
+        assert opt.flat is not None and len(opt.flat['params']) == 4 and net.frozen.weight.grad is None
+        for (n, p), (_, r) in zip(net.named_parameters(), ref.named_parameters()):
+            assert rel_err(p, r) < 1e-5, (it, n)
+    assert float(opt.state[net.late.weight]['step']) == 3.0 and float(opt.state[net.a.weight]['step']) == 5.0
+    sd = opt.state_dict()                           # still torch.optim.Adam's format
+    t = torch.optim.Adam(net.parameters(), lr=1e-2)
+    t.load_state_dict(sd)

@@ -256,3 +256,48 @@ def test_resnet152_trunk_bf16_vs_oracle(hip_lib, size):
     g, w = got.cpu().double(), want.double()
     for i in range(2):
         assert torch.corrcoef(torch.stack([g[i], w[i]]))[0, 1].item() > 0.999
+
+
+def test_trainable_trunk_under_no_grad_sees_the_optimizer_and_batchnorm_updates(hip_lib):
+    """Regression: train -> no_grad evaluation -> train -> no_grad evaluation of a TRAINABLE trunk, the order of
+    the reference's epoch loop (experiment.py:150-176: train(), then val() under no_grad).  The no_grad forward folds BatchNorm
+    into the convolutions; FusedAdam's kernel and the BatchNorm kernels change weights and running statistics through raw
+    pointers (no version counter moves), so a folded copy kept from the first evaluation would be served for ever.  The second
+    evaluation must equal the oracle on the UPDATED state_dict -- and differ from the first.  (``cache_folded_weights`` is the
+    opt-in for trunks nothing ever writes to; it is off here, as it is by default.)"""
+    from oracle import resnet_oracle
+    from lct_vqa_amd.resnet import ResNet152Trunk
+    from lct_vqa_amd.optim import FusedAdam
+    torch.manual_seed(17)
+    net = ResNet152Trunk()
+    _randomise_bn(net, 18)
+    net = net.to(DEV)
+    img = torch.randn(4, 3, 64, 64)
+    ev = torch.randn(2, 3, 64, 64)
+    opt = FusedAdam(list(net.parameters()), lr=1e-2, flatten=True)
+
+    def evaluate():
+        net.eval()
+        with torch.no_grad():
+            got = net(ev.to(DEV))
+        ref = resnet_oracle.resnet152().eval()
+        ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+        with torch.no_grad():
+            want = ref(ev)
+        return got, want
+
+    def train_step():
+        net.train()
+        opt.zero_grad()
+        net(img.to(DEV)).square().mean().backward()
+        opt.step(max_grad_norm=5.0)
+
+    got0, want0 = evaluate()
+    assert rel_err(got0, want0) < 2e-3
+    train_step()
+    got1, want1 = evaluate()
+    assert rel_err(want1, want0) > 1e-2                            # the step and the running statistics did move the function
+    assert rel_err(got1, want1) < 2e-3                             # ... and the no_grad path follows
+    train_step()
+    got2, want2 = evaluate()
+    assert rel_err(got2, want2) < 2e-3
