@@ -170,6 +170,26 @@ def self_launch(args):
     return subprocess.call(cmd)
 
 
+def dp_record(world, local, reducers):
+    """What lets a reader verify the N ranks of this line: transport, one entry per rank with the device it drives (gathered
+    over the process group itself), bucket layout, how many bucket all-reduces the backward hooks launched per step and the
+    time finish() waited for them (HIP events, timed region only).  Collective on every rank; None at world size 1."""
+    if world == 1:
+        return None
+    import torch.distributed as dist
+    from lct_vqa_amd import parallel
+    ranks = parallel.describe_ranks(local)
+    rec = {'backend': dist.get_backend(), 'rccl': '.'.join(map(str, torch.cuda.nccl.version())) if dist.get_backend() == 'nccl' else None,
+           'world': world, 'devices': ranks,
+           'distinct_devices': len({(r['bus'], r['uuid'], r['device']) for r in ranks}),
+           'rehearsal_one_gpu': os.environ.get('LCTVQA_REHEARSE_ONE_GPU') == '1'}
+    for i, r in enumerate(reducers):
+        d = r.describe()
+        rec.update({(k if i == 0 else f'{k}_{i}'): v for k, v in d.items()})
+    rec['allreduce_ms_per_step'] = sum(r.describe()['allreduce_wait_ms_per_step'] for r in reducers)
+    return rec
+
+
 def bench_darts_vqa(args, rank, world, dev, img, qst, lab):
     """BASELINE configs[4] (fp32 form, one GPU): the weight step of the darts_vqa driver with the PC-DARTS search encoder,
     K timed steps between the barriers; the architecture step (2-level, second order) is timed once beside it."""
@@ -207,11 +227,16 @@ def bench_darts_vqa(args, rank, world, dev, img, qst, lab):
     for _ in range(args.warmup):
         step()
     barrier()
+    if red is not None:
+        red.describe()
+        red.stats.update(steps=0, launched_by_hooks=0, launched_by_finish=0, wait_ms=0.0)
+        red.timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
+    dp = dp_record(world, dev.index, [red] if red is not None else [])
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -243,7 +268,7 @@ def bench_darts_vqa(args, rank, world, dev, img, qst, lab):
                             'frac': round(enc_bytes * B / (ms * 1e-3) / 8e12, 4), 'traffic': None,
                             'algorithmic_bytes_per_pair': enc_bytes,
                             'note': 'algorithmic bytes of the encoder edges only, over the WHOLE step time (LSTM, token head and torch glue included): a lower bound of the edge kernels\' own rate'},
-               'cpu_baseline': None}
+               'dp': dp, 'cpu_baseline': None}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -268,6 +293,17 @@ def main():
     config.DEVICE = dev
     config.ARCH_TYPE = 'fixed'
 
+    B = args.batch
+    g = torch.Generator().manual_seed(10 + rank)    # rank r uses seed 10+r for data
+    img = torch.randn(B, 3, 224, 224, generator=g).to(dev)
+    qst = torch.randint(DIMS['qst_vocab_size'], (B, 14), generator=g); qst[:, 0] = 2
+    qst = qst.to(dev)
+    lab = torch.randint(DIMS['ans_vocab_size'], (B,), generator=g).to(dev)
+    ops.manual_seed(10 + rank)
+
+    if args.workload == 'darts_vqa':                # its own model and optimizer: nothing of the W model is built beside it
+        return bench_darts_vqa(args, rank, world, dev, img, qst, lab)
+
     torch.manual_seed(10)                           # config.SEED: identical replicas on every rank
     if args.workload == 'resnet_gru':
         from lct_vqa_amd.basic_vqa import models_ext
@@ -279,17 +315,6 @@ def main():
     trainable = opt.flat['params']
     reducer = parallel.FlatGradReducer(trainable, opt.flat_grad, scale_fn=parallel.hip_scale) if world > 1 else None
 
-    B = args.batch
-    g = torch.Generator().manual_seed(10 + rank)    # rank r uses seed 10+r for data
-    img = torch.randn(B, 3, 224, 224, generator=g).to(dev)
-    qst = torch.randint(DIMS['qst_vocab_size'], (B, 14), generator=g); qst[:, 0] = 2
-    qst = qst.to(dev)
-    lab = torch.randint(DIMS['ans_vocab_size'], (B,), generator=g).to(dev)
-    ops.manual_seed(10 + rank)
-
-    if args.workload == 'darts_vqa':
-        return bench_darts_vqa(args, rank, world, dev, img, qst, lab)
-
     def step():
         opt.zero_grad()
         logits = model(img, qst)
@@ -300,6 +325,8 @@ def main():
         opt.step(max_grad_norm=config.GRAD_CLIP)
         return loss
 
+    ef_red = None
+    locals_ef_red = lambda: ef_red
     if args.workload == 'lct':
         # LCT stage 1 (EF model) + stage 2 (pseudo QA from EF.generate, W trained on real + pseudo tests)
         from lct_vqa_amd.basic_vqa import models_lct
@@ -343,6 +370,14 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    def arm_reducers():
+        # statistics of the timed region only
+        for r in (reducer, locals_ef_red()):
+            if r is not None:
+                r.describe()
+                r.stats.update(steps=0, launched_by_hooks=0, launched_by_finish=0, wait_ms=0.0)
+                r.timing(True)
 
     # The W model's VGG19 is frozen by construction (models.py:35-36; no optimizer or architect of this step holds its
     # parameters): keep its kernel-layout weights between steps instead of re-packing 15 layers per step.
@@ -434,6 +469,7 @@ def main():
             run_steps(args.warmup)
         ops.conv_timer_start()
         barrier()
+        arm_reducers()
         t0 = time.perf_counter()
         loss = run_steps(args.steps)
         for st in trunk_streams:
@@ -473,6 +509,7 @@ def main():
             run_steps(args.warmup)
         ops.conv_timer_start()
         barrier()
+        arm_reducers()
         t0 = time.perf_counter()
         loss = run_steps(args.steps)
         trunk_stream.synchronize()
@@ -483,12 +520,14 @@ def main():
             step()
         ops.conv_timer_start()                          # HIP events around every conv3x3 MFMA launch (same stream)
         barrier()
+        arm_reducers()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = step()
         barrier()
         dt = time.perf_counter() - t0
     conv = ops.conv_timer_stop()
+    dp = dp_record(world, local, [r for r in (reducer, ef_red) if r is not None])
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -585,6 +624,7 @@ def main():
         'model_flops_per_step': 39.48e9 * B if args.workload == 'w' else None,
         'model_tflops': round(39.48e9 * B / (ms * 1e-3) / 1e12, 2) if args.workload == 'w' else None,
         'roofline': roofline,
+        'dp': dp,
     }
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(args.cpu_steps)

@@ -47,10 +47,31 @@ class FlatGradReducer:
                 self.buckets[-1][1] = flat_grad.numel()
         self.handles = []
         self._hooks = []
+        # what a reader of the bench line needs to see that the collective ran: launches issued by the hooks (during
+        # backward) vs by finish() (stragglers), and the time finish() spent waiting (``timing(True)``: HIP events on the
+        # current stream around the waits when the buffer is in HBM, host clock otherwise)
+        self.stats = {'steps': 0, 'launched_by_hooks': 0, 'launched_by_finish': 0, 'wait_ms': 0.0}
+        self._timing, self._events = False, []
         if self.world > 1:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.reset()
+
+    def timing(self, on=True):
+        self._timing = bool(on)
+        return self
+
+    def describe(self):
+        """Summary for a benchmark record.  Drains the recorded events (synchronises)."""
+        if self._events:
+            torch.cuda.synchronize()
+            self.stats['wait_ms'] += sum(a.elapsed_time(b) for a, b in self._events)
+            self._events = []
+        st = self.stats
+        n = max(1, st['steps'])
+        return {'buckets': len(self.buckets), 'bucket_bytes': [(b[1] - b[0]) * self.flat.element_size() for b in self.buckets],
+                'steps': st['steps'], 'launched_during_backward_per_step': st['launched_by_hooks'] / n,
+                'launched_by_finish_per_step': st['launched_by_finish'] / n, 'allreduce_wait_ms_per_step': st['wait_ms'] / n}
 
     def _close(self, start, end, ids):
         b = len(self.buckets)
@@ -67,6 +88,7 @@ class FlatGradReducer:
         b = self.buckets[self.param_bucket[p]]
         b[2] -= 1
         if b[2] == 0:
+            self.stats['launched_by_hooks'] += 1
             self._launch(b)
 
     def _launch(self, b):
@@ -77,11 +99,27 @@ class FlatGradReducer:
         """Wait for every bucket (launching the ones whose hooks did not all fire, e.g. unused
         parameters), then average."""
         if self.world > 1:
+            ev = None
+            if self._timing:
+                if self.flat.is_cuda:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                else:
+                    import time
+                    t0 = time.perf_counter()
             for b in self.buckets:
-                if b[2] != 0:
+                if b[2] > 0:
+                    self.stats['launched_by_finish'] += 1
                     self._launch(b)
             for h in self.handles:
                 h.wait()
+            if self._timing:
+                if ev is not None:
+                    ev[1].record()
+                    self._events.append(ev)
+                else:
+                    self.stats['wait_ms'] += (time.perf_counter() - t0) * 1e3
+            self.stats['steps'] += 1
             if self.scale_fn is not None:
                 self.scale_fn(1.0 / self.world, self.flat)
             else:
@@ -95,28 +133,55 @@ def hip_scale(a, flat):
 
 
 def init_distributed():
-    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract) and bind this process
-    to its GPU.  Returns (rank, world, local_rank)."""
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract), bind this process to its GPU and bring up RCCL
+    (backend 'nccl').  Returns (rank, world, local_rank).  There is ONE way to a different transport: the explicit one-GPU
+    rehearsal ``LCTVQA_REHEARSE_ONE_GPU=1`` (every rank on device 0, gloo: RCCL refuses two ranks on one device; it exercises
+    hooks / buckets / barriers, not xGMI).  If RCCL cannot initialise, or its first all-reduce does not return the right sum,
+    this raises with RCCL's own error -- never a quiet fallback."""
     import os
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    # rehearsal on a 1-GPU box: every rank shares device 0 and the collective goes through gloo (RCCL refuses
-    # two ranks on one device); exercises hooks / buckets / barriers, not the xGMI transport
-    backend = os.environ.get('LCTVQA_DIST_BACKEND', 'nccl')
+    backend = 'nccl'
     if os.environ.get('LCTVQA_REHEARSE_ONE_GPU') == '1':
         local, backend = 0, 'gloo'
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
+        if backend == 'nccl' and local >= torch.cuda.device_count():
+            raise RuntimeError(f'rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPUs are visible '
+                               '(one process per GPU; set LCTVQA_REHEARSE_ONE_GPU=1 only to rehearse the control flow on one device)')
         torch.cuda.set_device(local)
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        try:
+            if backend == 'nccl':
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            probe = torch.full((4,), float(rank + 1), device=torch.device('cuda', local))
+            dist.all_reduce(probe, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            want = world * (world + 1) / 2.0
+            if not bool((probe == want).all()):
+                raise RuntimeError(f'first all-reduce returned {probe.tolist()}, expected {want}')
+        except Exception as e:
+            raise RuntimeError(f'rank {rank}/{world}: the {"RCCL (nccl)" if backend == "nccl" else backend} process group did not '
+                               f'come up on cuda:{local}: {type(e).__name__}: {e}') from e
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, world, local
+
+
+def describe_ranks(local):
+    """[{rank, device, name, bus}] gathered from every rank (rank order): which GPU each process really drives."""
+    import os
+    props = torch.cuda.get_device_properties(local)
+    me = {'rank': dist.get_rank() if dist.is_initialized() else 0, 'device': f'cuda:{local}', 'name': props.name,
+          'bus': getattr(props, 'pci_bus_id', None), 'uuid': str(getattr(props, 'uuid', '')) or None, 'pid': os.getpid()}
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [me]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, me)
+    return out
 
 
 def make_flat_grad(params):

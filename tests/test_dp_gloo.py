@@ -172,3 +172,54 @@ def test_architecture_step_under_dp_equals_the_large_batch_step(tmp_path):
     implicit = bilevel.fd_grad(w, g[1:], lambda: bilevel.grads(m._loss(x, y), m.arch_parameters()))
     ref = g[0] - 0.05 * implicit[0]
     assert torch.allclose(a0, ref, rtol=1e-9, atol=1e-12)
+
+
+def _w_arena_worker(rank, world, port, out):
+    """The W model's REAL trainable set (BASELINE configs[1]: 13 tensors, 21.05 M floats = 84 MB -> three 32 MiB buckets) in
+    FusedAdam's arena: the backward hooks must launch every bucket's all-reduce BEFORE finish() is called (that is the
+    overlap with backward), finish() only waits, and the averaged gradients are the large-batch ones."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lct_vqa_amd import parallel
+    from lct_vqa_amd.optim import FusedAdam
+    shapes = _w_trainable_shapes()
+    torch.manual_seed(21)
+    ps = [nn.Parameter(torch.randn(s) * 0.01) for s in shapes]
+    opt = FusedAdam(ps, lr=1e-3, flatten=True)
+    assert opt.flat_grad.numel() >= 21_045_883
+    red = parallel.FlatGradReducer(opt.flat['params'], opt.flat_grad).timing(True)
+    assert len(red.buckets) == 3
+    torch.manual_seed(100 + rank)
+    coef = [torch.randn(()) for _ in ps]
+    for it in range(2):
+        opt.zero_grad()
+        loss = sum((c * p).sum() + 0.5 * (rank + 1) * p.square().sum() for c, p in zip(coef, ps))
+        loss.backward()
+        assert all(b[2] == 0 for b in red.buckets) and len(red.handles) == 3       # all launched by the hooks, none left
+        red.finish()
+    d = red.describe()
+    assert d['steps'] == 2 and d['launched_during_backward_per_step'] == 3.0 and d['launched_by_finish_per_step'] == 0.0
+    assert d['buckets'] == 3 and sum(d['bucket_bytes']) == opt.flat_grad.numel() * 4 and d['allreduce_wait_ms_per_step'] >= 0.0
+    if rank == 0:
+        torch.save([[c for c in coef], [p.grad[..., :3].clone() for p in ps]], out)
+    else:
+        torch.save([c for c in coef], out + '.r1')
+    dist.destroy_process_group()
+
+
+def _w_trainable_shapes():
+    E, H, We, A, QV = 512, 512, 300, 3129, 17858
+    return [(E, 4096), (E,), (QV, We), (4 * H, We), (4 * H, H), (4 * H,), (4 * H,), (E, 2 * H), (E,), (A, E), (A,), (A, A), (A,)]
+
+
+def test_dp2_w_model_arena_three_buckets_launched_by_the_hooks(tmp_path):
+    assert sum(torch.Size(s).numel() for s in _w_trainable_shapes()) == 21_045_883     # = models.VqaModel(**bench.DIMS).trainable_parameters()
+    out = str(tmp_path / 'w.pt')
+    mp.spawn(_w_arena_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    coef0, grads = torch.load(out)
+    coef1 = torch.load(out + '.r1')
+    torch.manual_seed(21)
+    ps = [torch.randn(s) * 0.01 for s in _w_trainable_shapes()]
+    for p, g, c0, c1 in zip(ps, grads, coef0, coef1):
+        want = 0.5 * ((c0 + p) + (c1 + 2.0 * p))                  # mean over the two ranks of d loss_r / d p
+        assert torch.allclose(g, want[..., :3], rtol=1e-5, atol=1e-7)

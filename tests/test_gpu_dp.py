@@ -69,3 +69,21 @@ def test_bench_launches_its_own_ranks(hip_lib):
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 64 and out['scaling'] == 'weak'
     assert out['value'] > 0 and abs(out['value'] - 64 / (out['ms_per_step'] * 1e-3)) < 1e-2 * out['value']
     assert 0 < out['roofline']['frac'] <= 1.0
+    # the line carries what lets a reader verify its ranks: transport, one device entry per rank gathered over the group,
+    # bucket layout, all-reduces launched by the backward hooks, time finish() waited
+    dp = out['dp']
+    assert dp['world'] == 2 and dp['backend'] == 'gloo' and dp['rehearsal_one_gpu'] is True
+    assert [d['rank'] for d in dp['devices']] == [0, 1] and len({d['pid'] for d in dp['devices']}) == 2
+    assert dp['distinct_devices'] == 1                          # the rehearsal: both ranks on the one GPU, and the line says so
+    assert dp['buckets'] == 3 and dp['steps'] == 2 and dp['launched_during_backward_per_step'] == 3.0
+    assert dp['launched_by_finish_per_step'] == 0.0 and dp['allreduce_ms_per_step'] > 0.0
+
+
+def test_rccl_failure_is_loud(hip_lib):
+    """Two ranks asked to use RCCL on a box with ONE GPU (no rehearsal switch): the bench must exit non-zero naming the
+    cause -- never fall back to another transport and print a line."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                        '--batch', '8', '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert 'only 1 GPUs are visible' in r.stderr or 'did not come up' in r.stderr, r.stderr[-3000:]
