@@ -302,6 +302,28 @@ int lctvqa_copy_window_nhwc(const float* src, float* dst, int B, int Hs, int Ws,
 int lctvqa_gemm_bf16_supported(long M, int N, int K);
 int lctvqa_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, long M, int N, int K, const float* bias,
                      const void* addend, long ld_add, int act, int out_bf16, void* stream);
+/* ---- the heads under the bf16 compute dtype (BASELINE.json's bf16 configurations; fp32 master weights, fp32 accumulation, fp32
+ *      outputs).  What they replace: every nn.Linear product of reference basic_vqa/models.py:37,66,99-102 and models_lct.py:116,120
+ *      and the LSTM / GRU input projections (models.py:61), forward and both backward products, as NT GEMMs on bf16 copies:
+ *      lctvqa_cvt_pad_bf16 makes the (zero-padded, optionally transposed) bf16 operand, lctvqa_gemm_bf16x multiplies:
+ *        C[M][N] (fp32) = mask * mask_scale * act(A[M][K] . B[Np][K]^T + bias[n] + addend[m][n]),  act 0 none / 1 ReLU / 2 tanh,
+ *        K % 32 == 0 (zero padded), B padded to Np rows (Np % 64 == 0 >= N); few-tile problems split K into fp32 slabs in workspace.
+ *      lctvqa_linear_xent_bf16_{fwd,bwd}: the LCT token head Linear(H, QV) over all tokens fused with its cross entropy
+ *      (models_lct.py:118-120, 253-255): the [tokens, QV] logits never reach HBM.  fwd: loss = mean_m(lse[m] - logit[m][labels[m]]);
+ *      bwd: dl = (softmax - onehot) * g[0] / M as bf16 [M][Np] and transposed [Np][ld_dlT >= 256-padded M] (the A operands of
+ *      dX = dl . W and dW = dl^T . X), dbpart [2 * ceil(M/256)][Np] partial column sums (bias gradient).  Np % 128 == 0. ---- */
+long lctvqa_gemm_bf16x_workspace_bytes(long M, int N, int Np, int K);
+int lctvqa_gemm_bf16x(const void* A, long lda, const void* B, long ldb, float* C, long ldc, long M, int N, int Np, int K, const float* bias,
+                      const float* addend, long ld_add, int act, const uint8_t* mask, long ld_mask, float mask_scale, float* workspace,
+                      long workspace_bytes, void* stream);
+int lctvqa_cvt_pad_bf16(const float* src, long ld_src, int rows, int cols, void* dst, long ld_dst, int rows_pad, int cols_pad, int transpose,
+                        void* stream);
+long lctvqa_linear_xent_bf16_part_elems(long M, int Np);
+int lctvqa_linear_xent_bf16_fwd(const void* X, long ldx, const void* W, long ldw, const float* bias, const long* labels, long M, int N,
+                                int Np, int K, float* part, float* picked, float* lse, float* loss, void* stream);
+int lctvqa_linear_xent_bf16_bwd(const void* X, long ldx, const void* W, long ldw, const float* bias, const long* labels, const float* lse,
+                                const float* g, long M, int N, int Np, int K, void* dl, long ld_dl, void* dlT, long ld_dlT, float* dbpart,
+                                void* stream);
 int lctvqa_cvt_f32_to_bf16(const float* x, void* y, long n, void* stream);
 int lctvqa_cvt_bf16_to_f32(const void* x, float* y, long n, void* stream);
 int lctvqa_maxpool3x3_s2_bf16(const void* x, void* y, int B, int H, int W, int C, void* stream);

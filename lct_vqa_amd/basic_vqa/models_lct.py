@@ -72,7 +72,9 @@ class QstEncoder(nn.Module):
         torch.nn.init.zeros_(self.fc1.bias)
         torch.nn.init.zeros_(self.fc2.bias)
 
-    def forward(self, question, image_embedding):
+    def forward(self, question, image_embedding, token_loss=False):
+        """-> (question feature [B,E], token logits [B,T,QV]); with ``token_loss`` the second item is instead the scalar
+        CE(logits[:, :-1], question[:, 1:]) of models_lct.py:253-255, computed without materialising the logits."""
         B = image_embedding.shape[0]
         h0 = image_embedding.reshape(B, self.hidden_size)          # view(1,-1,H), L = 1
         qst_vec = ops.embed(question, self.word2vec.weight, True)  # [T,B,We]
@@ -80,6 +82,8 @@ class QstEncoder(nn.Module):
         qst_feature = ops.CatTanhFn.apply(hidden, cell)
         qst_feature = ops.linear(qst_feature, self.fc1.weight, self.fc1.bias)
         tout = ops.TanhFn.apply(out)                                # [T,B,H]
+        if token_loss:
+            return qst_feature, ops.token_head_loss(tout, self.fc2.weight, self.fc2.bias, question)
         qst_out = ops.linear(tout, self.fc2.weight, self.fc2.bias)  # [T,B,QV]
         return qst_feature, qst_out.transpose(0, 1)                 # [B,T,QV] view
 
@@ -170,6 +174,10 @@ class VqaModel(nn.Module):
 
     def _loss(self, images, questions, labels, conv_feature=None):
         """CE(ans) + CE(qst_out[:, :-1], qst[:, 1:]); <pad>=0 is not ignored (models_lct.py:250-257)."""
+        if ops.linear_xent_fused() and questions.shape[1] > 1:      # token head fused with its cross entropy: no [B,T,QV] tensor
+            img_feature = self._encode_image(images, conv_feature)
+            qst_feature, qst_loss = self.qst_encoder(questions, img_feature, token_loss=True)
+            return ops.cross_entropy(self._head(img_feature, qst_feature), labels) + qst_loss
         ans_out, qst_out = self(images, questions, conv_feature)
         ans_loss = ops.cross_entropy(ans_out, labels)
         qst = questions[:, 1:].flatten()

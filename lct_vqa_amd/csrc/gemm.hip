@@ -13,6 +13,7 @@
 // M-contiguous and 4-byte-aligned-only operands such as the reference's Linear(3129,3129));
 // LDS rows are 64 B with the 16-B chunk XOR-swizzled by ((row>>2)&3): conflict-free ds_read_b128.
 #include "common.h"
+#include "gemm_epi.h"
 
 enum { LD_KVEC = 0, LD_KSCALAR = 1, LD_MCONTIG = 2 };
 
@@ -70,21 +71,6 @@ __device__ __forceinline__ void store_tile(float* __restrict__ L, int tid, const
   }
 }
 
-struct GemmEpi {
-  // fused A-operand prologue of the fusion head (reference basic_vqa/models.py:96-98 feeding fc1):
-  //   A(m,k) := amask[m][k] ? ascale * tanh(A(m,k) * a2[m*a_ms + k*a_ks]) : 0      (a2 == null: plain A)
-  const float* a2;
-  const uint8_t* amask;  // dense [M][K] or null
-  float ascale;
-  const float* bias;     // [N] or null
-  const float* addend;   // [M][ld_add] or null
-  long ld_add;
-  const uint8_t* mask;   // [M][ld_mask] or null (0/1)
-  long ld_mask;
-  float mask_scale;
-  int act;               // 0 none, 1 relu, 2 tanh
-};
-
 // A(m,k) := mask * scale * tanh(A * A2) applied to the 8 staged elements of this thread (K-contiguous modes only)
 template <int MODE>
 __device__ __forceinline__ void fuse_a(float (&r)[8], const GemmEpi& e, long rs, long ks, int row0, int nrows, int k0, int kend,
@@ -98,15 +84,6 @@ __device__ __forceinline__ void fuse_a(float (&r)[8], const GemmEpi& e, long rs,
     if (e.amask) v = (row < nrows && k + i < kend && e.amask[(long)row * K + k + i]) ? v * e.ascale : 0.f;
     r[i] = v;
   }
-}
-
-__device__ __forceinline__ float apply_epi(float v, int m, int n, const GemmEpi& e) {
-  if (e.bias) v += e.bias[n];
-  if (e.addend) v += e.addend[(long)m * e.ld_add + n];
-  if (e.act == 1) v = fmaxf(v, 0.f);
-  else if (e.act == 2) v = tanhf(v);
-  if (e.mask) v = e.mask[(long)m * e.ld_mask + n] ? v * e.mask_scale : 0.f;
-  return v;
 }
 
 // Epilogue of one wave: MT x NT accumulator tiles whose first output is (mw, nw).  Interior tiles with the common epilogues
@@ -483,6 +460,14 @@ static thread_local float g_fuse_ascale = 1.f;
 
 typedef void (*gemm_kern_t)(const float*, long, long, const float*, long, long, float*, long, int, int, int, int,
                             GemmEpi, int, int);
+int lct_splitk_reduce(const float* ws, int splits, float* C, long ldc, int M, int N, const GemmEpi& epi, hipStream_t st) {
+  long total = (long)M * N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, splits, C, ldc, M, N, epi);
+  return lct_check_launch("gemm_splitk_reduce");
+}
+
 static gemm_kern_t gemm_table[3][3] = {
     {gemm_f32_kernel<0, 0>, gemm_f32_kernel<0, 1>, gemm_f32_kernel<0, 2>},
     {gemm_f32_kernel<1, 0>, gemm_f32_kernel<1, 1>, gemm_f32_kernel<1, 2>},
@@ -550,11 +535,7 @@ static int launch_gemm_dma(const float* A, long lda, int akm, const float* B, lo
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, workspace, (long)N, M, N, K, kper, epi, 0, 0L, 0L, 0L, relu_ab);
   int rc = lct_check_launch("gemm_f32_dma(splitk)");
   if (rc) return rc;
-  long total = (long)M * N;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, splits, C, ldc, M, N, epi);
-  return lct_check_launch("gemm_splitk_reduce");
+  return lct_splitk_reduce(workspace, splits, C, ldc, M, N, epi, st);
 }
 
 // relu_ab: bit 0 = apply ReLU to A elements as they are loaded, bit 1 = to B elements (PC-DARTS ReLU->Conv1x1
@@ -593,11 +574,7 @@ int lctvqa_gemm_f32_ex(const float* A, long a_ms, long a_ks, const float* B, lon
                      kper, epi, 0, relu_ab);
   int rc = lct_check_launch("gemm_f32(splitk)");
   if (rc) return rc;
-  long total = (long)M * N;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, splits, C, ldc, M, N, epi);
-  return lct_check_launch("gemm_splitk_reduce");
+  return lct_splitk_reduce(workspace, splits, C, ldc, M, N, epi, st);
 }
 
 static int colsum_splits(int M, int N) {

@@ -8,6 +8,7 @@
 // Rows beyond M read a zero page and are not stored.  Roofline: MFMA for K >= ~512, HBM below (1x1 convolutions with 64..256
 // input channels move (K + N) * 2 bytes per row for 2*K*N flops).
 #include "common.h"
+#include "gemm_epi.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -154,6 +155,296 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const unsigned short*
           }
         }
     }
+  }
+}
+
+
+// ---- the general form behind every nn.Linear of the heads under the bf16 compute dtype (fp32 master weights converted per call,
+// fp32 accumulation, fp32 output): ragged N (a store guard; the bf16 B copy is padded to the tile), split-K into fp32 slabs
+// (blockIdx.z), the full fp32 epilogue descriptor (bias / addend / ReLU / tanh / dropout mask), and two epilogues that fuse the
+// LCT token head (reference basic_vqa/models_lct.py:118-120, Linear(H, QV) over all tokens) with its cross entropy
+// (models_lct.py:253-255) so that the [T*B, QV] logits never exist in HBM:
+//   MODE 1  per-row (max, sum exp) partials of every 64-column chunk + the label's logit           (forward)
+//   MODE 2  recompute the tile, dl = (softmax - onehot) * g / rows, stored as bf16 row-major AND transposed (the operands of
+//           the two backward products), and per-128-row partial column sums (the bias gradient)   (backward)
+struct Bf16Job {
+  const unsigned short* A; long lda;       // [M][>= K]  bf16, K-contiguous, zero beyond the logical K
+  const unsigned short* B; long ldb;       // [Np][>= K] bf16 (rows >= Nvalid: anything finite or not -- never stored)
+  int M, Nvalid, Np, K, kper;              // K % 32 == 0, kper % 32 == 0: split z covers [z*kper, min(K, (z+1)*kper))
+  float* C; long ldc; int direct;          // direct: C[m][n] = epi(.), else slab z of [splits][M][Nvalid]
+  GemmEpi epi;
+  // token head + cross entropy
+  const long* labels;                      // [M] int64
+  const float* lse;                        // [M]                        (MODE 2)
+  float* pmax; float* psum;                // [Np/64][M]                 (MODE 1)
+  float* picked;                           // [M] logit of the label     (MODE 1)
+  const float* gscale; float inv_rows;     // dl scale = *gscale * inv_rows (MODE 2)
+  unsigned short* dl; long ld_dl;          // [M][Np] bf16               (MODE 2)
+  unsigned short* dlT; long ld_dlT;        // [Np][>= Mpad] bf16         (MODE 2)
+  float* dbpart;                           // [ceil(M/128)][Np]          (MODE 2)
+};
+
+template <int NT2, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x_kernel(const Bf16Job job) {
+  constexpr int BM = 256, BN = 64 * NT2, MT = 4;
+  constexpr int APL = BM * 4, BPL = BN * 4;
+  constexpr int ASZ = 4 * APL, BSZ = 4 * BPL;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* abuf = smem;
+  float* bbuf = smem + 2 * ASZ;
+  const unsigned short* __restrict__ A = job.A;
+  const unsigned short* __restrict__ B = job.B;
+  const long lda = job.lda, ldb = job.ldb;
+  const int M = job.M, Nvalid = job.Nvalid;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int j = lane & 31, h = lane >> 5;
+  const int NTL = job.Np / BN;
+  const int n_tile = blockIdx.x % NTL, m_tile = blockIdx.x / NTL;
+  const long m0 = (long)m_tile * BM;
+  const int n0 = n_tile * BN;
+  const int kbeg = blockIdx.z * job.kper;
+  const int kend = min(job.K, kbeg + job.kper);
+  const int S = (kend - kbeg) / 32;
+  const int rl = lane >> 2, sq = (lane & 3) ^ ((rl >> 2) & 3);
+  long aoff[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const long row = m0 + 16 * (wave + 4 * r) + rl;
+    aoff[r] = row < M ? row * lda + sq * 8 + kbeg : -1;
+  }
+  long boff[NT2];
+#pragma unroll
+  for (int r = 0; r < NT2; r++) boff[r] = (long)(n0 + 16 * (wave + 4 * r) + rl) * ldb + sq * 8 + kbeg;
+  auto stage = [&](int s, float* ad, float* bd) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float* src = aoff[r] >= 0 ? (const float*)(A + aoff[r] + (long)s * 32) : g_zero_page_gb;
+      glds16(src, ad + (wave + 4 * r) * 256);
+    }
+#pragma unroll
+    for (int r = 0; r < NT2; r++) glds16((const float*)(B + boff[r] + (long)s * 32), bd + (wave + 4 * r) * 256);
+  };
+  f32x16 acc[MT][NT2];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int nn = 0; nn < NT2; nn++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][nn][r] = 0.f;
+  if (S > 0) stage(0, abuf, bbuf);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int swz = (j >> 2) & 3;
+  const int fo[2] = {((0 + h) ^ swz) << 2, ((2 + h) ^ swz) << 2};
+  const int abase = (wm * MT * 32 + j) * 16;
+  const int bbase = (wn * NT2 * 32 + j) * 16;
+  for (int s = 0; s < S; s++) {
+    if (s + 1 < S) stage(s + 1, abuf + ((s + 1) & 1) * ASZ, bbuf + ((s + 1) & 1) * BSZ);
+    const float* ab = abuf + (s & 1) * ASZ + abase;
+    const float* bb = bbuf + (s & 1) * BSZ + bbase;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      bf16x8 bf[NT2];
+#pragma unroll
+      for (int nn = 0; nn < NT2; nn++) bf[nn] = __builtin_bit_cast(bf16x8, *(const f32x4*)(bb + nn * 512 + fo[kk]));
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+        const bf16x8 af = __builtin_bit_cast(bf16x8, *(const f32x4*)(ab + m * 512 + fo[kk]));
+#pragma unroll
+        for (int nn = 0; nn < NT2; nn++) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nn], acc[m][nn], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (MODE == 0) {
+    const int direct = job.direct;
+    float* __restrict__ out = direct ? job.C : job.C + (long)blockIdx.z * M * Nvalid;
+    const long ldo = direct ? job.ldc : (long)Nvalid;
+    const bool plain = !direct || (job.epi.addend == nullptr && job.epi.mask == nullptr && job.epi.act != 2);
+#pragma unroll
+    for (int nn = 0; nn < NT2; nn++) {
+      const int col = n0 + (wn * NT2 + nn) * 32 + j;
+      if (col >= Nvalid) continue;
+      const float bv = (direct && job.epi.bias) ? job.epi.bias[col] : 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const long row = m0 + wm * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) {
+            float v = acc[m][nn][r];
+            if (plain) {
+              v += bv;
+              if (direct && job.epi.act == 1) v = fmaxf(v, 0.f);
+            } else {
+              v = apply_epi(v, (int)row, col, job.epi);
+            }
+            out[row * ldo + col] = v;
+          }
+        }
+    }
+  } else {
+    // token head + cross entropy: each 32-row x 64-column block of a wave goes through the wave's private LDS tile
+    static_assert(MODE == 0 || NT2 == 2, "the cross-entropy epilogues use 128-column tiles");
+    constexpr int TS = 65;
+    float* T = smem + wave * 32 * TS;
+    const int col0 = n0 + wn * 64;
+    float bvs[NT2];
+#pragma unroll
+    for (int nn = 0; nn < NT2; nn++) {
+      const int col = col0 + nn * 32 + j;
+      bvs[nn] = col < Nvalid ? (job.epi.bias ? job.epi.bias[col] : 0.f) : -INFINITY;     // padded columns: exp() = 0
+    }
+    const int row = lane >> 1, half = lane & 1;                     // row pass: two lanes per row, 32 columns each
+    float dbacc = 0.f;                                              // MODE 2: column lane's sum over this wave's 128 rows
+    const float gs = (MODE == 2) ? job.gscale[0] * job.inv_rows : 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+      __syncthreads();
+#pragma unroll
+      for (int nn = 0; nn < NT2; nn++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) T[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + nn * 32 + j] = acc[m][nn][r] + bvs[nn];
+      __syncthreads();
+      const long grow = m0 + wm * 128 + m * 32 + row;
+      const float* tr = T + row * TS + half * 32;
+      if (MODE == 1) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 32; c++) mx = fmaxf(mx, tr[c]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        float sm = 0.f;
+        if (mx > -INFINITY) {
+#pragma unroll
+          for (int c = 0; c < 32; c++) sm += __expf(tr[c] - mx);
+        }
+        sm += __shfl_xor(sm, 1, 64);
+        if (grow < M) {
+          if (half == 0) {
+            const long o = (long)(col0 >> 6) * M + grow;
+            job.pmax[o] = mx;
+            job.psum[o] = sm;
+          }
+          const long lab = job.labels[grow] - (col0 + half * 32);
+          if (lab >= 0 && lab < 32) job.picked[grow] = tr[lab];
+        }
+      } else {
+        float* tw = T + row * TS + half * 32;
+        const bool live = grow < M;
+        const float ls = live ? job.lse[grow] : 0.f;
+        const long lab = live ? job.labels[grow] - (col0 + half * 32) : -1;
+        typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          us8 ov;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const int c = 8 * q + e;
+            float d = live ? (__expf(tr[c] - ls) - (c == lab ? 1.f : 0.f)) * gs : 0.f;
+            tw[c] = d;
+            ov[e] = f2bf(d);
+          }
+          if (live) *(us8*)(job.dl + grow * job.ld_dl + col0 + half * 32 + 8 * q) = ov;
+        }
+        __syncthreads();
+        // column pass: lane = column, the 32 rows of the block are 64 contiguous bytes of the transposed copy
+        const long rbase = m0 + wm * 128 + m * 32;
+        float cs = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          us8 ov;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const float d = T[(8 * q + e) * TS + lane];
+            cs += d;
+            ov[e] = f2bf(d);
+          }
+          *(us8*)(job.dlT + (long)(col0 + lane) * job.ld_dlT + rbase + 8 * q) = ov;      // rows beyond M hold zeros (dl = 0 there)
+        }
+        dbacc += cs;
+      }
+    }
+    if (MODE == 2) job.dbpart[(long)(m_tile * 2 + wm) * job.Np + col0 + lane] = dbacc;
+  }
+}
+
+// lse[m] = log sum_n exp(logit) from the per-chunk partials, loss = sum_m (lse[m] - picked[m]) * inv_rows (one workgroup, fixed order)
+__global__ __launch_bounds__(1024) void xent_chunks_finish_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+                                                                   const float* __restrict__ picked, int chunks, int M, float inv_rows,
+                                                                   float* __restrict__ lse, float* __restrict__ loss) {
+  __shared__ float red[1024];
+  float local = 0.f;
+  for (int m = threadIdx.x; m < M; m += 1024) {
+    float mx = -INFINITY;
+    for (int c = 0; c < chunks; c++) mx = fmaxf(mx, pmax[(long)c * M + m]);
+    float s = 0.f;
+    for (int c = 0; c < chunks; c++) {
+      const float pm = pmax[(long)c * M + m];
+      if (pm > -INFINITY) s += psum[(long)c * M + m] * __expf(pm - mx);
+    }
+    const float l = mx + logf(s);
+    lse[m] = l;
+    local += l - picked[m];
+  }
+  red[threadIdx.x] = local;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0] * inv_rows;
+}
+
+// dst (bf16) [rows_pad][ld_dst >= cols_pad] = src (fp32) [rows][cols] (row stride ld_src), zero beyond rows / cols
+__global__ void cvt_pad_bf16_kernel(const float* __restrict__ src, long ld_src, int rows, int cols, unsigned short* __restrict__ dst,
+                                    long ld_dst, int rows_pad, int cols_pad) {
+  typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+  const int g8 = cols_pad >> 3;
+  const bool vec = ((ld_src & 3) == 0) && (((uintptr_t)src & 15) == 0);
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < (long)rows_pad * g8; o += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(o % g8);
+    const long r = o / g8;
+    const int c = g * 8;
+    us8 ov = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < rows && c < cols) {
+      const float* p = src + r * ld_src + c;
+      if (vec && c + 8 <= cols) {
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+        ov = us8{f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) ov[e] = (c + e < cols) ? f2bf(p[e]) : (unsigned short)0;
+      }
+    }
+    *(us8*)(dst + r * ld_dst + c) = ov;
+  }
+}
+// transposed form: dst (bf16) [cols_pad][ld_dst >= rows_pad] = src^T; 64 x 64 tiles through LDS (coalesced on both sides)
+__global__ __launch_bounds__(256) void cvt_pad_bf16_t_kernel(const float* __restrict__ src, long ld_src, int rows, int cols,
+                                                             unsigned short* __restrict__ dst, long ld_dst, int rows_pad, int cols_pad) {
+  typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+  __shared__ float T[64][65];
+  const int tr = rows_pad / 64;                                   // tiles along the source rows (= dst columns)
+  const int r0 = (blockIdx.x % tr) * 64, c0 = (blockIdx.x / tr) * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int rr = (tid >> 6) + 4 * i, cc = tid & 63;
+    const long r = r0 + rr, c = c0 + cc;
+    T[rr][cc] = (r < rows && c < cols) ? src[r * ld_src + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int item = tid + 256 * i;                               // 64 dst rows x 8 groups of 8
+    const int cc = item >> 3, g = item & 7;
+    us8 ov;
+#pragma unroll
+    for (int e = 0; e < 8; e++) ov[e] = f2bf(T[8 * g + e][cc]);
+    *(us8*)(dst + (long)(c0 + cc) * ld_dst + r0 + 8 * g) = ov;
   }
 }
 
@@ -352,6 +643,143 @@ int lctvqa_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, 
   else { if (out_bf16) GB(1, true) else GB(1, false) }
 #undef GB
   return lct_check_launch("gemm_bf16");
+}
+
+static int bf16x_splits(long M, int Np, int K, int BN) {
+  const long tiles = ((M + 255) / 256) * (Np / BN);
+  int splits = 1;
+  if (tiles < 192) {
+    splits = (int)(512 / tiles);
+    const int maxs = K / 128;
+    if (splits > maxs) splits = maxs;
+    if (splits > 32) splits = 32;
+    if (splits < 1) splits = 1;
+  }
+  return splits;
+}
+// bytes of split-K workspace lctvqa_gemm_bf16x wants for this problem (0: no split)
+long lctvqa_gemm_bf16x_workspace_bytes(long M, int N, int Np, int K) {
+  const int s = bf16x_splits(M, Np, K, Np % 128 == 0 ? 128 : 64);
+  return s > 1 ? (long)s * M * N * (long)sizeof(float) : 0;
+}
+
+static int bf16x_check(const void* A, long lda, const void* B, long ldb, long M, int N, int Np, int K) {
+  LCT_REQUIRE(M >= 1 && M < (1L << 31) && N >= 1 && Np >= N && Np % 64 == 0 && K >= 32 && K % 32 == 0,
+              "gemm_bf16x: need Np %% 64 == 0 >= N, K %% 32 == 0 (got M=%ld N=%d Np=%d K=%d)", M, N, Np, K);
+  LCT_REQUIRE((lda & 7) == 0 && (ldb & 7) == 0 && lda >= K && ldb >= K && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
+              "gemm_bf16x: operands must be 16-byte aligned bf16 rows of at least K elements");
+  return LCT_OK;
+}
+
+// C[M][N] (fp32) = epi(A[M][K] . B[Np][K]^T), bf16 operands (zero-padded to K % 32 == 0; B padded to Np rows, Np % 64 == 0),
+// epi(v) = mask * mask_scale * act(v + bias[n] + addend[m][n]) (act 0 none / 1 ReLU / 2 tanh).  Few-tile problems are split along K
+// into fp32 slabs in `workspace` (lctvqa_gemm_bf16x_workspace_bytes) and reduced in a fixed order.
+int lctvqa_gemm_bf16x(const void* A, long lda, const void* B, long ldb, float* C, long ldc, long M, int N, int Np, int K, const float* bias,
+                      const float* addend, long ld_add, int act, const uint8_t* mask, long ld_mask, float mask_scale, float* workspace,
+                      long workspace_bytes, void* stream) {
+  int rc = bf16x_check(A, lda, B, ldb, M, N, Np, K);
+  if (rc) return rc;
+  LCT_REQUIRE(act >= 0 && act <= 2 && ldc >= N, "gemm_bf16x: bad act / ldc");
+  hipStream_t st = (hipStream_t)stream;
+  const int BN = Np % 128 == 0 ? 128 : 64;
+  int splits = bf16x_splits(M, Np, K, BN);
+  if (splits > 1) {
+    const long cap = workspace ? workspace_bytes / (M * N * (long)sizeof(float)) : 0;
+    if (cap < splits) splits = cap < 1 ? 1 : (int)cap;
+  }
+  int kper = ((cdiv(K, splits) + 31) / 32) * 32;
+  splits = cdiv(K, kper);
+  Bf16Job job{};
+  job.A = (const unsigned short*)A; job.lda = lda; job.B = (const unsigned short*)B; job.ldb = ldb;
+  job.M = (int)M; job.Nvalid = N; job.Np = Np; job.K = K; job.kper = kper;
+  job.epi = GemmEpi{nullptr, nullptr, 1.f, bias, addend, ld_add, mask, ld_mask, mask_scale, act};
+  job.direct = splits == 1;
+  job.C = splits == 1 ? C : workspace; job.ldc = ldc;
+  const long mt = (M + 255) / 256;
+  const size_t lds = (size_t)(2 * 4 * 256 * 4 + 2 * 4 * BN * 4) * sizeof(float);
+  dim3 grid((unsigned)(mt * (Np / BN)), 1, splits);
+  if (BN == 128) {
+    auto k = gemm_bf16x_kernel<2, 0>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, job);
+  } else {
+    auto k = gemm_bf16x_kernel<1, 0>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, job);
+  }
+  rc = lct_check_launch("gemm_bf16x");
+  if (rc || splits == 1) return rc;
+  return lct_splitk_reduce(workspace, splits, C, ldc, (int)M, N, job.epi, st);
+}
+
+// Token head fused with its cross entropy, forward (reference basic_vqa/models_lct.py:118-120 + 253-255):
+//   loss = mean_m( logsumexp_n(X[m] . W[n] + b[n]) - (X[m] . W[labels[m]] + b[labels[m]]) ), lse[m] kept for the backward pass.
+// X [M][K], W [Np][K] bf16 (Np % 128 == 0 >= N); part: 2 * (Np / 64) * M floats of scratch; picked: M floats.
+long lctvqa_linear_xent_bf16_part_elems(long M, int Np) { return 2L * (Np / 64) * M; }
+int lctvqa_linear_xent_bf16_fwd(const void* X, long ldx, const void* W, long ldw, const float* bias, const long* labels, long M, int N,
+                                int Np, int K, float* part, float* picked, float* lse, float* loss, void* stream) {
+  int rc = bf16x_check(X, ldx, W, ldw, M, N, Np, K);
+  if (rc) return rc;
+  LCT_REQUIRE(Np % 128 == 0, "linear_xent_bf16: Np %% 128");
+  hipStream_t st = (hipStream_t)stream;
+  Bf16Job job{};
+  job.A = (const unsigned short*)X; job.lda = ldx; job.B = (const unsigned short*)W; job.ldb = ldw;
+  job.M = (int)M; job.Nvalid = N; job.Np = Np; job.K = K; job.kper = K;
+  job.epi = GemmEpi{nullptr, nullptr, 1.f, bias, nullptr, 0, nullptr, 0, 1.f, 0};
+  job.labels = labels; job.pmax = part; job.psum = part + (long)(Np / 64) * M; job.picked = picked;
+  const size_t lds = (size_t)(2 * 4 * 256 * 4 + 2 * 4 * 128 * 4) * sizeof(float);
+  auto k = gemm_bf16x_kernel<2, 1>;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3((unsigned)(((M + 255) / 256) * (Np / 128))), dim3(256), lds, st, job);
+  rc = lct_check_launch("linear_xent_bf16_fwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(xent_chunks_finish_kernel, dim3(1), dim3(1024), 0, st, job.pmax, job.psum, picked, Np / 64, (int)M, 1.f / (float)M, lse,
+                     loss);
+  return lct_check_launch("xent_chunks_finish");
+}
+// backward: dl[m][n] = (exp(logit - lse[m]) - [n == labels[m]]) * g[0] / M as bf16, row-major [M][Np] and transposed [Np][ld_dlT >=
+// 256-padded M] (padded rows / columns are zeros), and dbpart [ceil(M/256)*2][Np] partial column sums (sum them for the bias gradient).
+int lctvqa_linear_xent_bf16_bwd(const void* X, long ldx, const void* W, long ldw, const float* bias, const long* labels, const float* lse,
+                                const float* g, long M, int N, int Np, int K, void* dl, long ld_dl, void* dlT, long ld_dlT, float* dbpart,
+                                void* stream) {
+  int rc = bf16x_check(X, ldx, W, ldw, M, N, Np, K);
+  if (rc) return rc;
+  const long Mp = ((M + 255) / 256) * 256;
+  LCT_REQUIRE(Np % 128 == 0 && ld_dl >= Np && (ld_dl & 7) == 0 && ld_dlT >= Mp && (ld_dlT & 7) == 0 &&
+              (((uintptr_t)dl | (uintptr_t)dlT) & 15) == 0, "linear_xent_bf16_bwd: bad dl / dlT layout");
+  hipStream_t st = (hipStream_t)stream;
+  Bf16Job job{};
+  job.A = (const unsigned short*)X; job.lda = ldx; job.B = (const unsigned short*)W; job.ldb = ldw;
+  job.M = (int)M; job.Nvalid = N; job.Np = Np; job.K = K; job.kper = K;
+  job.epi = GemmEpi{nullptr, nullptr, 1.f, bias, nullptr, 0, nullptr, 0, 1.f, 0};
+  job.labels = labels; job.lse = lse; job.gscale = g; job.inv_rows = 1.f / (float)M;
+  job.dl = (unsigned short*)dl; job.ld_dl = ld_dl; job.dlT = (unsigned short*)dlT; job.ld_dlT = ld_dlT; job.dbpart = dbpart;
+  const size_t lds = (size_t)(2 * 4 * 256 * 4 + 2 * 4 * 128 * 4) * sizeof(float);
+  auto k = gemm_bf16x_kernel<2, 2>;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3((unsigned)(((M + 255) / 256) * (Np / 128))), dim3(256), lds, st, job);
+  return lct_check_launch("linear_xent_bf16_bwd");
+}
+
+// dst (bf16) [rows_pad][ld_dst] = src (fp32) [rows][cols] zero-padded; transpose: dst [cols_pad][ld_dst] = src^T (rows_pad, cols_pad
+// multiples of 64 then).  cols_pad (rows_pad when transposed) % 8 == 0, dst 16-byte aligned, ld_dst % 8 == 0.
+int lctvqa_cvt_pad_bf16(const float* src, long ld_src, int rows, int cols, void* dst, long ld_dst, int rows_pad, int cols_pad, int transpose,
+                        void* stream) {
+  LCT_REQUIRE(rows >= 1 && cols >= 1 && rows_pad >= rows && cols_pad >= cols && (ld_dst & 7) == 0 && ((uintptr_t)dst & 15) == 0,
+              "cvt_pad_bf16: bad shape / alignment");
+  hipStream_t st = (hipStream_t)stream;
+  if (!transpose) {
+    LCT_REQUIRE(cols_pad % 8 == 0 && ld_dst >= cols_pad, "cvt_pad_bf16: cols_pad %% 8");
+    long nb = ((long)rows_pad * (cols_pad / 8) + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(cvt_pad_bf16_kernel, dim3((int)nb), dim3(256), 0, st, src, ld_src, rows, cols, (unsigned short*)dst, ld_dst, rows_pad,
+                       cols_pad);
+    return lct_check_launch("cvt_pad_bf16");
+  }
+  LCT_REQUIRE(rows_pad % 64 == 0 && cols_pad % 64 == 0 && ld_dst >= rows_pad, "cvt_pad_bf16(transpose): pads must be multiples of 64");
+  hipLaunchKernelGGL(cvt_pad_bf16_t_kernel, dim3((unsigned)((rows_pad / 64) * (cols_pad / 64))), dim3(256), 0, st, src, ld_src, rows, cols,
+                     (unsigned short*)dst, ld_dst, rows_pad, cols_pad);
+  return lct_check_launch("cvt_pad_bf16_t");
 }
 
 int lctvqa_cvt_f32_to_bf16(const float* x, void* y, long n, void* stream) {

@@ -111,13 +111,18 @@ class QstEncoder(QstEncoderBase):
         torch.nn.init.xavier_uniform_(self.fc2.weight.data)
         torch.nn.init.zeros_(self.fc2.bias)
 
-    def forward(self, question, image_embedding):
+    def forward(self, question, image_embedding, token_loss=False):
+        """``token_loss``: return the scalar CE(logits[:, :-1], question[:, 1:]) (vqa_model.py:357-361) in place of the logits,
+        computed without materialising them."""
         B = image_embedding.shape[0]
         h0 = image_embedding.reshape(B, self.hidden_size)
         qst_vec = ops.embed(question, self.word2vec.weight, True)
         out, hidden, cell = ops.lstm(qst_vec, *_single_layer(self.lstm), h0, h0)
         qst_feature = ops.linear(ops.CatTanhFn.apply(hidden, cell), self.fc2.weight, self.fc2.bias)
-        qst_out = ops.linear(ops.TanhFn.apply(out), self.fc1.weight, self.fc1.bias)
+        tout = ops.TanhFn.apply(out)
+        if token_loss:
+            return qst_feature, ops.token_head_loss(tout, self.fc1.weight, self.fc1.bias, question)
+        qst_out = ops.linear(tout, self.fc1.weight, self.fc1.bias)
         return qst_feature, qst_out.transpose(0, 1)
 
 
@@ -199,6 +204,12 @@ class VqaModel(VqaModelBase):
         return new_model
 
     def _loss(self, images, questions, labels, qst_only=False):
+        if ops.linear_xent_fused() and questions.shape[1] > 1:      # token head fused with its cross entropy
+            img_feature = self.img_encoder(images)
+            qst_feature, qst_loss = self.qst_encoder(questions, img_feature, token_loss=True)
+            if qst_only:
+                return qst_loss
+            return ops.cross_entropy(self._head(img_feature, qst_feature), labels) + qst_loss
         ans_out, qst_out = self(images, questions)
         ans_loss = ops.cross_entropy(ans_out, labels)
         qst = questions[:, 1:].flatten()

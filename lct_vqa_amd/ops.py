@@ -50,9 +50,17 @@ def gemm(A, a_ms, a_ks, B, b_ns, b_ks, M, N, K, bias=None, addend=None, act=ACT_
     return C
 
 
-def linear_fwd(x, W, b=None, act=ACT_NONE, mask=None, mask_scale=1.0, addend=None, out=None):
+def linear_fwd(x, W, b=None, act=ACT_NONE, mask=None, mask_scale=1.0, addend=None, out=None, cache_w=False):
+    """y = epi(x . W^T).  ``cache_w``: W belongs to a trunk that is frozen by construction (see _packed_weights): its bf16 copy may
+    be kept between calls under the bf16 compute dtype."""
     M, K = x.shape
     N = W.shape[0]
+    if _compute_dtype == 'bf16' and _bf16_able(x, W):
+        Kp, Np = _ceil(K, 32), _bf16_np(N)
+        xa = _bf16_rows(x, M, Kp)
+        wb = _packed_weights(W, 'bf16_rows', Np * Kp, lambda dst: lib('cvt_pad_bf16', W, W.stride(0), N, K, dst, Kp, Np, Kp, 0),
+                             cache_w, torch.bfloat16).view(Np, Kp)
+        return _gemm_bf16x(xa, wb, M, N, Np, Kp, b, addend, act, mask, mask_scale, out)
     return gemm(x, x.stride(0), 1, W, W.stride(0), 1, M, N, K, b, addend, act, mask, mask_scale, out)
 
 
@@ -60,6 +68,10 @@ def linear_bwd_input(dY, W):
     """dX[M,K] = dY[M,N] . W[N,K]"""
     M, N = dY.shape
     K = W.shape[1]
+    if _compute_dtype == 'bf16' and _bf16_able(dY, W):
+        Nk = _ceil(N, 64)                                      # the contraction runs over N here
+        Kp = _ceil(K, 128) if K > 64 else 64
+        return _gemm_bf16x(_bf16_rows(dY, M, Nk), _bf16_rows(W, Nk, Kp, transpose=True), M, K, Kp, Nk)
     return gemm(dY, dY.stride(0), 1, W, 1, W.stride(0), M, K, N)
 
 
@@ -67,7 +79,50 @@ def linear_bwd_weight(dY, X):
     """dW[N,K] = dY[M,N]^T . X[M,K]"""
     M, N = dY.shape
     K = X.shape[1]
+    if _compute_dtype == 'bf16' and _bf16_able(dY, X):
+        Mk = _ceil(M, 64)                                      # the contraction runs over the rows
+        Kp = _ceil(K, 128) if K > 64 else 64
+        return _gemm_bf16x(_bf16_rows(dY, Mk, _ceil(N, 64), transpose=True), _bf16_rows(X, Mk, Kp, transpose=True), N, K, Kp, Mk)
     return gemm(dY, 1, dY.stride(0), X, 1, X.stride(0), N, K, M)
+
+
+# ---- bf16 compute dtype for the heads: bf16 copies of the operands (fp32 master weights, converted per call), fp32 accumulation ----
+def _ceil(a, b):
+    return -(-a // b) * b
+
+
+def _bf16_np(N):
+    """Row count of the bf16 B operand: the kernel's 128-column tile where N allows it, else 64."""
+    return _ceil(N, 128) if N > 64 else 64
+
+
+def _bf16_able(a, b):
+    return (a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2
+            and a.shape[0] >= 1 and a.stride(1) == 1 and b.stride(1) == 1)
+
+
+def _bf16_rows(t, rows_pad, cols_pad, transpose=False):
+    """Zero-padded bf16 copy of a 2-D fp32 tensor [R, C] (unit column stride): [rows_pad, cols_pad], or its transpose
+    [cols_pad, rows_pad] (both pads multiples of 64 then)."""
+    R, C = t.shape
+    if transpose:
+        dst = torch.empty((cols_pad, rows_pad), dtype=torch.bfloat16, device=t.device)
+        lib('cvt_pad_bf16', t, t.stride(0), R, C, dst, rows_pad, rows_pad, cols_pad, 1)
+    else:
+        dst = torch.empty((rows_pad, cols_pad), dtype=torch.bfloat16, device=t.device)
+        lib('cvt_pad_bf16', t, t.stride(0), R, C, dst, cols_pad, rows_pad, cols_pad, 0)
+    return dst
+
+
+def _gemm_bf16x(A, Bm, M, N, Np, K, bias=None, addend=None, act=ACT_NONE, mask=None, mask_scale=1.0, out=None):
+    """C[M,N] fp32 = epi(A[M,K] . Bm[Np,K]^T) on the bf16 matrix cores (csrc/gemm_bf16.hip: gemm_bf16x_kernel)."""
+    dev = A.device
+    C = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
+    need = lib.query('gemm_bf16x_workspace_bytes', M, N, Np, K)
+    ws = _workspace(need, dev) if need else None
+    lib('gemm_bf16x', A, A.stride(0), Bm, Bm.stride(0), C, C.stride(0), M, N, Np, K, bias, addend,
+        addend.stride(0) if addend is not None else 0, act, mask, mask.stride(0) if mask is not None else 0, float(mask_scale), ws, need)
+    return C
 
 
 def colsum(X):
@@ -462,10 +517,17 @@ class FusionFc1Fn(torch.autograd.Function):
         img, qst, W = _chk(img), _chk(qst), _chk(W)
         B, E = img.shape
         A = W.shape[0]
-        h1 = torch.empty((B, A), dtype=torch.float32, device=img.device)
-        need = lib.query('gemm_workspace_bytes', B, A, E)
-        ws = _workspace(need, img.device) if need else None
-        lib('fusion_fc1', img, qst, mask1, float(scale1), W, b, mask2, float(scale2), h1, B, E, A, ws, need)
+        if _compute_dtype == 'bf16' and _bf16_able(img, W):
+            # the bf16 operand copy is where mul -> tanh -> dropout is materialised (B x E values)
+            t = torch.empty_like(img)
+            z = torch.empty_like(img)
+            lib('mul_tanh_drop_fwd', img, qst, mask1, float(scale1), t, z, img.numel())
+            h1 = linear_fwd(z, W, b, ACT_TANH, mask2, float(scale2))
+        else:
+            h1 = torch.empty((B, A), dtype=torch.float32, device=img.device)
+            need = lib.query('gemm_workspace_bytes', B, A, E)
+            ws = _workspace(need, img.device) if need else None
+            lib('fusion_fc1', img, qst, mask1, float(scale1), W, b, mask2, float(scale2), h1, B, E, A, ws, need)
         ctx.save_for_backward(img, qst, W, h1, mask1, mask2)
         ctx.scales = (float(scale1), float(scale2))
         return h1
@@ -552,6 +614,78 @@ class SoftmaxRowsFn(torch.autograd.Function):
         dx = torch.empty_like(y)
         lib('softmax_rows_bwd', _chk(dy), y, dx, y.shape[0], y.shape[1], ctx.inv_temp)
         return dx, None
+
+
+class LinearXentFn(torch.autograd.Function):
+    """mean_m CE(x[m] . W^T + b, labels[m]) with the logits never written to HBM: the LCT token head (reference
+    basic_vqa/models_lct.py:118-120, Linear(H, QV) over every token) fused with its cross entropy (models_lct.py:253-255) on the
+    bf16 matrix cores (csrc/gemm_bf16.hip: per-chunk (max, sum exp) partials in the forward GEMM's epilogue; the backward GEMM
+    recomputes the tile and emits dl = (softmax - onehot) / M as bf16, row-major and transposed, the operands of dX and dW)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, labels):
+        x, W = _chk(x, 'x'), _chk(W, 'weight')
+        M, K = x.shape
+        N = W.shape[0]
+        dev = x.device
+        if labels.dtype != torch.int64 or labels.numel() != M:
+            raise RuntimeError('linear_xent: labels must be int64 [M]')
+        labels = labels.contiguous()
+        Kp, Np = _ceil(K, 32), _ceil(N, 128)
+        xa = _bf16_rows(x, M, Kp)
+        wb = _bf16_rows(W, Np, Kp)
+        part = torch.empty(lib.query('linear_xent_bf16_part_elems', M, Np), dtype=torch.float32, device=dev)
+        picked = torch.empty(M, dtype=torch.float32, device=dev)
+        lse = torch.empty(M, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        lib('linear_xent_bf16_fwd', xa, Kp, wb, Kp, b, labels, M, N, Np, Kp, part, picked, lse, loss)
+        ctx.save_for_backward(x, W, b, labels, xa, wb, lse)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, b, labels, xa, wb, lse = ctx.saved_tensors
+        M, K = x.shape
+        N = W.shape[0]
+        dev = x.device
+        Kp, Np, Mp = _ceil(K, 32), _ceil(N, 128), _ceil(M, 256)
+        g = _chk(g.reshape(1))
+        dl = torch.empty((M, Np), dtype=torch.bfloat16, device=dev)
+        dlT = torch.empty((Np, Mp), dtype=torch.bfloat16, device=dev)
+        dbpart = torch.empty((2 * (Mp // 256), Np), dtype=torch.float32, device=dev)
+        lib('linear_xent_bf16_bwd', xa, Kp, wb, Kp, b, labels, lse, g, M, N, Np, Kp, dl, Np, dlT, Mp, dbpart)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:                              # dX = dl . W: contraction over the (padded) vocabulary
+            Ko = _ceil(K, 128) if K > 64 else 64
+            dx = _gemm_bf16x(dl, _bf16_rows(W, Np, Ko, transpose=True), M, K, Ko, Np)
+        if ctx.needs_input_grad[1]:                              # dW = dl^T . X: contraction over the (padded) rows
+            Ko = _ceil(K, 128) if K > 64 else 64
+            dW = _gemm_bf16x(dlT, _bf16_rows(x, Mp, Ko, transpose=True), N, K, Ko, Mp)
+        if b is not None and ctx.needs_input_grad[2]:
+            db = colsum(dbpart)[:N].contiguous()
+        return dx, dW, db, None
+
+
+def token_head_loss(tout, W, b, question):
+    """CE(token logits[:, :-1], question[:, 1:]) of the LCT examiner (reference models_lct.py:253-255; <pad> = 0 is a class like any
+    other) from the tanh'd LSTM outputs ``tout`` [T,B,H]: row t*B + b of the first T-1 steps predicts question[b, t+1]."""
+    T, B, H = tout.shape
+    rows = tout[:T - 1].reshape((T - 1) * B, H)
+    labels = question[:, 1:].t().contiguous().reshape(-1)
+    return linear_cross_entropy(rows, W, b, labels)
+
+
+def linear_xent_fused():
+    """True when the fused token head + cross entropy is in effect (bf16 compute dtype)."""
+    return _compute_dtype == 'bf16'
+
+
+def linear_cross_entropy(x, W, b, labels):
+    """nn.CrossEntropyLoss()(x . W^T + b, labels) for x [M,K]: fused (logits never materialised) under the bf16 compute dtype,
+    else the GEMM followed by the row-wise cross entropy."""
+    if _compute_dtype == 'bf16':
+        return LinearXentFn.apply(x, W, b, labels)
+    return cross_entropy(linear(x, W, b), labels)
 
 
 def cross_entropy(logits, labels):
@@ -651,10 +785,16 @@ _compute_dtype = os.environ.get('LCTVQA_COMPUTE_DTYPE', 'f32')
 
 
 def set_compute_dtype(name):
-    """Arithmetic of a FROZEN VGG19 trunk's convolutions: 'f32' (default: the reference's arithmetic, the only headline
-    path) or 'bf16' (bf16 activations / weights, fp32 accumulation on v_mfma_f32_32x32x16_bf16, csrc/conv3x3_bf16.hip:
-    BASELINE.json's bf16 configurations).  Everything trainable -- classifier, question encoder, fusion head, a trunk that
-    needs gradients -- keeps fp32 master weights and fp32 kernels.  Returns the previous setting."""
+    """'f32' (default: the reference's arithmetic, the only headline path) or 'bf16' (BASELINE.json's bf16 configurations):
+      * a FROZEN VGG19 / ResNet-152 trunk runs with bf16 activations and weights, fp32 accumulation on v_mfma_f32_32x32x16_bf16
+        (csrc/conv3x3_bf16.hip, csrc/gemm_bf16.hip);
+      * every nn.Linear product of the heads -- the VGG classifier, img fc, LSTM / GRU input projections, question feature fc,
+        fusion fc1 / fc2, the LCT token head -- forward and both backward products, multiplies bf16 copies of its fp32 operands
+        (fp32 master weights, fp32 accumulation, fp32 results: csrc/gemm_bf16.hip gemm_bf16x_kernel), and the token head is
+        fused with its cross entropy where the loss is all that is wanted (``linear_cross_entropy``);
+      * the recurrent products (h . W_hh per time step), the greedy decode (it emits integers), the pointwise kernels, the
+        optimizer, the trainable convolutions and the PC-DARTS edges stay fp32.
+    Returns the previous setting."""
     global _compute_dtype
     if name not in ('f32', 'bf16'):
         raise ValueError(name)
@@ -933,7 +1073,7 @@ def vgg_trunk_forward(image, convs, fcs, train, conv_feature=None, cache=False, 
     B, dev = x.shape[0], x.device
     for (w, b, act, drop_p) in fcs:
         m = dropout_mask((B, w.shape[0]), dev, drop_p) if (train and drop_p > 0) else None
-        x = linear_fwd(x, _chk(w), b, act, m, 1.0 / (1.0 - drop_p) if m is not None else 1.0)
+        x = linear_fwd(x, _chk(w), b, act, m, 1.0 / (1.0 - drop_p) if m is not None else 1.0, cache_w=cache)
     return x
 
 
