@@ -546,7 +546,8 @@ def main():
     algo = ops.get_conv_algo()
     tot_flops = sum(r['flops'] for r in conv)
     tot_exec = sum(r['flops'] / (4.0 if r['name'].startswith('wino4') else 2.25 if r['name'].startswith('wino') else 1.0) for r in conv)
-    ngemm = sum(1 for r in conv if r['name'].startswith('gemm'))
+    ngemm = sum(1 for r in conv if r['name'].startswith('gemm') and 'bf16' not in r['name'])
+    ngemm_bf = sum(1 for r in conv if r['name'].startswith('gemm') and 'bf16' in r['name'])
     tot_ms = sum(r['ms'] for r in conv)
     nlaunch = max(1, len(conv))
     direct_equiv = tot_flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
@@ -554,13 +555,14 @@ def main():
     nwino = sum(1 for r in conv if r['name'].startswith('wino'))
     nw4 = sum(1 for r in conv if r['name'].startswith('wino4'))
     nbf = sum(1 for r in conv if r['name'].startswith('bf16'))
-    peak = BF16_MFMA_PEAK_TFLOPS if nbf else FP32_MFMA_PEAK_TFLOPS
+    peak = BF16_MFMA_PEAK_TFLOPS if (nbf or ngemm_bf) else FP32_MFMA_PEAK_TFLOPS
     # achieved / frac: the multiply-adds the kernels' ALGORITHM performs on the MFMA pipe (Winograd F(4x4,3x3): 36 per
     # 4x4 output tile and channel pair = 1/4 of direct convolution's 144; F(2x2,3x3): 1/2.25) over the live HIP-event
     # time of those launches, against the dense fp32 MFMA peak: a utilisation, <= 1.  What Winograd buys on top is
     # `algorithmic_speedup`; `direct_equivalent_tflops` = the direct-convolution FLOP count per second.
     roofline = {'bound': 'mfma',
-                'kernel': ('gemm_f32_kernel (1x1 convolutions of the bottlenecks as fp32 MFMA GEMMs, %d launches) + conv3x3_wino4_kernel (%d)' % (ngemm, nw4)) if ngemm else
+                'kernel': ('gemm_bf16_kernel (1x1 convolutions of the bottlenecks on v_mfma_f32_32x32x16_bf16, %d launches) + conv3x3_bf16_kernel (%d)' % (ngemm_bf, nbf)) if ngemm_bf else
+                          ('gemm_f32_kernel (1x1 convolutions of the bottlenecks as fp32 MFMA GEMMs, %d launches) + conv3x3_wino4_kernel (%d)' % (ngemm, nw4)) if ngemm else
                           ('conv3x3_bf16_kernel (direct implicit GEMM on v_mfma_f32_32x32x16_bf16, fp32 accumulate, %d launches)' % nbf) if nbf else
                           ('conv3x3_wino4_kernel (Winograd F(4x4,3x3), %d launches) + conv3x3_wino2/3_kernel (F(2x2,3x3), %d) + '
                            'conv3x3_mfma_kernel (direct, %d): fp32 MFMA' % (nw4, nwino - nw4, nlaunch - nwino)) if nwino else
@@ -575,16 +577,24 @@ def main():
                 'conv_ms_per_step': round(tot_ms / args.steps, 3)}
     # HBM bytes per launch of the same kernel family from the committed rocprofv3 --pmc passes of this command (FETCH_SIZE,
     # WRITE_SIZE: tools/pmc_profile.py); used only while the kernels are the ones that were profiled (source stamp)
+    # ... and only for the workload / dtype / batch the passes were taken on (the W workload at B=256): another workload's layers have
+    # other shapes, so its algorithmic bytes and these measured bytes do not belong in one ratio.
     try:
-        pfile = 'r02_pmc_conv_bf16.json' if nbf else 'r02_pmc_conv_wino.json' if nwino else 'r01_pmc_conv_gemm.json'
-        pm = json.load(open(os.path.join(ROOT, 'profiles', pfile)))
-        if pm.get('csrc_stamp') in (None, conv_source_stamp()):
+        kind = 'bf16' if nbf else 'wino' if nwino else 'gemm'
+        cands = [os.environ['LCTVQA_PMC_FILE']] if os.environ.get('LCTVQA_PMC_FILE') else \
+            sorted(__import__('glob').glob(os.path.join(ROOT, 'profiles', f'r*_pmc_conv_{kind}.json')), reverse=True)
+        pfile = cands[0]
+        pm = json.load(open(pfile))
+        shown = os.path.relpath(pfile, ROOT)
+        if args.workload != 'w' or B != 256:
+            roofline['traffic_source'] = f'{shown} was measured on workload w at B=256: not reported for this run'
+        elif pm.get('csrc_stamp') in (None, conv_source_stamp()):
             roofline['traffic'] = pm['conv3x3_family']['hbm_bytes_per_launch']
-            roofline['traffic_source'] = f'profiles/{pfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per launch)'
+            roofline['traffic_source'] = f'{shown} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per launch)'
             if roofline['algorithmic_bytes_per_launch']:
                 roofline['traffic_ratio'] = round(roofline['traffic'] / roofline['algorithmic_bytes_per_launch'], 3)
         else:
-            roofline['traffic_source'] = f'profiles/{pfile} is of other kernel sources (stamp mismatch): not reported'
+            roofline['traffic_source'] = f'{shown} is of other kernel sources (stamp mismatch): not reported'
     except Exception:
         pass
     if args.layer_report:
@@ -600,7 +610,7 @@ def main():
         'metric': ('image-question pairs/sec (train step) at 224x224, seq=14, 3129-way' if args.workload == 'w' else
                    ('image-question pairs/sec (ResNet-152+GRU train step, %s trunk) at 224x224, seq=14, 3129-way' % ('trainable' if args.train_encoder else 'frozen')) if args.workload == 'resnet_gru' else
                    'image-question pairs/sec (LCT stage1+stage2 step: EF + generate + W soft loss%s) at 224x224, seq=14, 3129-way' % (', examiner trunk TRAINED' if args.train_encoder else ''))
-                  + (' [bf16 frozen trunk, fp32 accumulate, fp32 heads: NOT the headline fp32 metric]' if args.dtype == 'bf16' else ''),
+                  + (' [bf16 compute dtype: bf16 frozen trunk and bf16 head GEMMs, fp32 accumulate, fp32 master weights: NOT the headline fp32 metric]' if args.dtype == 'bf16' else ''),
         'value': round(value, 2),
         'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',

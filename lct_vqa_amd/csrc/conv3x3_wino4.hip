@@ -85,9 +85,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
   const int j = lane & 31, h = lane >> 5;
   const int NT = Cout / 64;
   // workgroups are dealt to the 8 XCDs round-robin: the NT workgroups reading one input patch share an XCD (its L2)
-  const int n_tile = (blockIdx.x >> 3) % NT, m_tile = ((blockIdx.x >> 3) / NT) * 8 + (blockIdx.x & 7);
   const int CT = Wp / TW;
-  if (m_tile >= ((Btot * Hp + TH - 1) / TH) * CT) return;
+  const int MTALL = ((Btot * Hp + TH - 1) / TH) * CT;
+#ifdef W4_XCD_BAND
+  // each XCD walks a contiguous band of patches in row-major order: horizontally and vertically adjacent patches (which share
+  // halo columns / rows) run on the same XCD close in time, so the shared lines are served by its L2
+  const int n_tile = (blockIdx.x >> 3) % NT, m_tile = (blockIdx.x & 7) * ((MTALL + 7) / 8) + (blockIdx.x >> 3) / NT;
+  if ((blockIdx.x >> 3) / NT >= (MTALL + 7) / 8 || m_tile >= MTALL) return;
+#else
+  const int n_tile = (blockIdx.x >> 3) % NT, m_tile = ((blockIdx.x >> 3) / NT) * 8 + (blockIdx.x & 7);
+  if (m_tile >= MTALL) return;
+#endif
   const int ct = m_tile % CT, rt = m_tile / CT;
   const int R0 = rt * TH, x0 = ct * TW;
   const int n0img = R0 / Hp, y0 = R0 % Hp;                      // stacked PADDED rows: R = n * Hp + y
