@@ -318,6 +318,8 @@ int lctvqa_gemm_bf16x(const void* A, long lda, const void* B, long ldb, float* C
                       long workspace_bytes, void* stream);
 int lctvqa_cvt_pad_bf16(const float* src, long ld_src, int rows, int cols, void* dst, long ld_dst, int rows_pad, int cols_pad, int transpose,
                         void* stream);
+int lctvqa_cvt_pad_bf16_both(const float* src, long ld_src, int rows, int cols, void* plain, long ld_plain, void* dst_t, long ld_t,
+                             int rows_pad, int cols_pad, void* stream);
 long lctvqa_linear_xent_bf16_part_elems(long M, int Np);
 int lctvqa_linear_xent_bf16_fwd(const void* X, long ldx, const void* W, long ldw, const float* bias, const long* labels, long M, int N,
                                 int Np, int K, float* part, float* picked, float* lse, float* loss, void* stream);

@@ -72,7 +72,7 @@ class QstEncoder(nn.Module):
         torch.nn.init.zeros_(self.fc1.bias)
         torch.nn.init.zeros_(self.fc2.bias)
 
-    def forward(self, question, image_embedding, token_loss=False):
+    def forward(self, question, image_embedding, token_loss=False, feature_only=False):
         """-> (question feature [B,E], token logits [B,T,QV]); with ``token_loss`` the second item is instead the scalar
         CE(logits[:, :-1], question[:, 1:]) of models_lct.py:253-255, computed without materialising the logits."""
         B = image_embedding.shape[0]
@@ -81,6 +81,8 @@ class QstEncoder(nn.Module):
         out, hidden, cell = ops.lstm(qst_vec, *_single_layer(self.lstm), h0, h0)   # teacher forcing
         qst_feature = ops.CatTanhFn.apply(hidden, cell)
         qst_feature = ops.linear(qst_feature, self.fc1.weight, self.fc1.bias)
+        if feature_only:                                            # generate()'s re-encoding: the token logits are not used
+            return qst_feature, None
         tout = ops.TanhFn.apply(out)                                # [T,B,H]
         if token_loss:
             return qst_feature, ops.token_head_loss(tout, self.fc2.weight, self.fc2.bias, question)
@@ -158,7 +160,7 @@ class VqaModel(nn.Module):
         """(generated questions, answer logits for them) -- reference models_lct.py:220-241."""
         img_feature = self._encode_image(img, conv_feature)
         qst = self.qst_encoder.generate(img_feature)
-        qst_feature, _ = self.qst_encoder(qst, img_feature)
+        qst_feature, _ = self.qst_encoder(qst, img_feature, feature_only=True)
         return qst, self._head(img_feature, qst_feature)
 
     def trainable_parameters(self):

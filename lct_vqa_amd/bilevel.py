@@ -19,22 +19,31 @@ caches anything derived from a trainable parameter.
 import torch
 import torch.distributed as dist
 
-_dp = {'group': None, 'on': False}
+_dp = {'group': None, 'on': None}      # on: None = automatic (on whenever a process group with more than one rank exists)
 
 
 def data_parallel(on=True, process_group=None):
     """Under data parallelism every gradient the architecture steps take (dtheta of the virtual steps, grad_wprime, kappa,
     both halves of every finite difference: SURVEY.md section 8e / 2.4) must be the gradient of the GLOBAL batch.  With this
-    switched on, ``grads`` averages its result over the ranks (one flat all-reduce per call), so every quantity derived from
-    it -- the virtual steps, ||v|| in R = r / ||v||, the alpha gradient -- is identical on all ranks and equal to the
-    single-process large-batch step (losses are means over samples; equal shards).  Returns the previous setting."""
+    on, ``grads`` averages its result over the ranks (one flat all-reduce per call), so every quantity derived from it -- the
+    virtual steps, ||v|| in R = r / ||v||, the alpha gradient -- is identical on all ranks.  It is ON BY DEFAULT whenever
+    ``torch.distributed`` is initialised with more than one rank (an architect stepping on local-shard gradients would let
+    alpha drift apart between the ranks); ``data_parallel(False)`` switches it off explicitly, ``data_parallel(None)`` restores
+    the automatic setting.  Returns the previous setting.
+
+    What it equals: for models WITHOUT BatchNorm (VGG / LSTM / fusion head) the single-process step on the concatenated batch
+    (losses are means over samples; equal shards).  For the PC-DARTS and trainable ResNet encoders it equals N reference
+    processes whose gradients are averaged: BatchNorm uses each rank's own batch statistics (the reference's semantics per
+    process; a SyncBN that all-reduces the per-channel sums between the statistics kernels and their finish is not built), and
+    the running statistics are per rank -- ``parallel.broadcast_buffers(model)`` copies rank 0's to every rank (before a
+    validation pass or a checkpoint)."""
     prev = _dp['on']
-    _dp['on'], _dp['group'] = bool(on), process_group
+    _dp['on'], _dp['group'] = (None if on is None else bool(on)), process_group
     return prev
 
 
 def _average_over_ranks(tensors):
-    world = dist.get_world_size(_dp['group']) if (_dp['on'] and dist.is_available() and dist.is_initialized()) else 1
+    world = dist.get_world_size(_dp['group']) if (_dp['on'] is not False and dist.is_available() and dist.is_initialized()) else 1
     if world == 1:
         return tensors
     flat = torch.cat([t.reshape(-1) for t in tensors])

@@ -371,24 +371,46 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x_kernel(const Bf16Job job) {
   }
 }
 
-// lse[m] = log sum_n exp(logit) from the per-chunk partials, loss = sum_m (lse[m] - picked[m]) * inv_rows (one workgroup, fixed order)
-__global__ __launch_bounds__(1024) void xent_chunks_finish_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
-                                                                   const float* __restrict__ picked, int chunks, int M, float inv_rows,
-                                                                   float* __restrict__ lse, float* __restrict__ loss) {
+// lse[m] = log sum_n exp(logit) from the per-chunk (max, sum exp) partials; rowloss[m] = lse[m] - picked[m].
+// Workgroup = 32 rows x 8 chunk groups: thread (row r = tid & 31, group g = tid >> 5) folds chunks g, g + 8, ... online, the 8
+// groups of a row meet in LDS in a fixed order.  Reads are coalesced along m (partials are [chunk][M]).
+__global__ __launch_bounds__(256) void xent_chunks_rows_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+                                                               const float* picked, int chunks, int M,
+                                                               float* __restrict__ lse, float* rowloss /* may alias picked */) {
+  __shared__ float smx[8][32], ssm[8][32];
+  const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int m = blockIdx.x * 32 + r;
+  float mx = -INFINITY, sm = 0.f;
+  if (m < M) {
+    for (int c = g; c < chunks; c += 8) {
+      const float pm = pmax[(long)c * M + m], ps = psum[(long)c * M + m];
+      if (pm > -INFINITY) {
+        if (pm > mx) { sm = sm * __expf(mx - pm) + ps; mx = pm; }      // exp(-inf - pm) = 0 on the first chunk
+        else sm += ps * __expf(pm - mx);
+      }
+    }
+  }
+  smx[g][r] = mx;
+  ssm[g][r] = sm;
+  __syncthreads();
+  if (g == 0 && m < M) {
+    float M2 = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; k++) M2 = fmaxf(M2, smx[k][r]);
+    float S2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (smx[k][r] > -INFINITY) S2 += ssm[k][r] * __expf(smx[k][r] - M2);
+    const float l = M2 + logf(S2);
+    lse[m] = l;
+    rowloss[m] = l - picked[m];
+  }
+}
+// loss = inv_rows * sum_m rowloss[m] (one workgroup, fixed order)
+__global__ __launch_bounds__(1024) void xent_rows_sum_kernel(const float* __restrict__ rowloss, int M, float inv_rows, float* __restrict__ loss) {
   __shared__ float red[1024];
   float local = 0.f;
-  for (int m = threadIdx.x; m < M; m += 1024) {
-    float mx = -INFINITY;
-    for (int c = 0; c < chunks; c++) mx = fmaxf(mx, pmax[(long)c * M + m]);
-    float s = 0.f;
-    for (int c = 0; c < chunks; c++) {
-      const float pm = pmax[(long)c * M + m];
-      if (pm > -INFINITY) s += psum[(long)c * M + m] * __expf(pm - mx);
-    }
-    const float l = mx + logf(s);
-    lse[m] = l;
-    local += l - picked[m];
-  }
+  for (int m = threadIdx.x; m < M; m += 1024) local += rowloss[m];
   red[threadIdx.x] = local;
   __syncthreads();
   for (int o = 512; o > 0; o >>= 1) {
@@ -424,7 +446,8 @@ __global__ void cvt_pad_bf16_kernel(const float* __restrict__ src, long ld_src, 
 }
 // transposed form: dst (bf16) [cols_pad][ld_dst >= rows_pad] = src^T; 64 x 64 tiles through LDS (coalesced on both sides)
 __global__ __launch_bounds__(256) void cvt_pad_bf16_t_kernel(const float* __restrict__ src, long ld_src, int rows, int cols,
-                                                             unsigned short* __restrict__ dst, long ld_dst, int rows_pad, int cols_pad) {
+                                                             unsigned short* __restrict__ dst, long ld_dst, int rows_pad, int cols_pad,
+                                                             unsigned short* __restrict__ plain, long ld_plain) {
   typedef unsigned short us8 __attribute__((ext_vector_type(8)));
   __shared__ float T[64][65];
   const int tr = rows_pad / 64;                                   // tiles along the source rows (= dst columns)
@@ -445,6 +468,17 @@ __global__ __launch_bounds__(256) void cvt_pad_bf16_t_kernel(const float* __rest
 #pragma unroll
     for (int e = 0; e < 8; e++) ov[e] = f2bf(T[8 * g + e][cc]);
     *(us8*)(dst + (long)(c0 + cc) * ld_dst + r0 + 8 * g) = ov;
+  }
+  if (plain) {                                                    // the un-transposed copy [rows_pad][cols_pad] from the same tile
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int item = tid + 256 * i;
+      const int rr = item >> 3, g = item & 7;
+      us8 ov;
+#pragma unroll
+      for (int e = 0; e < 8; e++) ov[e] = f2bf(T[rr][8 * g + e]);
+      *(us8*)(plain + (long)(r0 + rr) * ld_plain + c0 + 8 * g) = ov;
+    }
   }
 }
 
@@ -733,9 +767,13 @@ int lctvqa_linear_xent_bf16_fwd(const void* X, long ldx, const void* W, long ldw
   hipLaunchKernelGGL(k, dim3((unsigned)(((M + 255) / 256) * (Np / 128))), dim3(256), lds, st, job);
   rc = lct_check_launch("linear_xent_bf16_fwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(xent_chunks_finish_kernel, dim3(1), dim3(1024), 0, st, job.pmax, job.psum, picked, Np / 64, (int)M, 1.f / (float)M, lse,
-                     loss);
-  return lct_check_launch("xent_chunks_finish");
+  // picked[] is consumed by the row kernel and then re-used as the per-row loss buffer of the final sum
+  hipLaunchKernelGGL(xent_chunks_rows_kernel, dim3((unsigned)((M + 31) / 32)), dim3(256), 0, st, job.pmax, job.psum, picked, Np / 64, (int)M, lse,
+                     picked);
+  rc = lct_check_launch("xent_chunks_rows");
+  if (rc) return rc;
+  hipLaunchKernelGGL(xent_rows_sum_kernel, dim3(1), dim3(1024), 0, st, picked, (int)M, 1.f / (float)M, loss);
+  return lct_check_launch("xent_rows_sum");
 }
 // backward: dl[m][n] = (exp(logit - lse[m]) - [n == labels[m]]) * g[0] / M as bf16, row-major [M][Np] and transposed [Np][ld_dlT >=
 // 256-padded M] (padded rows / columns are zeros), and dbpart [ceil(M/256)*2][Np] partial column sums (sum them for the bias gradient).
@@ -778,8 +816,19 @@ int lctvqa_cvt_pad_bf16(const float* src, long ld_src, int rows, int cols, void*
   }
   LCT_REQUIRE(rows_pad % 64 == 0 && cols_pad % 64 == 0 && ld_dst >= rows_pad, "cvt_pad_bf16(transpose): pads must be multiples of 64");
   hipLaunchKernelGGL(cvt_pad_bf16_t_kernel, dim3((unsigned)((rows_pad / 64) * (cols_pad / 64))), dim3(256), 0, st, src, ld_src, rows, cols,
-                     (unsigned short*)dst, ld_dst, rows_pad, cols_pad);
+                     (unsigned short*)dst, ld_dst, rows_pad, cols_pad, (unsigned short*)nullptr, 0L);
   return lct_check_launch("cvt_pad_bf16_t");
+}
+// both copies of one fp32 matrix in one pass: plain [rows_pad][ld_plain >= cols_pad] and transposed [cols_pad][ld_t >= rows_pad]
+// (pads multiples of 64): the gradient dY of a Linear is the A operand of dX = dY . W as it is and of dW = dY^T . X transposed
+int lctvqa_cvt_pad_bf16_both(const float* src, long ld_src, int rows, int cols, void* plain, long ld_plain, void* dst_t, long ld_t,
+                             int rows_pad, int cols_pad, void* stream) {
+  LCT_REQUIRE(rows >= 1 && cols >= 1 && rows_pad >= rows && cols_pad >= cols && rows_pad % 64 == 0 && cols_pad % 64 == 0 &&
+              ld_plain >= cols_pad && ld_t >= rows_pad && (ld_plain & 7) == 0 && (ld_t & 7) == 0 &&
+              (((uintptr_t)plain | (uintptr_t)dst_t) & 15) == 0, "cvt_pad_bf16_both: bad shape / alignment");
+  hipLaunchKernelGGL(cvt_pad_bf16_t_kernel, dim3((unsigned)((rows_pad / 64) * (cols_pad / 64))), dim3(256), 0, (hipStream_t)stream, src, ld_src,
+                     rows, cols, (unsigned short*)dst_t, ld_t, rows_pad, cols_pad, (unsigned short*)plain, ld_plain);
+  return lct_check_launch("cvt_pad_bf16_both");
 }
 
 int lctvqa_cvt_f32_to_bf16(const float* x, void* y, long n, void* stream) {

@@ -111,7 +111,7 @@ class QstEncoder(QstEncoderBase):
         torch.nn.init.xavier_uniform_(self.fc2.weight.data)
         torch.nn.init.zeros_(self.fc2.bias)
 
-    def forward(self, question, image_embedding, token_loss=False):
+    def forward(self, question, image_embedding, token_loss=False, feature_only=False):
         """``token_loss``: return the scalar CE(logits[:, :-1], question[:, 1:]) (vqa_model.py:357-361) in place of the logits,
         computed without materialising them."""
         B = image_embedding.shape[0]
@@ -119,6 +119,8 @@ class QstEncoder(QstEncoderBase):
         qst_vec = ops.embed(question, self.word2vec.weight, True)
         out, hidden, cell = ops.lstm(qst_vec, *_single_layer(self.lstm), h0, h0)
         qst_feature = ops.linear(ops.CatTanhFn.apply(hidden, cell), self.fc2.weight, self.fc2.bias)
+        if feature_only:                                            # generate()'s re-encoding: the token logits are not used
+            return qst_feature, None
         tout = ops.TanhFn.apply(out)
         if token_loss:
             return qst_feature, ops.token_head_loss(tout, self.fc1.weight, self.fc1.bias, question)
@@ -188,7 +190,7 @@ class VqaModel(VqaModelBase):
     def generate(self, img):
         img_feature = self.img_encoder(img)
         qst = self.qst_encoder.generate(img_feature)
-        qst_feature, _ = self.qst_encoder(qst, img_feature)
+        qst_feature, _ = self.qst_encoder(qst, img_feature, feature_only=True)
         return qst, self._head(img_feature, qst_feature)
 
     def trainable_parameters(self):

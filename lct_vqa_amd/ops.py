@@ -64,25 +64,41 @@ def linear_fwd(x, W, b=None, act=ACT_NONE, mask=None, mask_scale=1.0, addend=Non
     return gemm(x, x.stride(0), 1, W, W.stride(0), 1, M, N, K, b, addend, act, mask, mask_scale, out)
 
 
-def linear_bwd_input(dY, W):
+def bf16_grad_copies(dY):
+    """(dY as bf16 [Mp][Np], dY^T as bf16 [Np][Mp]) from ONE pass over a Linear's output gradient (pads to multiples of 64), the
+    A operands of its two backward products; (None, None) outside the bf16 compute dtype.  Hand them to ``linear_bwd_input`` /
+    ``linear_bwd_weight`` when the same dY feeds several products (LSTM: dx, dW_ih, dW_hh)."""
+    if _compute_dtype != 'bf16' or not (dY.is_cuda and dY.dtype == torch.float32 and dY.dim() == 2 and dY.stride(1) == 1):
+        return None, None
+    M, N = dY.shape
+    Mp, Np = _ceil(M, 64), _ceil(N, 64)
+    plain = torch.empty((Mp, Np), dtype=torch.bfloat16, device=dY.device)
+    trans = torch.empty((Np, Mp), dtype=torch.bfloat16, device=dY.device)
+    lib('cvt_pad_bf16_both', dY, dY.stride(0), M, N, plain, Np, trans, Mp, Mp, Np)
+    return plain, trans
+
+
+def linear_bwd_input(dY, W, dY_bf16=None):
     """dX[M,K] = dY[M,N] . W[N,K]"""
     M, N = dY.shape
     K = W.shape[1]
     if _compute_dtype == 'bf16' and _bf16_able(dY, W):
         Nk = _ceil(N, 64)                                      # the contraction runs over N here
         Kp = _ceil(K, 128) if K > 64 else 64
-        return _gemm_bf16x(_bf16_rows(dY, M, Nk), _bf16_rows(W, Nk, Kp, transpose=True), M, K, Kp, Nk)
+        a = dY_bf16 if dY_bf16 is not None else _bf16_rows(dY, M, Nk)
+        return _gemm_bf16x(a, _bf16_rows(W, Nk, Kp, transpose=True), M, K, Kp, Nk)
     return gemm(dY, dY.stride(0), 1, W, 1, W.stride(0), M, K, N)
 
 
-def linear_bwd_weight(dY, X):
+def linear_bwd_weight(dY, X, dYT_bf16=None):
     """dW[N,K] = dY[M,N]^T . X[M,K]"""
     M, N = dY.shape
     K = X.shape[1]
     if _compute_dtype == 'bf16' and _bf16_able(dY, X):
         Mk = _ceil(M, 64)                                      # the contraction runs over the rows
         Kp = _ceil(K, 128) if K > 64 else 64
-        return _gemm_bf16x(_bf16_rows(dY, Mk, _ceil(N, 64), transpose=True), _bf16_rows(X, Mk, Kp, transpose=True), N, K, Kp, Mk)
+        a = dYT_bf16 if dYT_bf16 is not None else _bf16_rows(dY, Mk, _ceil(N, 64), transpose=True)
+        return _gemm_bf16x(a, _bf16_rows(X, Mk, Kp, transpose=True), N, K, Kp, Mk)
     return gemm(dY, 1, dY.stride(0), X, 1, X.stride(0), N, K, M)
 
 
@@ -220,10 +236,11 @@ class LinearFn(torch.autograd.Function):
         else:
             dpre = dy
         dx = dW = db = None
+        g16, g16t = bf16_grad_copies(dpre) if (ctx.needs_input_grad[0] and ctx.needs_input_grad[1]) else (None, None)
         if ctx.needs_input_grad[0]:
-            dx = linear_bwd_input(dpre, W).reshape(ctx.shp)
+            dx = linear_bwd_input(dpre, W, g16).reshape(ctx.shp)
         if ctx.needs_input_grad[1]:
-            dW = linear_bwd_weight(dpre, x2)
+            dW = linear_bwd_weight(dpre, x2, g16t)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = colsum(dpre)
         return dx, dW, db, None, None, None
@@ -334,9 +351,10 @@ class LSTMFn(torch.autograd.Function):
                     dh_rec = linear_bwd_input(dgates[t], w_hh)
         dg2 = dgates.reshape(T * B, 4 * H)
         ni = ctx.needs_input_grad
-        dx = linear_bwd_input(dg2, w_ih).reshape(T, B, I) if ni[0] else None
-        dw_ih = linear_bwd_weight(dg2, x.reshape(T * B, I)) if ni[1] else None
-        dw_hh = linear_bwd_weight(dg2, h_all[:T].reshape(T * B, H)) if ni[2] else None
+        g16, g16t = bf16_grad_copies(dg2)                            # one conversion for the three products
+        dx = linear_bwd_input(dg2, w_ih, g16).reshape(T, B, I) if ni[0] else None
+        dw_ih = linear_bwd_weight(dg2, x.reshape(T * B, I), g16t) if ni[1] else None
+        dw_hh = linear_bwd_weight(dg2, h_all[:T].reshape(T * B, H), g16t) if ni[2] else None
         db = colsum(dg2) if (ni[3] or ni[4]) else None
         dh0 = dh_rec if (ctx.has_init and ni[5]) else None
         dc0 = dc if (ctx.has_init and ni[6]) else None
@@ -542,11 +560,12 @@ class FusionFc1Fn(torch.autograd.Function):
         t = torch.empty_like(img)
         z = torch.empty_like(img)
         lib('mul_tanh_drop_fwd', img, qst, mask1, s1, t, z, img.numel())
-        dW = linear_bwd_weight(dpre, z) if ctx.needs_input_grad[2] else None
+        g16, g16t = bf16_grad_copies(dpre)
+        dW = linear_bwd_weight(dpre, z, g16t) if ctx.needs_input_grad[2] else None
         db = colsum(dpre) if ctx.needs_input_grad[3] else None
         da = dq = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            dz = linear_bwd_input(dpre, W)
+            dz = linear_bwd_input(dpre, W, g16)
             da = torch.empty_like(img) if ctx.needs_input_grad[0] else None
             dq = torch.empty_like(qst) if ctx.needs_input_grad[1] else None
             lib('mul_tanh_drop_bwd', dz, img, qst, t, mask1, s1, da, dq, img.numel())

@@ -184,6 +184,16 @@ def describe_ranks(local):
     return out
 
 
+def broadcast_buffers(model, src=0, process_group=None):
+    """Copy rank ``src``'s buffers (BatchNorm running statistics, num_batches_tracked) to every rank.  Data-parallel training of
+    the BatchNorm encoders (PC-DARTS search network, trainable ResNet) keeps per-rank statistics (bilevel.data_parallel's note):
+    call this before validation or checkpointing so that every rank evaluates / saves the same model.  No-op at world size 1."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return
+    for b in model.buffers():
+        dist.broadcast(b, src=src, group=process_group)
+
+
 def make_flat_grad(params):
     """Allocate one flat fp32 gradient buffer and point every p.grad at its slice (any device).
     optim.FusedAdam(flatten=True) does the same for the HBM arena; this helper serves callers that
