@@ -255,11 +255,13 @@ def bench_darts_vqa(args, rank, world, dev, img, qst, lab):
         # edge, T = 4 * P * Cq bytes): cells at 224^2 x 16, 112^2 x 32 (reduction), 56^2 x 64 (reduction), 56^2 x 64
         T = [224 * 224 * 4 * 4, 112 * 112 * 8 * 4, 56 * 56 * 16 * 4, 56 * 56 * 16 * 4]
         enc_bytes = 89 * 14 * sum(T)
-        out = {'metric': 'image-question pairs/sec (darts_vqa weight step: PC-DARTS search encoder + LSTM encoder-decoder) at 224x224, seq=14, 3129-way',
+        bf = args.dtype == 'bf16'
+        out = {'metric': 'image-question pairs/sec (darts_vqa weight step: PC-DARTS search encoder + LSTM encoder-decoder) at 224x224, seq=14, 3129-way'
+                         + (' [bf16 compute dtype: bf16 head GEMMs and fused token head, fp32 accumulation and master weights; the MixedOp edges stay fp32]' if bf else ''),
                'value': round(world * B * args.steps / dt, 2), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-               'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': "darts_vqa VqaModel(img_encoder_type='darts') fp32 weight step (fwd + CE(ans) + CE(qst) + bwd + clip + Adam), "
-                                      'batch %d per GPU, 224x224x3, 14 tokens, A=3129, QV=17858: BASELINE configs[4] on one GPU in fp32' % B,
+               'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+               'config': {'workload': "darts_vqa VqaModel(img_encoder_type='darts') %s weight step (fwd + CE(ans) + CE(qst) + bwd + clip + Adam), "
+                                      'batch %d per GPU, 224x224x3, 14 tokens, A=3129, QV=17858: BASELINE configs[4] on one GPU' % (args.dtype, B),
                           'global_batch': world * B, 'seq_len': 14, 'parallelism': f'dp{world}',
                           'architect_step_ms': None if arch_ms is None else round(arch_ms, 1)},
                'loss': round(float(loss.item()), 5),

@@ -9,7 +9,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'lctvqa.h')
-LIB_PATH = os.path.join(HERE, '_C', 'liblctvqa_hip.so')
+LIB_PATH = os.environ.get('LCTVQA_LIB') or os.path.join(HERE, '_C', 'liblctvqa_hip.so')      # LCTVQA_LIB: a variant build (A/B tools)
 
 _CT = {
     'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float,

@@ -88,9 +88,12 @@ __device__ __forceinline__ void load_tile(f32x4* __restrict__ tile, const float*
 }
 
 // depthwise K x K at one output pixel: taps at (cy + DIL*j, cx + DIL*i) of the tile (cy, cx = top-left tap), ReLU'd on read
-template <int CQ, int K, int DIL, bool RELU>
+// TAPS: weights staged tap-major [K*K][CQ] (stage_weights_taps: one 16-byte broadcast read per tap and channel quad) or
+// channel-major [CQ][K*K] as the parameter stores them (four 4-byte reads).  Same accumulation order either way (bit-identical);
+// measured per kernel: the forward kernels gain from the tap-major form at Cq = 4 and lose at Cq = 8 / 16, the backward kernel gains.
+template <int CQ, int K, int DIL, bool RELU, bool TAPS>
 __device__ __forceinline__ void dw_at(const f32x4* __restrict__ tile, int npos, int tw, int cy, int cx,
-                                      const float* __restrict__ wl /* LDS [CQ][K*K] */, float* __restrict__ out) {
+                                      const float* __restrict__ wl, float* __restrict__ out) {
 #pragma unroll
   for (int q = 0; q < CQ / 4; q++) {
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -100,8 +103,14 @@ __device__ __forceinline__ void dw_at(const f32x4* __restrict__ tile, int npos, 
       for (int i = 0; i < K; i++) {
         f32x4 v = tile[q * npos + (cy + DIL * j) * tw + cx + DIL * i];
         if (RELU) v = relu4(v);
+        if (TAPS) {
+          const f32x4 w4 = *(const f32x4*)(wl + (j * K + i) * CQ + 4 * q);
 #pragma unroll
-        for (int e = 0; e < 4; e++) a[e] = fmaf(wl[(4 * q + e) * K * K + j * K + i], v[e], a[e]);
+          for (int e = 0; e < 4; e++) a[e] = fmaf(w4[e], v[e], a[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) a[e] = fmaf(wl[(4 * q + e) * K * K + j * K + i], v[e], a[e]);
+        }
       }
 #pragma unroll
     for (int e = 0; e < 4; e++) out[4 * q + e] = a[e];
@@ -112,9 +121,9 @@ __device__ __forceinline__ void dw_at(const f32x4* __restrict__ tile, int npos, 
 template <int NO, int NI>
 __device__ __forceinline__ void pw_at(const float* __restrict__ wl, const float* __restrict__ in, float* __restrict__ out) {
 #pragma unroll
-  for (int oc = 0; oc < NO; oc++) {
-    float a = 0.f;
-#pragma unroll
+  for (int oc = 0; oc < NO; oc++) {            // one accumulation chain per output in channel order (the compiler merges the weight
+    float a = 0.f;                             // reads into 8-byte pairs): splitting it into four partial sums changes the rounding
+#pragma unroll                                 // of the forward values, and with it which elements sit on a ReLU boundary
     for (int c = 0; c < NI; c++) a = fmaf(wl[oc * NI + c], in[c], a);
     out[oc] = a;
   }
@@ -122,6 +131,10 @@ __device__ __forceinline__ void pw_at(const float* __restrict__ wl, const float*
 
 __device__ __forceinline__ void stage_weights(float* __restrict__ dst, const float* __restrict__ src, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+// depthwise weights [CQ][KK] (the parameter's layout) -> tap-major [KK][CQ] in LDS
+__device__ __forceinline__ void stage_weights_taps(float* __restrict__ dst, const float* __restrict__ src, int cq, int kk) {
+  for (int i = threadIdx.x; i < cq * kk; i += blockDim.x) dst[(i % kk) * cq + i / kk] = src[i];
 }
 
 
@@ -134,6 +147,9 @@ __device__ __forceinline__ void phase_stats(const float (*u)[CQ], bool live, flo
                                             double* __restrict__ acc, int slot_base) {
   constexpr int NC = 4 * NS;
   const int t = threadIdx.x;
+#ifdef EDGE_ABL_NOSTATS
+  return;                                                      // ablation build (tools/ab_edge.py): what the statistics reduction costs
+#endif
 #pragma unroll
   for (int q = 0; q < CQ / 4; q++) {
     __syncthreads();                                           // red[] of the previous round consumed
@@ -188,10 +204,18 @@ __global__ __launch_bounds__(TH * TW) void edge_fwd_a_kernel(const float* __rest
   float* red = w_fr + CQ * CQ;                                 // [12][TPB+1]
   float* seg = red + 12 * (TPB + 1);                           // [2][12][8]
   double* acc = (double*)(seg + 2 * 12 * 8);                   // [2][7*CQ] (an even number of floats precedes it)
-  stage_weights(w_dw3a, wts.dw[0], CQ * 9);
-  stage_weights(w_dw5a, wts.dw[1], CQ * 25);
-  stage_weights(w_dd3, wts.dw[2], CQ * 9);
-  stage_weights(w_dd5, wts.dw[3], CQ * 25);
+  constexpr bool TAPS = CQ == 4;
+  if (TAPS) {
+    stage_weights_taps(w_dw3a, wts.dw[0], CQ, 9);
+    stage_weights_taps(w_dw5a, wts.dw[1], CQ, 25);
+    stage_weights_taps(w_dd3, wts.dw[2], CQ, 9);
+    stage_weights_taps(w_dd5, wts.dw[3], CQ, 25);
+  } else {
+    stage_weights(w_dw3a, wts.dw[0], CQ * 9);
+    stage_weights(w_dw5a, wts.dw[1], CQ * 25);
+    stage_weights(w_dd3, wts.dw[2], CQ * 9);
+    stage_weights(w_dd5, wts.dw[3], CQ * 25);
+  }
   for (int k = 0; k < 4; k++) stage_weights(w_pw + k * CQ * CQ, wts.pw[k], CQ * CQ);
   if (S == 2) { stage_weights(w_fr, wts.fr[0], CQ / 2 * CQ); stage_weights(w_fr + CQ / 2 * CQ, wts.fr[1], CQ / 2 * CQ); }
   for (int i = threadIdx.x; i < 2 * 7 * CQ; i += TPB) acc[i] = 0.0;
@@ -258,18 +282,18 @@ __global__ __launch_bounds__(TH * TW) void edge_fwd_a_kernel(const float* __rest
     }
     {   // ---- first stages of sep_conv_3x3 / sep_conv_5x5: relu -> depthwise (stride S) -> 1x1 ----
       float u[2][CQ], d[CQ];
-      dw_at<CQ, 3, 1, true>(tile, NPOS, IW, cy - 1, cx - 1, w_dw3a, d);
+      dw_at<CQ, 3, 1, true, TAPS>(tile, NPOS, IW, cy - 1, cx - 1, w_dw3a, d);
       pw_at<CQ, CQ>(w_pw, d, u[0]);
-      dw_at<CQ, 5, 1, true>(tile, NPOS, IW, cy - 2, cx - 2, w_dw5a, d);
+      dw_at<CQ, 5, 1, true, TAPS>(tile, NPOS, IW, cy - 2, cx - 2, w_dw5a, d);
       pw_at<CQ, CQ>(w_pw + CQ * CQ, d, u[1]);
       if (live) { store_row<CQ>(pre + (3 * P + qo) * CQ, u[0]); store_row<CQ>(pre + (4 * P + qo) * CQ, u[1]); }
       phase_stats<CQ, 2, 7, TPB>(u, live, red, seg, acc, 3);
     }
     {   // ---- dil_conv_3x3 / dil_conv_5x5: relu -> depthwise (stride S, dilation 2) -> 1x1 ----
       float u[2][CQ], d[CQ];
-      dw_at<CQ, 3, 2, true>(tile, NPOS, IW, cy - 2, cx - 2, w_dd3, d);
+      dw_at<CQ, 3, 2, true, TAPS>(tile, NPOS, IW, cy - 2, cx - 2, w_dd3, d);
       pw_at<CQ, CQ>(w_pw + 2 * CQ * CQ, d, u[0]);
-      dw_at<CQ, 5, 2, true>(tile, NPOS, IW, cy - 4, cx - 4, w_dd5, d);
+      dw_at<CQ, 5, 2, true, TAPS>(tile, NPOS, IW, cy - 4, cx - 4, w_dd5, d);
       pw_at<CQ, CQ>(w_pw + 3 * CQ * CQ, d, u[1]);
       if (live) { store_row<CQ>(pre + (5 * P + qo) * CQ, u[0]); store_row<CQ>(pre + (6 * P + qo) * CQ, u[1]); }
       phase_stats<CQ, 2, 7, TPB>(u, live, red, seg, acc, 5);
@@ -299,8 +323,14 @@ __global__ __launch_bounds__(TH * TW) void edge_fwd_b_kernel(int B, int Ho, int 
   float* red = ms + 4 * CQ;                                    // [8][TPB+1]
   float* seg = red + 8 * (TPB + 1);                            // [2][8][8]
   double* acc = (double*)(seg + 128);                          // [2][2*CQ]
-  stage_weights(w_dw3, wts.dw[4], CQ * 9);
-  stage_weights(w_dw5, wts.dw[5], CQ * 25);
+  constexpr bool TAPS = CQ == 4;
+  if (TAPS) {
+    stage_weights_taps(w_dw3, wts.dw[4], CQ, 9);
+    stage_weights_taps(w_dw5, wts.dw[5], CQ, 25);
+  } else {
+    stage_weights(w_dw3, wts.dw[4], CQ * 9);
+    stage_weights(w_dw5, wts.dw[5], CQ * 25);
+  }
   stage_weights(w_pw, wts.pw[4], CQ * CQ);
   stage_weights(w_pw + CQ * CQ, wts.pw[5], CQ * CQ);
   for (int i = threadIdx.x; i < 2 * CQ; i += TPB) {
@@ -323,9 +353,9 @@ __global__ __launch_bounds__(TH * TW) void edge_fwd_b_kernel(int B, int Ho, int 
     const int oy = ty0 + ly, ox = tx0 + lx;
     const bool live = oy < Ho && ox < Wo;
     float u[2][CQ], d[CQ];
-    dw_at<CQ, 3, 1, false>(tile3, NPOS, IW, ly + 1, lx + 1, w_dw3, d);
+    dw_at<CQ, 3, 1, false, TAPS>(tile3, NPOS, IW, ly + 1, lx + 1, w_dw3, d);
     pw_at<CQ, CQ>(w_pw, d, u[0]);
-    dw_at<CQ, 5, 1, false>(tile5, NPOS, IW, ly, lx, w_dw5, d);
+    dw_at<CQ, 5, 1, false, TAPS>(tile5, NPOS, IW, ly, lx, w_dw5, d);
     pw_at<CQ, CQ>(w_pw + CQ * CQ, d, u[1]);
     const long qo = ((long)n * Ho + oy) * Wo + ox;
     if (live) {
@@ -891,7 +921,7 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
   float* red = msi + 2 * CQ;                                   // MODE 1: [8][TPB+1]
   float* seg = red + (MODE == 1 ? 8 * (TPB + 1) : 0);          // MODE 1: [2][8][8]
   double* acc = (double*)(seg + (MODE == 1 ? 128 : 0));        // MODE 1: [2][2*CQ]
-  stage_weights(wdl, w_dw, CQ * KK);
+  stage_weights_taps(wdl, w_dw, CQ, KK);
   stage_weights(wpl, w_pw, CQ * CQ);
   for (int i = threadIdx.x; i < CQ; i += TPB) {
     mso[i] = mean_o[i]; mso[CQ + i] = invstd_o[i];
@@ -908,6 +938,13 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
   float acc_pw[NPW];
 #pragma unroll
   for (int i = 0; i < NPW; i++) acc_pw[i] = 0.f;
+  // 1x1 weight gradient for Cq >= 8: thread = (4 x 4 block of (output, input) channels, slice of the tile's pixels); a pixel costs two
+  // 16-byte LDS reads for 16 multiply-adds (entry per thread: two 4-byte reads per multiply-add, 512 per tile at Cq = 16)
+  constexpr bool PWB = CQ >= 8;
+  constexpr int NB = (CQ / 4) * (CQ / 4), SLB = TPB / NB;
+  float acc_pb[PWB ? 16 : 1];
+#pragma unroll
+  for (int i = 0; i < (PWB ? 16 : 1); i++) acc_pb[i] = 0.f;
   for (long tidx = blockIdx.x; tidx < ntiles; tidx += gridDim.x) {
     const int n = (int)(tidx / (tiles_y * tiles_x));
     const int tr = (int)(tidx % (tiles_y * tiles_x));
@@ -950,11 +987,16 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
               g[c] = in[r] ? cfo[c] * (dv[r][q4][e] - cfo[16 + c] - xh * cfo[32 + c]) : 0.f;
             }
 #pragma unroll
-          for (int c = 0; c < CQ; c++) {
-            float a = 0.f;
+          for (int c4 = 0; c4 < NQ; c4++) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int oc = 0; oc < CQ; oc++) a = fmaf(wpl[oc * CQ + c], g[oc], a);
-            dd[c] = a;
+            for (int oc = 0; oc < CQ; oc++) {
+              const f32x4 w4 = *(const f32x4*)(wpl + oc * CQ + 4 * c4);
+#pragma unroll
+              for (int e = 0; e < 4; e++) a[e] = fmaf(w4[e], g[oc], a[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) dd[4 * c4 + e] = a[e];
           }
 #pragma unroll
           for (int q4 = 0; q4 < NQ; q4++) ddt[q4 * DN + idx] = f32x4{dd[4 * q4], dd[4 * q4 + 1], dd[4 * q4 + 2], dd[4 * q4 + 3]};
@@ -974,7 +1016,7 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
     {
       float d[CQ];
       if (live) {
-        dw_at<CQ, K, DIL, false>(rt, IN, IW, S * ly, S * lx, wdl, d);
+        dw_at<CQ, K, DIL, false, true>(rt, IN, IW, S * ly, S * lx, wdl, d);
       } else {
 #pragma unroll
         for (int c = 0; c < CQ; c++) d[c] = 0.f;
@@ -983,15 +1025,27 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
       for (int c = 0; c < CQ; c++) Ds[threadIdx.x * CQ + c] = d[c];
     }
     __syncthreads();
+    if constexpr (PWB) {
+      const int blk = threadIdx.x % NB, sl = threadIdx.x / NB;
+      const int ob = blk / (CQ / 4), cb = blk % (CQ / 4);
+      for (int p = sl; p < TPB; p += SLB) {
+        const f32x4 g4 = *(const f32x4*)(Gs + p * CQ + 4 * ob), d4 = *(const f32x4*)(Ds + p * CQ + 4 * cb);
 #pragma unroll
-    for (int i = 0; i < NPW; i++) {
-      const int t = threadIdx.x + i * TPB;
-      if (t < SL * CQ * CQ) {
-        const int e = t % (CQ * CQ), sl = t / (CQ * CQ);
-        const int oc = e / CQ, c = e % CQ;
-        float a = 0.f;
-        for (int p = sl; p < TPB; p += SL) a = fmaf(Gs[p * CQ + oc], Ds[p * CQ + c], a);
-        acc_pw[i] += a;
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 4; b++) acc_pb[4 * a + b] = fmaf(g4[a], d4[b], acc_pb[4 * a + b]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPW; i++) {
+        const int t = threadIdx.x + i * TPB;
+        if (t < SL * CQ * CQ) {
+          const int e = t % (CQ * CQ), sl = t / (CQ * CQ);
+          const int oc = e / CQ, c = e % CQ;
+          float a = 0.f;
+          for (int p = sl; p < TPB; p += SL) a = fmaf(Gs[p * CQ + oc], Ds[p * CQ + c], a);
+          acc_pw[i] += a;
+        }
       }
     }
     // ---- depthwise weight gradient: entry (channel quad, tap) sums dd[o][c] * r[S*o - PAD + DIL*tap][c] over the tile's
@@ -1030,8 +1084,9 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
               const int tx = b + PAD - DIL * i;
               if (tx % S != 0) continue;
               const f32x4 v = ddt[q4 * DN + (ly + HB + ty / S) * DW + lx + HB + tx / S];
+              const f32x4 w4 = *(const f32x4*)(wdl + (j * K + i) * CQ + 4 * q4);
 #pragma unroll
-              for (int e = 0; e < 4; e++) sacc[e] = fmaf(wdl[(4 * q4 + e) * KK + j * K + i], v[e], sacc[e]);
+              for (int e = 0; e < 4; e++) sacc[e] = fmaf(w4[e], v[e], sacc[e]);
             }
           }
           const f32x4 r = rt[q4 * IN + (S * ly + a + PAD) * IW + S * lx + b + PAD];
@@ -1070,7 +1125,20 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
     for (int e = 0; e < 4; e++) wrow[dw_off + (4 * q4 + e) * KK + tap] = a[e];
   }
   __syncthreads();
-  if (SL > 1) {
+  if constexpr (PWB) {
+    // [slice][block][16] through LDS (TPB * 16 floats = the Gs + Ds region at Cq = 8, half of it at Cq = 16), then one thread per entry
+    // adds the slices in a fixed order
+#pragma unroll
+    for (int i = 0; i < 16; i++) Gs[threadIdx.x * 16 + i] = acc_pb[i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < CQ * CQ; e += TPB) {
+      const int oc = e / CQ, c = e % CQ;
+      const int blk = (oc / 4) * (CQ / 4) + c / 4, within = (oc % 4) * 4 + c % 4;
+      float a = 0.f;
+      for (int sl = 0; sl < SLB; sl++) a += Gs[(sl * NB + blk) * 16 + within];
+      wrow[pw_off + e] = a;
+    }
+  } else if (SL > 1) {
     Gs[threadIdx.x] = acc_pw[0];
     __syncthreads();
     if (threadIdx.x < CQ * CQ) {

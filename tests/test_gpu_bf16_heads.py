@@ -209,3 +209,41 @@ def test_resnet_gru_model_train_step_bf16(hip_lib, bf16_mode):
     assert set(g16) == set(g32) and len(g32) > 0
     for n in g32:
         assert rel_err(g16[n], g32[n]) < 1e-1, (n, rel_err(g16[n], g32[n]))
+
+
+def test_darts_vqa_weight_step_bf16_vs_fp32(hip_lib, bf16_mode):
+    """BASELINE configs[4]'s model (darts_vqa VqaModel with the PC-DARTS search encoder) under the bf16 compute dtype at its own
+    shapes (224x224, QV = 17 858, A = 3129, B = 2): the heads -- encoder fc 12544 -> 512, LSTM input projection, fused token head +
+    cross entropy, fusion fc1 / fc2 -- run on the bf16 GEMMs, the MixedOp edges stay fp32 (HBM-bound stencils: DESIGN.md).  One
+    weight step against the same step in fp32: loss 2e-3, every gradient within 5e-2 of its largest entry (alpha / beta included),
+    and the fused token-head path is really taken (no [B,T,QV] logits tensor is allocated)."""
+    ops = bf16_mode
+    from lct_vqa_amd.darts_vqa import config, vqa_model
+    from lct_vqa_amd.basic_vqa import config as bconfig
+    config.DEVICE = bconfig.DEVICE = torch.device(DEV)
+    dims = dict(embed_size=512, qst_vocab_size=17858, ans_vocab_size=3129, word_embed_size=300, num_layers=1, hidden_size=512)
+    g = torch.Generator().manual_seed(21)
+    img = torch.randn(2, 3, 224, 224, generator=g).to(DEV)
+    qst = torch.randint(0, dims['qst_vocab_size'], (2, 14), generator=g).to(DEV)
+    lab = torch.randint(0, dims['ans_vocab_size'], (2,), generator=g).to(DEV)
+    torch.manual_seed(21)
+    m = vqa_model.VqaModel(img_encoder_type='darts', **dims).to(DEV).train()
+    params = list(m.parameters()) + list(m.arch_parameters())
+    res = {}
+    for dt in ('f32', 'bf16'):
+        ops.set_compute_dtype(dt)
+        state = {k: v.clone() for k, v in m.state_dict().items()}          # BatchNorm running statistics move in train mode
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        with ops.dropout_disabled():
+            loss = m._loss(img, qst, lab)
+        peak = torch.cuda.max_memory_allocated() - base
+        gr = torch.autograd.grad(loss, params)
+        m.load_state_dict(state)
+        res[dt] = (loss.item(), gr, peak)
+    ops.set_compute_dtype('bf16')
+    (l32, g32, p32), (l16, g16, p16) = res['f32'], res['bf16']
+    assert abs(l16 - l32) < 2e-3 * abs(l32)
+    for (n, _), a, r in zip(list(m.named_parameters()) + [(f'arch{i}', None) for i in range(4)], g16, g32):
+        assert torch.isfinite(a).all(), n
+        assert rel_err(a, r) < 5e-2, (n, rel_err(a, r))
