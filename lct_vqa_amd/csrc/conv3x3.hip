@@ -343,6 +343,104 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restr
   }
 }
 
+// The first layer on the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32: fp32 FMA chains): implicit GEMM with K = 27 (c, ky, kx)
+// padded to 28 = 14 MFMA steps per 32-pixel x 32-channel tile.  The VALU kernel above spends 27 FMAs per output at the scalar-FMA rate
+// (22 G multiply-adds per B=256 batch = 0.57 ms at peak, 0.85 ms measured); here the multiply-adds cost 0.3 ms of MFMA time under the
+// 3.29 GB of output the layer has to write, which becomes its bound.  Workgroup = 4 waves = 8 output rows x 128 columns x 64 channels;
+// wave w owns columns 32w .. 32w+31.  The zero-padded image rows sit in LDS as [3][6][RL] (index j <-> ix = ox0 + j - 1); a lane's A
+// value of step s is the pixel's tap k = 2s + (lane >> 5), one ds_read_b32 (consecutive lanes, consecutive addresses); its B values
+// (the weights of its output channel for the two taps of each step, both 32-channel halves) live in 28 registers for the whole kernel.
+constexpr int FM_ROWS = 8, FM_NR = FM_ROWS + 2, FM_RL = 132, FM_TS = 68;
+__global__ __launch_bounds__(256, 2) void conv3x3_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ bias, float* __restrict__ y, int B, int H,
+                                                                    int W, int relu) {
+  __shared__ float xin[3 * FM_NR * FM_RL];
+  __shared__ __attribute__((aligned(16))) float tile[4 * 32 * FM_TS];
+  const int gx = (W + 127) / 128, gy = (H + FM_ROWS - 1) / FM_ROWS;
+  const int xh = blockIdx.x % gx, yb = (blockIdx.x / gx) % gy, n = blockIdx.x / (gx * gy);
+  const int ox0 = 128 * xh, oy0 = FM_ROWS * yb;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  // image rows: every load issued before the first LDS store
+  constexpr int NXI = (3 * FM_NR * FM_RL + 255) / 256;
+  float xv[NXI];
+#pragma unroll
+  for (int k = 0; k < NXI; k++) {
+    const int i = tid + 256 * k;
+    const int jj = i % FM_RL, rr = (i / FM_RL) % FM_NR, c = i / (FM_RL * FM_NR);
+    const int iy = oy0 - 1 + rr, ix = ox0 + jj - 1;
+    const bool ok = i < 3 * FM_NR * FM_RL && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    xv[k] = ok ? x[(((long)n * 3 + c) * H + iy) * W + ix] : 0.f;
+  }
+  // weights through LDS: a coalesced copy of the 64 x 27 floats, then this lane's 28 values wr[t][s] = w[32 t + j][k = 2 s + h]
+  // (k = 27: zero) -- fetched straight from global each lane's loads touch 64 cache lines per instruction
+  float wv[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) wv[k] = (tid + 256 * k < 64 * 27) ? w[tid + 256 * k] : 0.f;
+#pragma unroll
+  for (int k = 0; k < NXI; k++)
+    if (tid + 256 * k < 3 * FM_NR * FM_RL) xin[tid + 256 * k] = xv[k];
+#pragma unroll
+  for (int k = 0; k < 7; k++)
+    if (tid + 256 * k < 64 * 27) tile[tid + 256 * k] = wv[k];      // the output tile's space: free until the first row is done
+  __syncthreads();
+  float wr[2][14];
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int s = 0; s < 14; s++) {
+      const int k = 2 * s + h;
+      wr[t][s] = k < 27 ? tile[(32 * t + j) * 27 + k] : 0.f;      // stride 27 floats between lanes: conflict-free (27 is odd)
+    }
+  __syncthreads();                                               // every wave has its weights before any wave reuses the tile
+  const int lx = 32 * wave + j;                                  // this lane's pixel column inside the 128-column chunk
+  if (ox0 + 32 * wave >= W) return;                              // a wave entirely right of the image (no barrier follows)
+  // LDS offset of tap k = 2 s + h relative to (row oyl, column lx): (c * FM_NR + ky) * FM_RL + kx
+  int koff[14];
+#pragma unroll
+  for (int s = 0; s < 14; s++) {
+    const int k = min(2 * s + h, 26);
+    koff[s] = ((k / 9) * FM_NR + (k % 9) / 3) * FM_RL + k % 3 + lx;
+  }
+  const float b0 = bias ? bias[j] : 0.f, b1 = bias ? bias[32 + j] : 0.f;
+  for (int oyl = 0; oyl < FM_ROWS; oyl++) {
+    const int oy = oy0 + oyl;
+    if (oy >= H) break;                                          // uniform
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = b0; acc1[r] = b1; }
+    const float* xr = xin + oyl * FM_RL;
+#pragma unroll
+    for (int s = 0; s < 14; s++) {
+      const float a = xr[koff[s]];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr[0][s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr[1][s], acc1, 0, 0, 0);
+    }
+    // D[row][col]: this lane holds channel col = j of pixels row = (r & 3) + 8 (r >> 2) + 4 h.  Stored from here a store instruction
+    // would write 4 bytes per lane (two 128-byte pieces); through the wave's private LDS tile a lane stores 16 bytes of one pixel and an
+    // instruction four whole 256-byte pixel rows.  LDS operations of one wave execute in order: no barrier.
+    float* T = tile + wave * 32 * FM_TS;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      float v0 = acc0[r], v1 = acc1[r];
+      if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+      T[row * FM_TS + j] = v0;
+      T[row * FM_TS + 32 + j] = v1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float* yb = y + (((long)n * H + oy) * W + ox0 + 32 * wave) * 64 + 4 * (lane & 15);
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const int pr = (lane >> 4) + 4 * c;
+      const f32x4 v = *(const f32x4*)(T + pr * FM_TS + 4 * (lane & 15));
+      if (ox0 + 32 * wave + pr < W) *(f32x4*)(yb + (long)pr * 64) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the tile is rewritten by the next row
+  }
+}
+
 __global__ void maxpool2x2_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W,
                                        int C) {
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
@@ -511,6 +609,15 @@ int lctvqa_conv3x3_nhwc(const float* x, const float* w_oihw, const float* w_pack
 int lctvqa_conv3x3_first_nchw(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc, int B,
                               int H, int W, int Cout, int relu, void* stream) {
   LCT_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_first: bad shape");
+  static int use_mfma = -1;                                      // LCTVQA_FIRST_MFMA=0: the VALU kernel (A/B)
+  if (use_mfma < 0) { const char* e = getenv("LCTVQA_FIRST_MFMA"); use_mfma = (e && e[0] == '0') ? 0 : 1; }
+  if (use_mfma && Cout == 64 && W >= 32) {
+    const long grid = (long)B * ((H + FM_ROWS - 1) / FM_ROWS) * ((W + 127) / 128);
+    LCT_REQUIRE(grid < (1L << 31), "conv3x3_first: grid too large");
+    hipLaunchKernelGGL(conv3x3_first_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw, bias, y_nhwc,
+                       B, H, W, relu);
+    return lct_check_launch("conv3x3_first_mfma");
+  }
   size_t lds = (size_t)(9 * ((W + 2 + 8 + 3) & ~3) + 27 * 64) * sizeof(float);
   LCT_REQUIRE(lds <= 64 * 1024, "conv3x3_first: W too large");
   hipLaunchKernelGGL(conv3x3_first_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, x_nchw, w_oihw, bias,

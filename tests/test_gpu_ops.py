@@ -147,14 +147,17 @@ def test_conv3x3_full_res_layer(ops, hip_lib):
 
 def test_conv_first_and_pool_and_avgpool(hip_lib):
     g = torch.Generator().manual_seed(1)
-    for (B, H, W) in [(2, 32, 32), (1, 224, 224), (3, 10, 6)]:
+    # (2,32,32), (1,224,224), (2,40,150), (1,33,129): the fp32 MFMA kernel (Cout = 64, W >= 32; ragged rows / column chunks / a
+    # wave right of the image); (3,10,6): the VALU kernel
+    for (B, H, W) in [(2, 32, 32), (1, 224, 224), (3, 10, 6), (2, 40, 150), (1, 33, 129)]:
         x = torch.randn(B, 3, H, W, generator=g)
         w = torch.randn(64, 3, 3, 3, generator=g) * 0.2
         b = torch.randn(64, generator=g) * 0.1
         ref = torch.relu(F.conv2d(x, w, b, padding=1))
-        y = torch.empty(B, H, W, 64, device=DEV)
+        y = torch.full((B, H, W, 64), float('nan'), device=DEV)
         hip_lib('conv3x3_first_nchw', x.to(DEV), w.to(DEV), b.to(DEV), y, B, H, W, 64, 1)
         assert rel_err(y.permute(0, 3, 1, 2).cpu(), ref) < 1e-5
+        y = y.clone()
         yp = torch.empty(B, H // 2, W // 2, 64, device=DEV)
         hip_lib('maxpool2x2_nhwc', y, yp, B, H, W, 64)
         assert torch.equal(yp.permute(0, 3, 1, 2).cpu(), F.max_pool2d(y.permute(0, 3, 1, 2).cpu(), 2, 2))

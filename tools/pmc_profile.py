@@ -25,7 +25,20 @@ def load(d):
 
 
 def short(k):
-    return k.split('(')[0]
+    """kernel name without return type, anonymous-namespace prefix and argument list (template arguments kept)"""
+    import re
+    k = re.sub(r'\(anonymous namespace\)::', '', k)
+    k = re.sub(r'^void ', '', k)
+    depth, out = 0, []
+    for ch in k:                       # cut at the first '(' outside template brackets
+        if ch == '<':
+            depth += 1
+        elif ch == '>':
+            depth -= 1
+        elif ch == '(' and depth == 0:
+            break
+        out.append(ch)
+    return ''.join(out).strip()
 
 
 def main():
