@@ -178,15 +178,26 @@ def dp_record(world, local, reducers):
         return None
     import torch.distributed as dist
     from lct_vqa_amd import parallel
-    ranks = parallel.describe_ranks(local)
-    rec = {'backend': dist.get_backend(), 'rccl': '.'.join(map(str, torch.cuda.nccl.version())) if dist.get_backend() == 'nccl' else None,
-           'world': world, 'devices': ranks,
-           'distinct_devices': len({(r['bus'], r['uuid'], r['device']) for r in ranks}),
-           'rehearsal_one_gpu': os.environ.get('LCTVQA_REHEARSE_ONE_GPU') == '1'}
-    for i, r in enumerate(reducers):
-        d = r.describe()
-        rec.update({(k if i == 0 else f'{k}_{i}'): v for k, v in d.items()})
-    rec['allreduce_ms_per_step'] = sum(r.describe()['allreduce_wait_ms_per_step'] for r in reducers)
+    # the record is diagnostic: nothing in it may cost the bench line.  The gather itself is a collective every rank takes part in, so
+    # it either works on all ranks or raises on all of them (and then the record says why instead of listing devices).
+    rec = {'backend': dist.get_backend(), 'world': world, 'rehearsal_one_gpu': os.environ.get('LCTVQA_REHEARSE_ONE_GPU') == '1'}
+    try:
+        rec['rccl'] = '.'.join(map(str, torch.cuda.nccl.version())) if rec['backend'] == 'nccl' else None
+    except Exception as e:                          # noqa: BLE001
+        rec['rccl'] = f'unavailable ({type(e).__name__})'
+    try:
+        ranks = parallel.describe_ranks(local)
+        rec['devices'] = ranks
+        rec['distinct_devices'] = len({(r['bus'], r['uuid'], r['device']) for r in ranks})
+    except Exception as e:                          # noqa: BLE001
+        rec['devices'] = f'gather failed: {type(e).__name__}: {e}'
+    try:
+        per = [r.describe() for r in reducers]
+        for i, d in enumerate(per):
+            rec.update({(k if i == 0 else f'{k}_{i}'): v for k, v in d.items()})
+        rec['allreduce_ms_per_step'] = sum(d['allreduce_wait_ms_per_step'] for d in per)
+    except Exception as e:                          # noqa: BLE001
+        rec['reducers'] = f'unavailable: {type(e).__name__}: {e}'
     return rec
 
 

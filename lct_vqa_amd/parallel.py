@@ -175,8 +175,12 @@ def describe_ranks(local):
     """[{rank, device, name, bus}] gathered from every rank (rank order): which GPU each process really drives."""
     import os
     props = torch.cuda.get_device_properties(local)
+    try:
+        uuid = str(props.uuid)
+    except Exception:                               # noqa: BLE001 - not every build exposes it
+        uuid = None
     me = {'rank': dist.get_rank() if dist.is_initialized() else 0, 'device': f'cuda:{local}', 'name': props.name,
-          'bus': getattr(props, 'pci_bus_id', None), 'uuid': str(getattr(props, 'uuid', '')) or None, 'pid': os.getpid()}
+          'bus': getattr(props, 'pci_bus_id', None), 'uuid': uuid, 'pid': os.getpid()}
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [me]
     out = [None] * dist.get_world_size()
