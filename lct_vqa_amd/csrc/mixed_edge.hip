@@ -49,17 +49,18 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 // floats); ACT 0: as stored, 1: ReLU'd, 2: normalised + ReLU'd ((v - mean) * invstd, then max 0: the input of a sep_conv's
 // second stage).  The trip counts are compile-time, so the loads of up to 8 rounds are issued back to back before the first
 // LDS store (one memory round trip per batch instead of one per round).
-template <int NQ, int ACT, int TH_, int TW_, int TPB>
+template <int NQ, int ACT, int TH_, int TW_, int TPB, int BATCH_ = 0>
 __device__ __forceinline__ void load_tile(f32x4* __restrict__ tile, const float* __restrict__ src, long ld, int n, int H, int W,
-                                          int y0, int x0, const float* __restrict__ mean, const float* __restrict__ invstd) {
-  constexpr int NPOS = TH_ * TW_, TOT = NPOS * NQ, ROUNDS = (TOT + TPB - 1) / TPB, BATCH = NQ >= 4 ? 4 : 8;
+                                          int y0, int x0, const float* __restrict__ mean, const float* __restrict__ invstd, int tid_ = -1) {
+  constexpr int NPOS = TH_ * TW_, TOT = NPOS * NQ, ROUNDS = (TOT + TPB - 1) / TPB, BATCH = BATCH_ ? BATCH_ : (NQ >= 4 ? 4 : 8);
+  const int tid = tid_ < 0 ? (int)threadIdx.x : tid_;            // a caller may pass a laundered copy (keeps the index math inside its tile loop)
 #pragma unroll
   for (int r0 = 0; r0 < ROUNDS; r0 += BATCH) {
     f32x4 v[BATCH];
     bool ok[BATCH];
 #pragma unroll
     for (int r = 0; r < BATCH; r++) {
-      const int idx = threadIdx.x + (r0 + r) * TPB;
+      const int idx = tid + (r0 + r) * TPB;
       const int q = idx % NQ, pos = idx / NQ;
       const int ly = pos / TW_, lx = pos - ly * TW_;
       const int y = y0 + ly, x = x0 + lx;
@@ -69,7 +70,7 @@ __device__ __forceinline__ void load_tile(f32x4* __restrict__ tile, const float*
     }
 #pragma unroll
     for (int r = 0; r < BATCH; r++) {
-      const int idx = threadIdx.x + (r0 + r) * TPB;
+      const int idx = tid + (r0 + r) * TPB;
       if (r0 + r < ROUNDS && idx < TOT) {
         const int q = idx % NQ, pos = idx / NQ;
         f32x4 t = v[r];
@@ -588,7 +589,17 @@ __global__ __launch_bounds__(256) void edge_bwd_sums_kernel(const float* __restr
 __global__ __launch_bounds__(1024) void edge_bwd_coef_kernel(const float* __restrict__ part, int nblk, int CQ, long P, int S, int training,
                                                              const float* __restrict__ wsel, const float* __restrict__ beta,
                                                              const float* __restrict__ invstd, float* __restrict__ coef,
-                                                             float* __restrict__ dw, float* __restrict__ dbeta) {
+                                                             float* __restrict__ dw, float* __restrict__ dbeta, EdgeW wts,
+                                                             float* __restrict__ wtaps /* tap-major [K*K][CQ] copies of the six depthwise weights */) {
+  {
+    const int taps[6] = {9, 25, 9, 25, 9, 25};
+    int off = 0;
+    for (int i = 0; i < 6; i++) {
+      const int kk = taps[i];
+      for (int idx = threadIdx.x; idx < kk * CQ; idx += 1024) wtaps[off + (idx % kk) * CQ + idx / kk] = wts.dw[i][idx];
+      off += kk * CQ;
+    }
+  }
   __shared__ double grp[7][8 * 16 + 1];
   __shared__ double tot[8 * 16 + 1];
   const int ncol = 8 * CQ + 1;
@@ -1160,6 +1171,282 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// edge_bwd_conv2: the same stage backward (same arguments, same outputs), laid out for the machine instead of for the pixel:
+//   phase B  dd = Wpw^T g on the halo of output positions: lane = (position, channel quad), the 1x1 product is four
+//            v_mfma_f32_16x16x4_f32 (exact fp32) whose B operand IS that layout (k-slot (kk, lane group) = channel 4*quad + kk) and
+//            whose result lands in it again; the 1x1 weights sit in four registers per lane (block-diagonal for Cq < 16: 16 / Cq
+//            position blocks share one instruction).  No LDS traffic for the 1x1.
+//   phase C  depthwise part: a WAVE owns one channel quad for the whole kernel, a lane one pixel of a 64-pixel item.  The quad's
+//            weights are wave-uniform: scalar loads from a tap-major copy (SGPR operands of v_pk_fma_f32, no LDS, no VGPRs);
+//            the recomputed depthwise output, the input gradient (gather over the taps of the dd tile) and the depthwise weight
+//            gradient share the tile reads; the weight gradient is K*K float4 accumulators PER LANE carried over all tiles
+//            (the first version re-read both tiles once per (tap, pixel) from a second thread mapping).
+//   phase D  1x1 weight gradient = sum over pixels g (x) d on the matrix cores, pixels on the k index (A = Gs, B = Ds read as
+//            4-byte words, lane = channel), accumulated in 4 registers per lane over all tiles.
+// LDS bytes read per tile: about a third of the first version's; three barriers per tile instead of four.
+// ------------------------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) f32x4* const_f32x4_ptr;   // constant address space: uniform loads become s_load
+
+template <int CQ, int K, int DIL, int S, int MODE, int TH, int TW, int NW, int WPE>
+__global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_kernel(const float* __restrict__ in, long ldin, const float* __restrict__ gsrc /* dY or dBN */,
+                                                                 const float* __restrict__ usrc /* u or t: pre-BN output of this stage */,
+                                                                 const float* __restrict__ mean_o, const float* __restrict__ invstd_o,
+                                                                 const float* __restrict__ coef_o, const float* __restrict__ mean_i,
+                                                                 const float* __restrict__ invstd_i, const float* __restrict__ w_taps /* [K*K][CQ] */,
+                                                                 const float* __restrict__ w_pw, int B, int H, int W,
+                                                                 float* __restrict__ dst /* dx1c [B,H,W,CQ] (MODE 0, 2) or dBN [P][CQ] (MODE 1) */,
+                                                                 int accumulate, double* __restrict__ spart /* MODE 1: [grid][2*CQ][2] */,
+                                                                 float* __restrict__ wpart, int wtot, int dw_off, int pw_off) {
+  constexpr int TPB = 64 * NW, NPX = TH * TW, NQ = CQ / 4, KK = K * K, PAD = DIL * (K - 1) / 2, HB = (PAD + S - 1) / S;
+  constexpr int IH = S * (TH - 1) + 2 * PAD + 1, IW = S * (TW - 1) + 2 * PAD + 1, IN = IH * IW;
+  constexpr int DH = TH + 2 * HB, DW = TW + 2 * HB, DN = DH * DW;
+  constexpr int PPW = 64 / NQ;                                   // positions of one phase-B item (16 per position block)
+  constexpr int NITB = (DN + PPW - 1) / PPW, ITB = (NITB + NW - 1) / NW;
+  constexpr int NITC = NPX / 64, ITC = NITC * NQ / NW;           // 64-pixel items; (item, quad) pairs per wave
+  constexpr int NBK = 16 / CQ;                                   // position blocks of one 16x16x4 instruction
+  constexpr int NM = NPX / (4 * NBK), MPW = NM / NW;             // phase-D instructions per tile / per wave
+  constexpr int RK = NW / NQ, NT = (KK + RK - 1) / RK;           // waves that share a quad split the K*K taps of the depthwise weight gradient
+  static_assert(NW % NQ == 0 && (NITC * NQ) % NW == 0 && NPX % 64 == 0 && NM % NW == 0 && (TW & (TW - 1)) == 0, "tile / wave split");
+  extern __shared__ __align__(16) unsigned char smem[];
+  f32x4* rt = (f32x4*)smem;                                     // [NQ][IN] activated input
+  f32x4* ddt = rt + NQ * IN;                                    // [NQ][DN]
+  float* Gs = (float*)(ddt + NQ * DN);                         // [NPX][CQ]
+  float* Ds = Gs + NPX * CQ;                                   // [NPX][CQ]
+  float* cst = Ds + NPX * CQ;                                  // [5][CQ]: mean, invstd of the stage's output BN, its three coefficients
+  float* msi = cst + 5 * CQ;                                   // MODE 1: mean/invstd of the input BN [2][CQ]
+  for (int i = threadIdx.x; i < CQ; i += TPB) {
+    cst[i] = mean_o[i]; cst[CQ + i] = invstd_o[i];
+    cst[2 * CQ + i] = coef_o[i]; cst[3 * CQ + i] = coef_o[16 + i]; cst[4 * CQ + i] = coef_o[32 + i];
+    if (MODE == 1) { msi[i] = mean_i[i]; msi[CQ + i] = invstd_i[i]; }
+  }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n16 = lane & 15, jg = lane >> 4;
+  // phase B: lane = (position slot n16 + 16 * block, channel quad qB)
+  const int qB = jg % NQ, blkB = jg / NQ, slotB = n16 + 16 * blkB;
+  float aop[4];                                                 // A[i = (block, c)][k-slot (kk, jg)] = Wpw[oc = 4 qB + kk][c] on the block diagonal
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) aop[kk] = (n16 / CQ == blkB) ? w_pw[(4 * qB + kk) * CQ + n16 % CQ] : 0.f;
+  // phase C: this wave's channel quad and its weights (scalar loads)
+  const int qC = wave % NQ, itc0 = wave / NQ;                   // itc0 = this wave's rank among the RK waves of its quad
+  f32x4 accdw[NT];                                              // taps s * RK + rank (a clamped duplicate in the last slot of some ranks: never written out)
+  int toff[NT];                                                 // their tile offsets (scalar)
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    accdw[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tap = (t * RK + itc0) < KK ? t * RK + itc0 : KK - 1;
+    toff[t] = (DIL * (tap / K)) * IW + DIL * (tap % K);
+  }
+  f32x4 accp = {0.f, 0.f, 0.f, 0.f};
+  f32x4 st0 = {0.f, 0.f, 0.f, 0.f}, st1 = st0;
+  const int Ho = H / S, Wo = W / S;
+  const int tiles_y = (Ho + TH - 1) / TH, tiles_x = (Wo + TW - 1) / TW;
+  const long ntiles = (long)B * tiles_y * tiles_x;
+  for (long tidx = blockIdx.x; tidx < ntiles; tidx += gridDim.x) {
+    const int n = (int)(tidx / (tiles_y * tiles_x));
+    const int tr = (int)(tidx % (tiles_y * tiles_x));
+    const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+    __syncthreads();
+    int tid = threadIdx.x, slot = slotB, ln = lane;
+    asm volatile("" : "+v"(tid), "+v"(slot), "+v"(ln));           // per-tile copies: the index math of every round stays inside the loop
+    {   // ---- phase B (the loads of its first rows are requested BEFORE the input tile: one memory round trip for both) ----
+      constexpr int UB = ITB < 4 ? ITB : 4;
+      f32x4 dv[UB], uv[UB];
+      bool inb[UB];
+      auto request = [&](int b0) {
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+          const int idx = (wave + (b0 + u) * NW) * PPW + slot;
+          const int oy = ty0 - HB + idx / DW, ox = tx0 - HB + idx % DW;
+          inb[u] = (b0 + u < ITB) && idx < DN && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
+          dv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          uv[u] = dv[u];
+          if (inb[u]) {
+            const long q = ((long)n * Ho + oy) * Wo + ox;
+#ifdef EDGE_ABL_NOGLOAD
+            dv[u] = f32x4{1.f, 2.f, 3.f, (float)q}; uv[u] = dv[u];
+#else
+            dv[u] = *(const f32x4*)(gsrc + q * CQ + 4 * qB);
+            uv[u] = *(const f32x4*)(usrc + q * CQ + 4 * qB);
+#endif
+          }
+        }
+      };
+      request(0);
+#ifdef EDGE_ABL_NOTILE
+      for (int i = tid; i < NQ * IN; i += TPB) rt[i] = f32x4{1.f, 0.f, 2.f, (float)i};
+#else
+      load_tile<NQ, MODE == 1 ? 2 : 1, IH, IW, TPB>(rt, in, ldin, n, H, W, S * ty0 - PAD, S * tx0 - PAD, msi, msi + CQ, tid);
+#endif
+      const f32x4 mn = *(const f32x4*)(cst + 4 * qB), is = *(const f32x4*)(cst + CQ + 4 * qB);
+      const f32x4 c0 = *(const f32x4*)(cst + 2 * CQ + 4 * qB), c1 = *(const f32x4*)(cst + 3 * CQ + 4 * qB), c2 = *(const f32x4*)(cst + 4 * CQ + 4 * qB);
+#pragma unroll
+      for (int b0 = 0; b0 < ITB; b0 += UB) {
+        if (b0) request(b0);
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+          if (b0 + u < ITB && wave + (b0 + u) * NW < NITB) {      // wave-uniform
+            const int idx = (wave + (b0 + u) * NW) * PPW + slot;
+            f32x4 g;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const float xh = (uv[u][e] - mn[e]) * is[e];
+              g[e] = inb[u] ? c0[e] * (dv[u][e] - c1[e] - xh * c2[e]) : 0.f;
+            }
+            f32x4 dd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) dd = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[kk], g[kk], dd, 0, 0, 0);
+            if (idx < DN) {
+              ddt[qB * DN + idx] = dd;
+              const int py = idx / DW - HB, px = idx % DW - HB;     // position inside the owned tile: leave g for the 1x1 weight gradient
+              if (py >= 0 && py < TH && px >= 0 && px < TW) *(f32x4*)(Gs + (py * TW + px) * CQ + 4 * qB) = g;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase C ----  (one item at a time: unrolled items would keep several items' tile reads and all K*K weight quads live)
+#pragma unroll 1
+    for (int t = 0; t < ITC; t++) {
+      unsigned long wqa = (unsigned long)(uintptr_t)(w_taps + 4 * qC);
+      asm volatile("" : "+s"(wqa));                              // re-issue the scalar weight loads per item instead of holding 4*K*K SGPRs
+      const const_f32x4_ptr wq = (const_f32x4_ptr)wqa;
+      const int p = (itc0 + t * (NW / NQ)) * 64 + ln;
+      const int ly = p / TW, lx = p % TW;
+      const int oy = ty0 + ly, ox = tx0 + lx;
+      const bool live = oy < Ho && ox < Wo;
+      const f32x4* rp = rt + qC * IN + (S * ly) * IW + S * lx;
+      const f32x4* dq = ddt + qC * DN + (ly + HB) * DW + lx + HB;
+      f32x4 prev[S * S];                                           // what the earlier stages left in dst: requested now, used after the tap loops
+#pragma unroll
+      for (int ab = 0; ab < S * S; ab++) {
+        prev[ab] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int iy = S * oy + ab / S, ix = S * ox + ab % S;
+#ifndef EDGE_ABL_NOACC
+        if (MODE != 1 && accumulate && live && iy < H && ix < W) prev[ab] = *(const f32x4*)(dst + (((long)n * H + iy) * W + ix) * CQ + 4 * qC);
+#endif
+      }
+      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < K; j++)
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+          const f32x4 v = rp[(DIL * j) * IW + DIL * i];
+          const f32x4 w4 = wq[(j * K + i) * NQ];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            d[e] = fmaf(w4[e], v[e], d[e]);
+          }
+        }
+      *(f32x4*)(Ds + p * CQ + 4 * qC) = d;
+#pragma unroll
+      for (int a = 0; a < S; a++)
+#pragma unroll
+        for (int b = 0; b < S; b++) {
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            const int ty = a + PAD - DIL * j;
+            if (ty % S != 0) continue;
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+              const int tx = b + PAD - DIL * i;
+              if (tx % S != 0) continue;
+              const f32x4 v = dq[(ty / S) * DW + tx / S];
+              const f32x4 w4 = wq[(j * K + i) * NQ];
+#pragma unroll
+              for (int e = 0; e < 4; e++) sacc[e] = fmaf(w4[e], v[e], sacc[e]);
+            }
+          }
+          const f32x4 r = rp[(a + PAD) * IW + b + PAD];
+          f32x4 din;
+#pragma unroll
+          for (int e = 0; e < 4; e++) din[e] = r[e] > 0.f ? sacc[e] : 0.f;
+          if (MODE == 1 && live) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { st0[e] += din[e]; st1[e] = fmaf(din[e], r[e], st1[e]); }
+          }
+          const int iy = S * oy + a, ix = S * ox + b;
+          if (live && iy < H && ix < W) {
+            float* dp = dst + (((long)n * H + iy) * W + ix) * CQ + 4 * qC;
+            *(f32x4*)dp = din + prev[a * S + b];
+          }
+        }
+    }
+#ifndef EDGE_ABL_NODW
+    // depthwise weight gradient: every wave walks ALL items of the tile for its quad with its own NT taps (K*K accumulators per lane
+    // cost K = 5 its occupancy: 256 registers and spills; split over the RK waves of the quad they are 28 / 52 registers)
+#pragma unroll 1
+    for (int it = 0; it < NITC; it++) {
+      const int p = it * 64 + ln;
+      const int ly = p / TW, lx = p % TW;
+      const f32x4* rp = rt + qC * IN + (S * ly) * IW + S * lx;
+      const f32x4 ddo = ddt[qC * DN + (ly + HB) * DW + lx + HB];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const f32x4 v = rp[toff[t]];
+#pragma unroll
+        for (int e = 0; e < 4; e++) accdw[t][e] = fmaf(ddo[e], v[e], accdw[t][e]);
+      }
+    }
+#endif
+    __syncthreads();
+    // ---- phase D ----
+#pragma unroll
+    for (int m = 0; m < MPW; m++) {
+      const int pix = (wave * MPW + m) * (4 * NBK) + 4 * (n16 / CQ) + jg;
+      accp = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[pix * CQ + n16 % CQ], Ds[pix * CQ + n16 % CQ], accp, 0, 0, 0);
+    }
+  }
+  // ---- per-workgroup partial weight gradients (fixed order) ----
+  __syncthreads();
+  float* wrow = wpart + (long)blockIdx.x * wtot;
+  float* fin = (float*)smem;                                    // [NW][16][NT*4] then [NW][16][16] then [NW][8]
+  float* fin2 = fin + NW * 16 * NT * 4;
+  float* fin3 = fin2 + NW * 256;
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    f32x4 v = accdw[t];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { v[e] += __shfl_xor(v[e], 32, 64); v[e] += __shfl_xor(v[e], 16, 64); }
+    if (lane < 16) *(f32x4*)(fin + ((wave * 16 + lane) * NT + t) * 4) = v;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) fin2[wave * 256 + (4 * jg + r) * 16 + n16] = accp[r];
+  if (MODE == 1) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float a = wave_sum(st0[e]), b = wave_sum(st1[e]);
+      if (lane == 0) { fin3[wave * 8 + e] = a; fin3[wave * 8 + 4 + e] = b; }
+    }
+  }
+  __syncthreads();
+  for (int ent = threadIdx.x; ent < CQ * KK; ent += TPB) {
+    const int c = ent / KK, tap = ent % KK;
+    const int w = c / 4 + NQ * (tap % RK), t = tap / RK;           // the one wave that owns (quad, tap)
+    float a = 0.f;
+    for (int l = 0; l < 16; l++) a += fin[((w * 16 + l) * NT + t) * 4 + c % 4];
+    wrow[dw_off + ent] = a;
+  }
+  for (int ent = threadIdx.x; ent < CQ * CQ; ent += TPB) {
+    const int oc = ent / CQ, c = ent % CQ;
+    float a = 0.f;
+    for (int w = 0; w < NW; w++)
+      for (int b = 0; b < NBK; b++) a += fin2[w * 256 + (b * CQ + oc) * 16 + b * CQ + c];
+    wrow[pw_off + ent] = a;
+  }
+  if (MODE == 1) {
+    for (int i = threadIdx.x; i < 2 * CQ; i += TPB) {
+      const int k = i / CQ, c = i % CQ;
+      double a = 0.0;
+      for (int w = c / 4; w < NW; w += NQ) a += (double)fin3[w * 8 + 4 * k + c % 4];
+      spart[((long)blockIdx.x * 2 * CQ + i) * 2 + 0] = a;
+      spart[((long)blockIdx.x * 2 * CQ + i) * 2 + 1] = 0.0;
+    }
+  }
+}
+
 // out[col] = sum over the partial rows of the kernel that produced the column (fixed order, fp64).  Column sections: the
 // depthwise gradients of conv 0..5 (9, 25, 9, 25, 9, 25 taps x Cq), their 1x1 gradients (Cq x Cq each), FactorizedReduce;
 // nb.n[i] = workgroups of conv kernel i (i = 0..5), nb.n[6] = of the pooling kernel.
@@ -1195,6 +1482,15 @@ size_t bwd_conv_lds() {
   size_t floats = (size_t)NQ * IN * 4 + NQ * DN * 4 + 2 * TPB * CQ + CQ * KK + CQ * CQ + 2 * CQ + COEF + 2 * CQ;
   if (MODE == 1) floats += 8 * (TPB + 1) + 128 + 1;
   return floats * 4 + (MODE == 1 ? 4 * CQ * 8 : 0) + 16;
+}
+
+template <int CQ, int K, int DIL, int S, int MODE, int TH, int TW, int NW>
+size_t bwd_conv2_lds() {
+  constexpr int NPX = TH * TW, NQ = CQ / 4, KK0 = K * K, RK = NW / NQ, KK = (KK0 + RK - 1) / RK, PAD = DIL * (K - 1) / 2, HB = (PAD + S - 1) / S;
+  constexpr int IN = (S * (TH - 1) + 2 * PAD + 1) * (S * (TW - 1) + 2 * PAD + 1), DN = (TH + 2 * HB) * (TW + 2 * HB);
+  const size_t tile = (size_t)NQ * IN * 4 + NQ * DN * 4 + 2 * NPX * CQ + 7 * CQ;
+  const size_t fin = (size_t)NW * 16 * KK * 4 + NW * 256 + NW * 8;
+  return (tile > fin ? tile : fin) * 4 + 16;
 }
 
 template <int CQ, int S, int TH, int TW>
@@ -1273,7 +1569,7 @@ long lctvqa_mixed_edge_bwd_scratch_floats(int B, int H, int W, int C, int stride
   const int CQ = C / 4;
   const long P = (long)B * (H / stride) * (W / stride);
   const long G = lctvqa_mixed_edge_grid(B, H, W, C, stride);
-  return 3 * P * CQ + (long)B * H * W * CQ + 1536L * (8 * CQ + 1) + 9 * COEF + G * lctvqa_mixed_edge_wgrad_elems(C) + 2 * (2 * G * 2 * CQ * 2) + 8;
+  return 3 * P * CQ + (long)B * H * W * CQ + 1536L * (8 * CQ + 1) + 9 * COEF + 102 * CQ + G * lctvqa_mixed_edge_wgrad_elems(C) + 2 * (2 * G * 2 * CQ * 2) + 8;
 }
 
 // Forward of one edge.  w: 14 pointers = dw[6], pw[6], fr[2] (fr null on stride-1 edges); bn: 27 pointers = run_mean[9],
@@ -1367,7 +1663,8 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
   float* part1 = dx1c + (long)B * H * W * CQ;                  // [<=1536][8*CQ+1]
   float* coef = part1 + 1536L * (8 * CQ + 1);
   coef += (4 - ((coef - scratch) & 3)) & 3;
-  float* wpart = coef + 9 * COEF;                              // [G][wtot]
+  float* wtaps = coef + 9 * COEF;                              // tap-major copies of the depthwise weights (16-byte aligned), offsets dw_off
+  float* wpart = wtaps + 102 * CQ;                             // [G][wtot]
   float* sp = wpart + (long)G * wtot;
   sp += ((uintptr_t)sp & 7) ? 1 : 0;
   double* spart = (double*)sp;                                 // [2][G][2*CQ][2]
@@ -1382,11 +1679,38 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
     else
       hipLaunchKernelGGL(edge_bwd_sums_kernel<2>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, part1);
     if ((rc = lct_check_launch("edge_bwd_sums"))) return rc;
-    hipLaunchKernelGGL(edge_bwd_coef_kernel, dim3(1), dim3(1024), 0, st, part1, (int)nb, CQ, P, stride, training, wsel, beta, invstd, coef, dwsel, dbeta);
+    hipLaunchKernelGGL(edge_bwd_coef_kernel, dim3(1), dim3(1024), 0, st, part1, (int)nb, CQ, P, stride, training, wsel, beta, invstd, coef, dwsel, dbeta, ew, wtaps);
     if ((rc = lct_check_launch("edge_bwd_coef"))) return rc;
   }
 #define TILES(Hv, Wv, THv, TWv) ((long)B * (((Hv) + (THv) - 1) / (THv)) * (((Wv) + (TWv) - 1) / (TWv)))
   // CONV(CQ, K, DIL, S, MODE, TH, TW, conv index, slot of its output BN, input tensor, ldin, H, W, gradient source, dst, accumulate, spart)
+#ifndef EDGE_CONV_V1
+#ifndef EDGE_NW4
+#define EDGE_NW4 4
+#endif
+#ifndef EDGE_NW8
+#define EDGE_NW8 8
+#endif
+#ifndef EDGE_NW16
+#define EDGE_NW16 8
+#endif
+#ifndef EDGE_WPE
+#define EDGE_WPE(CQv, Kv) ((CQv) == 16 ? 2 : ((Kv) == 5 ? 3 : 4))
+#endif
+#define EDGE_NW(CQv, THv, TWv) ((CQv) == 16 ? EDGE_NW16 : ((CQv) == 8 ? EDGE_NW8 : EDGE_NW4))
+#define CONV(CQv, Kv, DILv, Sv, MODEv, THv, TWv, ci, slot, inp, ldv, Hv, Wv, gs, dstp, accv, spp)                           \
+  {                                                                                                                        \
+    constexpr int NWv = EDGE_NW(CQv, THv, TWv);                                                                            \
+    const size_t lds = bwd_conv2_lds<CQv, Kv, DILv, Sv, MODEv, THv, TWv, NWv>();                                           \
+    grid = tile_grid((const void*)edge_bwd_conv2_kernel<CQv, Kv, DILv, Sv, MODEv, THv, TWv, NWv, EDGE_WPE(CQv, Kv)>, 64 * NWv, lds, \
+                     TILES((Hv) / Sv, (Wv) / Sv, THv, TWv), G);                                                            \
+    rows.n[ci] = grid;                                                                                                     \
+    hipLaunchKernelGGL((edge_bwd_conv2_kernel<CQv, Kv, DILv, Sv, MODEv, THv, TWv, NWv, EDGE_WPE(CQv, Kv)>), dim3(grid), dim3(64 * NWv), lds, st, inp, (long)(ldv), gs, \
+                       pre + (long)(slot) * P * CQ, mean + (slot) * CQ, invstd + (slot) * CQ, coef + (slot) * COEF,       \
+                       mean + ((slot) - 4) * CQ, invstd + ((slot) - 4) * CQ, wtaps + dw_off[ci], ew.pw[ci], B, Hv, Wv, dstp, accv, spp, wpart, wtot, \
+                       dw_off[ci], pw_off[ci]);                                                                            \
+  }
+#else
 #define CONV(CQv, Kv, DILv, Sv, MODEv, THv, TWv, ci, slot, inp, ldv, Hv, Wv, gs, dstp, accv, spp)                           \
   {                                                                                                                        \
     const size_t lds = bwd_conv_lds<CQv, Kv, DILv, Sv, MODEv, THv, TWv>();                                                 \
@@ -1398,6 +1722,7 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
                        mean + ((slot) - 4) * CQ, invstd + ((slot) - 4) * CQ, ew.dw[ci], ew.pw[ci], B, Hv, Wv, dstp, accv, spp, wpart, wtot, \
                        dw_off[ci], pw_off[ci]);                                                                            \
   }
+#endif
 #define STAGES(CQv, Sv, THv, TWv)                                                                                          \
   {                                                                                                                        \
     CONV(CQv, 3, 2, Sv, 0, THv, TWv, 2, 5, x, C, H, W, dY, dx1c, 0, (double*)nullptr)                                      \
