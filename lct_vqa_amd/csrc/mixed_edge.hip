@@ -498,7 +498,8 @@ __global__ __launch_bounds__(256) void edge_bwd_sums_kernel(const float* __restr
                                                             const float* __restrict__ pre, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ beta,
                                                             int B, int Ho, int Wo, int CQ, float* __restrict__ dY,
-                                                            float* __restrict__ part /* [grid][8*CQ+1] */) {
+                                                            float* __restrict__ part /* [grid][8*CQ+1] */,
+                                                            float* __restrict__ x1d /* dense copy of x[..., :CQ] for the conv stages: [B,H,W,CQ] */) {
   __shared__ float red[4][33];
   const int NQ = CQ / 4, C = 4 * CQ;
   const long P = (long)B * Ho * Wo;
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(256) void edge_bwd_sums_kernel(const float* __restr
     if (S == 1) {
       const float* xp = x + q * C + 4 * q4;
       const f32x4 x1v = *(const f32x4*)xp;
+      *(f32x4*)(x1d + q * CQ + 4 * q4) = x1v;
 #pragma unroll
       for (int e = 0; e < 4; e++) acc[2][e] = fmaf(dy[e], x1v[e], acc[2][e]);
 #pragma unroll
@@ -542,6 +544,13 @@ __global__ __launch_bounds__(256) void edge_bwd_sums_kernel(const float* __restr
       const int W = 2 * Wo, H = 2 * Ho;
       const long base = (((long)n * H + 2 * oy) * W + 2 * ox) * C + 4 * q4;
       const long rs = (long)W * C;
+      {   // the four x1 quads of the window (same rows as the bypass channels read below)
+        const long pix = ((long)n * H + 2 * oy) * W + 2 * ox;
+        *(f32x4*)(x1d + pix * CQ + 4 * q4) = *(const f32x4*)(x + base);
+        *(f32x4*)(x1d + (pix + 1) * CQ + 4 * q4) = *(const f32x4*)(x + base + C);
+        *(f32x4*)(x1d + (pix + W) * CQ + 4 * q4) = *(const f32x4*)(x + base + rs);
+        *(f32x4*)(x1d + (pix + W + 1) * CQ + 4 * q4) = *(const f32x4*)(x + base + rs + C);
+      }
 #pragma unroll
       for (int g = 1; g < 4; g++) {
         const f32x4 a = *(const f32x4*)(x + base + g * CQ), b = *(const f32x4*)(x + base + C + g * CQ);
@@ -701,7 +710,8 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_pools_kernel(const float* __
                                                                  const float* __restrict__ pre, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ coef,
                                                                  const float* __restrict__ dx1c, int B, int H, int W, EdgeW wts,
-                                                                 float* __restrict__ dx, float* __restrict__ wpart, int wtot, int fr_off) {
+                                                                 float* __restrict__ dx, float* __restrict__ wpart, int wtot, int fr_off,
+                                                                 const float* __restrict__ x1src, long ld1 /* where the x1 tile comes from */) {
   constexpr int TPB = TH * TW, NQ = CQ / 4, C = 4 * CQ;
   constexpr int XH = TH + 4, XW = TW + 4, XN = XH * XW;         // x1 tile, halo 2
   constexpr int GH = TH / S + 2, GW = TW / S + 2, GN = GH * GW;   // gradient tiles: outputs (ty0/S - 1) .. (ty0/S + TH/S)
@@ -736,7 +746,7 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_pools_kernel(const float* __
     const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
     const int gy0 = ty0 / S - 1, gx0 = tx0 / S - 1;             // first output row / column of the gradient tiles
     __syncthreads();
-    load_tile<NQ, 0, XH, XW, TPB>(xt, x, C, n, H, W, ty0 - 2, tx0 - 2, nullptr, nullptr);
+    load_tile<NQ, 0, XH, XW, TPB>(xt, x1src, ld1, n, H, W, ty0 - 2, tx0 - 2, nullptr, nullptr);
     __syncthreads();
     for (int idx = threadIdx.x; idx < GN; idx += TPB) {
       const int gy = gy0 + idx / GW, gx = gx0 + idx % GW;
@@ -1569,7 +1579,7 @@ long lctvqa_mixed_edge_bwd_scratch_floats(int B, int H, int W, int C, int stride
   const int CQ = C / 4;
   const long P = (long)B * (H / stride) * (W / stride);
   const long G = lctvqa_mixed_edge_grid(B, H, W, C, stride);
-  return 3 * P * CQ + (long)B * H * W * CQ + 1536L * (8 * CQ + 1) + 9 * COEF + 102 * CQ + G * lctvqa_mixed_edge_wgrad_elems(C) + 2 * (2 * G * 2 * CQ * 2) + 8;
+  return 3 * P * CQ + 2L * B * H * W * CQ + 1536L * (8 * CQ + 1) + 9 * COEF + 102 * CQ + G * lctvqa_mixed_edge_wgrad_elems(C) + 2 * (2 * G * 2 * CQ * 2) + 8;
 }
 
 // Forward of one edge.  w: 14 pointers = dw[6], pw[6], fr[2] (fr null on stride-1 edges); bn: 27 pointers = run_mean[9],
@@ -1660,7 +1670,8 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
   float* dY = scratch;
   float* dBN = dY + P * CQ;                                    // [2][P][CQ]
   float* dx1c = dBN + 2 * P * CQ;                              // [B][H][W][CQ]: what the conv stages send to x1
-  float* part1 = dx1c + (long)B * H * W * CQ;                  // [<=1536][8*CQ+1]
+  float* x1d = dx1c + (long)B * H * W * CQ;                    // [B][H][W][CQ]: dense x[..., :CQ] (a 16..64-byte slice of every NHWC row of x otherwise)
+  float* part1 = x1d + (long)B * H * W * CQ;                   // [<=1536][8*CQ+1]
   float* coef = part1 + 1536L * (8 * CQ + 1);
   coef += (4 - ((coef - scratch) & 3)) & 3;
   float* wtaps = coef + 9 * COEF;                              // tap-major copies of the depthwise weights (16-byte aligned), offsets dw_off
@@ -1675,9 +1686,9 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
     long nb = (P * (CQ / 4) + 255) / 256;
     if (nb > 1536) nb = 1536;                                    // six workgroups per CU hide the load latency; one partial row each
     if (stride == 1)
-      hipLaunchKernelGGL(edge_bwd_sums_kernel<1>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, part1);
+      hipLaunchKernelGGL(edge_bwd_sums_kernel<1>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, part1, x1d);
     else
-      hipLaunchKernelGGL(edge_bwd_sums_kernel<2>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, part1);
+      hipLaunchKernelGGL(edge_bwd_sums_kernel<2>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, part1, x1d);
     if ((rc = lct_check_launch("edge_bwd_sums"))) return rc;
     hipLaunchKernelGGL(edge_bwd_coef_kernel, dim3(1), dim3(1024), 0, st, part1, (int)nb, CQ, P, stride, training, wsel, beta, invstd, coef, dwsel, dbeta, ew, wtaps);
     if ((rc = lct_check_launch("edge_bwd_coef"))) return rc;
@@ -1725,9 +1736,9 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
 #endif
 #define STAGES(CQv, Sv, THv, TWv)                                                                                          \
   {                                                                                                                        \
-    CONV(CQv, 3, 2, Sv, 0, THv, TWv, 2, 5, x, C, H, W, dY, dx1c, 0, (double*)nullptr)                                      \
+    CONV(CQv, 3, 2, Sv, 0, THv, TWv, 2, 5, x1d, CQv, H, W, dY, dx1c, 0, (double*)nullptr)                                      \
     if ((rc = lct_check_launch("edge_bwd_conv(dil3)"))) return rc;                                                         \
-    CONV(CQv, 5, 2, Sv, 0, THv, TWv, 3, 6, x, C, H, W, dY, dx1c, 1, (double*)nullptr)                                      \
+    CONV(CQv, 5, 2, Sv, 0, THv, TWv, 3, 6, x1d, CQv, H, W, dY, dx1c, 1, (double*)nullptr)                                      \
     if ((rc = lct_check_launch("edge_bwd_conv(dil5)"))) return rc;                                                         \
     CONV(CQv, 3, 1, 1, 1, 8, 32, 4, 7, pre + 3L * P * CQv, CQv, Ho, Wo, dY, dBN, 0, spart)                                 \
     g3b = grid;                                                                                                            \
@@ -1737,16 +1748,16 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
     if ((rc = lct_check_launch("edge_bwd_conv(sep5b)"))) return rc;                                                        \
     hipLaunchKernelGGL(edge_bwd_coef_a_kernel, dim3(2 * CQv), dim3(64), 0, st, spart, G, g3b, g5b, CQv, P, training, invstd, coef); \
     if ((rc = lct_check_launch("edge_bwd_coef_a"))) return rc;                                                             \
-    CONV(CQv, 3, 1, Sv, 2, THv, TWv, 0, 3, x, C, H, W, dBN, dx1c, 1, (double*)nullptr)                                     \
+    CONV(CQv, 3, 1, Sv, 2, THv, TWv, 0, 3, x1d, CQv, H, W, dBN, dx1c, 1, (double*)nullptr)                                     \
     if ((rc = lct_check_launch("edge_bwd_conv(sep3a)"))) return rc;                                                        \
-    CONV(CQv, 5, 1, Sv, 2, THv, TWv, 1, 4, x, C, H, W, dBN + P * CQv, dx1c, 1, (double*)nullptr)                           \
+    CONV(CQv, 5, 1, Sv, 2, THv, TWv, 1, 4, x1d, CQv, H, W, dBN + P * CQv, dx1c, 1, (double*)nullptr)                           \
     if ((rc = lct_check_launch("edge_bwd_conv(sep5a)"))) return rc;                                                        \
     {                                                                                                                      \
       const size_t lds = bwd_pools_lds<CQv, Sv, 8, 32>();                                                                  \
       grid = tile_grid((const void*)edge_bwd_pools_kernel<CQv, Sv, 8, 32>, 256, lds, TILES(H, W, 8, 32), G);               \
       rows.n[6] = grid;                                                                                                    \
       hipLaunchKernelGGL((edge_bwd_pools_kernel<CQv, Sv, 8, 32>), dim3(grid), dim3(256), lds, st, x, dY, dout, ldd, beta, pre, mean, invstd, \
-                         coef, dx1c, B, H, W, ew, dx, wpart, wtot, fr_off);                                                \
+                         coef, dx1c, B, H, W, ew, dx, wpart, wtot, fr_off, Sv == 1 ? x1d : x, (long)(Sv == 1 ? CQv : C)); \
       if ((rc = lct_check_launch("edge_bwd_pools"))) return rc;                                                            \
     }                                                                                                                      \
   }

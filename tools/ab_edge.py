@@ -37,7 +37,7 @@ def main():
         bn = (ctypes.c_void_p * 27)(*([None] * 27))
         pre = torch.empty(9, Pn, Cq, device=dev)
         stats = torch.empty(2, 9, Cq, device=dev)
-        grid = dlls[0].lctvqa_mixed_edge_grid(B, H, H, C, s)
+        grid = max(d.lctvqa_mixed_edge_grid(B, H, H, C, s) for d in dlls)
         part = torch.empty(grid * 7 * Cq * 2, dtype=torch.float64, device=dev)
         wsel = torch.softmax(torch.randn(7, device=dev), 0)
         beta = torch.ones(1, device=dev)
@@ -45,8 +45,8 @@ def main():
         dout = torch.randn(B, Ho, Ho, C, device=dev)
         dx = torch.empty_like(x)
         dw, dbeta = torch.empty(7, device=dev), torch.empty(1, device=dev)
-        wgrad = torch.empty(dlls[0].lctvqa_mixed_edge_wgrad_elems(C), device=dev)
-        scratch = torch.empty(dlls[0].lctvqa_mixed_edge_bwd_scratch_floats(B, H, H, C, s), device=dev)
+        wgrad = torch.empty(max(d.lctvqa_mixed_edge_wgrad_elems(C) for d in dlls), device=dev)
+        scratch = torch.empty(max(d.lctvqa_mixed_edge_bwd_scratch_floats(B, H, H, C, s) for d in dlls), device=dev)   # builds differ in their scratch layout
         times = [[[], []] for _ in dlls]
         for rnd in range(args.rounds + 1):
             for i, d in enumerate(dlls):
