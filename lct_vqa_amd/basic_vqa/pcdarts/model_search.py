@@ -96,7 +96,7 @@ class MixedOp(nn.Module):
             self.__dict__['_plan'] = plan
         return plan or None
 
-    def forward(self, x, weights, state=None, beta=None, selected=False):
+    def forward(self, x, weights, state=None, beta=None, selected=False, slot=None):
         """``state (+)= beta * shuffle(cat(sum_k w_k op_k(x[:C/4]), bypass(x[C/4:])))``; with the defaults this is the
         reference's ``MixedOp.forward(x, weights)``.  ``selected``: ``weights`` already holds the live primitives only."""
         if selected:
@@ -115,7 +115,7 @@ class MixedOp(nn.Module):
             bns, mods = plan
             modes = {b.training or not b.track_running_stats for b in bns if b is not None}
             if len(modes) == 1:                                   # one kernel, one mode: every BatchNorm of the edge agrees
-                return D.MixedEdgeFn.apply(state, x, wsel, beta.reshape(1), self.stride, bns, modes.pop(), *[m.weight for m in mods])
+                return D.MixedEdgeFn.apply(state, x, wsel, beta.reshape(1), self.stride, bns, modes.pop(), slot, *[m.weight for m in mods])
         outs, _ = self.branches(x)
         return D.MixedCombineFn.apply(state, x, wsel, beta.reshape(1), self.stride == 2, *outs)
 
@@ -139,15 +139,32 @@ class Cell(nn.Module):
         parts = None
         if live == list(range(live[0], live[-1] + 1)) and all(op._live == live for op in self._ops):
             parts = D.EdgeWeightsFn.apply(weights, weights2, live[0], live[-1] + 1)     # every edge's operands, one autograd node
+        # a state is read by up to four edges and by the concatenation: one alias per reader (D.FanoutFn), the edges' input gradients
+        # meet in one buffer inside their kernels instead of in ATen adds
+        fan = D.FUSED_EDGE and parts is not None and torch.is_grad_enabled()
+        nstates = self._steps + 2
+        readers = [sum(1 for first, last in _node_slices(self._steps) if last - first > i) + (1 if i >= nstates - self._multiplier else 0)
+                   for i in range(nstates)]
+        taps, slots = {}, {}
+
+        def tap(i):
+            if not fan or readers[i] < 2:
+                return states[i], None
+            if i not in taps:
+                slots[i] = D.GradSlot()
+                taps[i] = list(D.FanoutFn.apply(states[i], readers[i], slots[i]))
+            return taps[i].pop(), slots[i]
+
         for first, last in _node_slices(self._steps):
             node = None
             for e in range(first, last):                           # edge e reads state e - first; the kernel accumulates
+                x, slot = tap(e - first)
                 if parts is not None:
-                    node = self._ops[e](states[e - first], parts[2 * e], node, parts[2 * e + 1], selected=True)
+                    node = self._ops[e](x, parts[2 * e], node, parts[2 * e + 1], selected=True, slot=slot)
                 else:
-                    node = self._ops[e](states[e - first], weights[e], node, weights2[e])
+                    node = self._ops[e](x, weights[e], node, weights2[e])
             states.append(node)
-        return torch.cat(states[-self._multiplier:], dim=3)
+        return torch.cat([tap(i)[0] for i in range(nstates - self._multiplier, nstates)], dim=3)
 
 
 class Network(nn.Module):

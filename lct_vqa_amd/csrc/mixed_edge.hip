@@ -711,7 +711,8 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_pools_kernel(const float* __
                                                                  const float* __restrict__ invstd, const float* __restrict__ coef,
                                                                  const float* __restrict__ dx1c, int B, int H, int W, EdgeW wts,
                                                                  float* __restrict__ dx, float* __restrict__ wpart, int wtot, int fr_off,
-                                                                 const float* __restrict__ x1src, long ld1 /* where the x1 tile comes from */) {
+                                                                 const float* __restrict__ x1src, long ld1 /* where the x1 tile comes from */,
+                                                                 int acc_dx /* dx += (a state with several consumers: one buffer, no add pass) */) {
   constexpr int TPB = TH * TW, NQ = CQ / 4, C = 4 * CQ;
   constexpr int XH = TH + 4, XW = TW + 4, XN = XH * XW;         // x1 tile, halo 2
   constexpr int GH = TH / S + 2, GW = TW / S + 2, GN = GH * GW;   // gradient tiles: outputs (ty0/S - 1) .. (ty0/S + TH/S)
@@ -726,6 +727,7 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_pools_kernel(const float* __
   float* Gs = w_fr + CQ * CQ;                                  // S == 2: g2 rows of the tile's outputs [TPB/4][CQ]
   float* R0 = Gs + (TPB / 4) * CQ;                             //         relu(x1) at the even / odd taps [TPB/4][CQ] each
   float* R1 = R0 + (TPB / 4) * CQ;
+  float* Xs = R1 + (TPB / 4) * CQ;                             // the tile's x1 gradients [TPB][CQ] on their way to the row writer
   const int Ho = H / S, Wo = W / S;
   const long P = (long)B * Ho * Wo;
   const float bt = beta[0];
@@ -869,36 +871,46 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_pools_kernel(const float* __
         acc_fr += a;
       }
     }
-    if (live) {
-      float* drow = dx + (((long)n * H + iy) * W + ix) * C;
-      store_row<CQ>(drow, dxv);
-      // ---- bypass channels g*Cq + i <- beta * dOut[q][4i + g] ----
-      const long q = ((long)n * Ho + iy / S) * Wo + ix / S;
-      const float* xr = x + (((long)n * H + (iy & ~(S - 1))) * W + (ix & ~(S - 1))) * C;   // top-left of the 2x2 window (S = 2)
-      const int me = (iy & 1) * 2 + (ix & 1);
-#pragma unroll
-      for (int q4 = 0; q4 < NQ; q4++) {
+    // ---- write the tile's rows of dx: lane = (pixel, 16-byte chunk of its row), so that neighbouring lanes touch neighbouring chunks
+    //      (one thread per whole row cost 64 cache lines per store instruction and made the accumulating form twice as slow) ----
+    store_row<CQ>(Xs + threadIdx.x * CQ, dxv);                   // the x1 chunks go through LDS
+    __syncthreads();
+    constexpr int NCH = 4 * NQ;                                  // chunks of a row: NQ of x1, then the bypass groups g = 1..3
+    for (int it = threadIdx.x; it < TPB * NCH; it += TPB) {
+      const int pix = it / NCH, ch = it % NCH;
+      const int g = ch / NQ, q4 = ch % NQ;
+      const int py = pix / TW, px = pix % TW;
+      const int jy = ty0 + py, jx = tx0 + px;
+      if (jy >= H || jx >= W) continue;
+      float* dp = dx + (((long)n * H + jy) * W + jx) * C + g * CQ + 4 * q4;
+      f32x4 v;
+      if (g == 0) {
+        v = *(const f32x4*)(Xs + pix * CQ + 4 * q4);
+      } else {
+        // bypass channel g*Cq + i <- beta * dOut[q][4i + g]
+        const long q = ((long)n * Ho + jy / S) * Wo + jx / S;
         f32x4 D[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) D[e] = *(const f32x4*)(dout + q * ldd + 16 * q4 + 4 * e);
 #pragma unroll
-        for (int g = 1; g < 4; g++) {
-          f32x4 v = {D[0][g] * bt, D[1][g] * bt, D[2][g] * bt, D[3][g] * bt};
-          if (S == 2) {
-            const f32x4 va = *(const f32x4*)(xr + g * CQ + 4 * q4), vb = *(const f32x4*)(xr + C + g * CQ + 4 * q4);
-            const f32x4 vc = *(const f32x4*)(xr + (long)W * C + g * CQ + 4 * q4), vd = *(const f32x4*)(xr + (long)W * C + C + g * CQ + 4 * q4);
+        for (int e = 0; e < 4; e++) v[e] = (g == 1 ? D[e][1] : g == 2 ? D[e][2] : D[e][3]) * bt;
+        if (S == 2) {
+          const float* xr = x + (((long)n * H + (jy & ~1)) * W + (jx & ~1)) * C + g * CQ + 4 * q4;   // top-left of the 2x2 window
+          const int me = (jy & 1) * 2 + (jx & 1);
+          const f32x4 va = *(const f32x4*)xr, vb = *(const f32x4*)(xr + C);
+          const f32x4 vc = *(const f32x4*)(xr + (long)W * C), vd = *(const f32x4*)(xr + (long)W * C + C);
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-              int best = 0; float bv = va[e];                   // first maximum in scan order, like MaxPool2d(2, 2)
-              if (vb[e] > bv) { bv = vb[e]; best = 1; }
-              if (vc[e] > bv) { bv = vc[e]; best = 2; }
-              if (vd[e] > bv) { bv = vd[e]; best = 3; }
-              if (best != me) v[e] = 0.f;
-            }
+          for (int e = 0; e < 4; e++) {
+            int best = 0; float bv = va[e];                     // first maximum in scan order, like MaxPool2d(2, 2)
+            if (vb[e] > bv) { bv = vb[e]; best = 1; }
+            if (vc[e] > bv) { bv = vc[e]; best = 2; }
+            if (vd[e] > bv) { bv = vd[e]; best = 3; }
+            if (best != me) v[e] = 0.f;
           }
-          *(f32x4*)(drow + g * CQ + 4 * q4) = v;
         }
       }
+      if (acc_dx) v += *(const f32x4*)dp;
+      *(f32x4*)dp = v;
     }
   }
   if (S == 2 && threadIdx.x < CQ * CQ) wpart[(long)blockIdx.x * wtot + fr_off + threadIdx.x] = acc_fr;
@@ -1482,7 +1494,7 @@ __global__ __launch_bounds__(64) void edge_wgrad_finish_kernel(const float* __re
 template <int CQ, int S, int TH, int TW>
 size_t bwd_pools_lds() {
   constexpr int TPB = TH * TW, NQ = CQ / 4, XN = (TH + 4) * (TW + 4), GN = (TH / S + 2) * (TW / S + 2);
-  size_t floats = (size_t)NQ * XN * 4 + 3 * NQ * GN * 4 + 6 * CQ + 3 * COEF + CQ * CQ + 3 * (TPB / 4) * CQ;
+  size_t floats = (size_t)NQ * XN * 4 + 3 * NQ * GN * 4 + 6 * CQ + 3 * COEF + CQ * CQ + 3 * (TPB / 4) * CQ + TPB * CQ;
   return floats * 4 + 16;
 }
 template <int CQ, int K, int DIL, int S, int MODE, int TH, int TW>
@@ -1647,12 +1659,13 @@ int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride
 #undef TILES
 }
 
-// Backward of one edge (see the block comment above edge_bwd_sums_kernel).  dx [B,H,W,C] is written completely; dwsel [7],
+// Backward of one edge (see the block comment above edge_bwd_sums_kernel).  dx [B,H,W,C] is written completely (accumulate_dx = 0) or
+// added to (1: the gradient buffer of a state that several edges read); dwsel [7],
 // dbeta [1]; wgrad = flat weight gradients (lctvqa_mixed_edge_wgrad_elems, order dw[6], pw[6], fr[2]); scratch >=
 // lctvqa_mixed_edge_bwd_scratch_floats floats, 16-byte aligned.
 int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, int H, int W, int C, int stride, const void* const* w,
                           const float* pre, const float* mean, const float* invstd, const float* wsel, const float* beta, float* dx,
-                          float* dwsel, float* dbeta, float* wgrad, float* scratch, int training, void* stream) {
+                          float* dwsel, float* dbeta, float* wgrad, float* scratch, int training, int accumulate_dx, void* stream) {
   LCT_REQUIRE(lctvqa_mixed_edge_supported(B, H, W, C, stride), "mixed_edge_bwd: unsupported shape B=%d H=%d W=%d C=%d s=%d", B, H, W, C, stride);
   LCT_REQUIRE((((uintptr_t)dout | (uintptr_t)x | (uintptr_t)pre | (uintptr_t)dx | (uintptr_t)scratch | (uintptr_t)wgrad) & 15) == 0 && (ldd & 3) == 0,
               "mixed_edge_bwd: tensors must be 16-B aligned");
@@ -1757,7 +1770,7 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
       grid = tile_grid((const void*)edge_bwd_pools_kernel<CQv, Sv, 8, 32>, 256, lds, TILES(H, W, 8, 32), G);               \
       rows.n[6] = grid;                                                                                                    \
       hipLaunchKernelGGL((edge_bwd_pools_kernel<CQv, Sv, 8, 32>), dim3(grid), dim3(256), lds, st, x, dY, dout, ldd, beta, pre, mean, invstd, \
-                         coef, dx1c, B, H, W, ew, dx, wpart, wtot, fr_off, Sv == 1 ? x1d : x, (long)(Sv == 1 ? CQv : C)); \
+                         coef, dx1c, B, H, W, ew, dx, wpart, wtot, fr_off, Sv == 1 ? x1d : x, (long)(Sv == 1 ? CQv : C), accumulate_dx); \
       if ((rc = lct_check_launch("edge_bwd_pools"))) return rc;                                                            \
     }                                                                                                                      \
   }
