@@ -25,6 +25,7 @@
 #include "common.h"
 
 #include <mutex>
+#include <type_traits>
 #include <unordered_map>
 
 namespace {
@@ -1469,6 +1470,287 @@ __global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_kernel(const floa
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// edge_bwd_conv2_pair: the 3x3 and the 5x5 stage that read the SAME input (dil_conv_3x3 + dil_conv_5x5: MODE 0; the first stages of
+// sep_conv_3x3 + sep_conv_5x5: MODE 2) in one pass over the tiles: one input tile (the 5x5 halo), one read-modify-write of dx1c
+// instead of two, half the launches.  At Cq = 4 / 8 these stages move bytes, not flops (7 T each alone, 8.6 - 10.3 T as a pair).
+// Same phases and lane layouts as edge_bwd_conv2_kernel; stage 0 = 3x3, stage 1 = 5x5.
+// ------------------------------------------------------------------------------------------------------------------
+struct StageArgs {
+  const float* gsrc;      // dY or dBN
+  const float* usrc;      // pre-BN output of the stage
+  const float* mean_o; const float* invstd_o; const float* coef_o;
+  const float* w_taps;    // tap-major depthwise weights [K*K][CQ]
+  const float* w_pw;
+  int dw_off, pw_off;
+};
+
+template <int CQ, int DIL, int S, int MODE, int TH, int TW, int NW, int WPE>
+__global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_pair_kernel(const float* __restrict__ in, long ldin, StageArgs sa, StageArgs sb, int B, int H, int W,
+                                                                      float* __restrict__ dst, int accumulate, float* __restrict__ wpart, int wtot) {
+  static_assert(MODE == 0 || MODE == 2, "stages that read x1");
+  constexpr int TPB = 64 * NW, NPX = TH * TW, NQ = CQ / 4;
+  constexpr int PAD = 2 * DIL;                                   // the 5x5 stage's reach: the shared input tile
+  constexpr int IH = S * (TH - 1) + 2 * PAD + 1, IW = S * (TW - 1) + 2 * PAD + 1, IN = IH * IW;
+  constexpr int PPW = 64 / NQ, NITC = NPX / 64, ITC = NITC * NQ / NW, NBK = 16 / CQ, NM = NPX / (4 * NBK), MPW = NM / NW, RK = NW / NQ;
+  static_assert(NW % NQ == 0 && (NITC * NQ) % NW == 0 && NPX % 64 == 0 && NM % NW == 0 && (TW & (TW - 1)) == 0, "tile / wave split");
+  // per stage: K, its padding inside the shared tile, halo of output positions, dd tile
+  constexpr int K0 = 3, K1 = 5, P0 = DIL, P1 = 2 * DIL, HB0 = (P0 + S - 1) / S, HB1 = (P1 + S - 1) / S;
+  constexpr int DW0 = TW + 2 * HB0, DN0 = (TH + 2 * HB0) * DW0, DW1 = TW + 2 * HB1, DN1 = (TH + 2 * HB1) * DW1;
+  constexpr int NT0 = (K0 * K0 + RK - 1) / RK, NT1 = (K1 * K1 + RK - 1) / RK;
+  extern __shared__ __align__(16) unsigned char smem[];
+  f32x4* rt = (f32x4*)smem;                                     // [NQ][IN]
+  f32x4* ddt0 = rt + NQ * IN;                                   // [NQ][DN0]
+  f32x4* ddt1 = ddt0 + NQ * DN0;                                // [NQ][DN1]
+  float* Gs0 = (float*)(ddt1 + NQ * DN1);                      // [NPX][CQ] each
+  float* Gs1 = Gs0 + NPX * CQ;
+  float* Ds0 = Gs1 + NPX * CQ;
+  float* Ds1 = Ds0 + NPX * CQ;
+  float* cst0 = Ds1 + NPX * CQ;                                // [5][CQ] each
+  float* cst1 = cst0 + 5 * CQ;
+  for (int i = threadIdx.x; i < CQ; i += TPB) {
+    cst0[i] = sa.mean_o[i]; cst0[CQ + i] = sa.invstd_o[i];
+    cst0[2 * CQ + i] = sa.coef_o[i]; cst0[3 * CQ + i] = sa.coef_o[16 + i]; cst0[4 * CQ + i] = sa.coef_o[32 + i];
+    cst1[i] = sb.mean_o[i]; cst1[CQ + i] = sb.invstd_o[i];
+    cst1[2 * CQ + i] = sb.coef_o[i]; cst1[3 * CQ + i] = sb.coef_o[16 + i]; cst1[4 * CQ + i] = sb.coef_o[32 + i];
+  }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n16 = lane & 15, jg = lane >> 4;
+  const int qB = jg % NQ, blkB = jg / NQ, slotB = n16 + 16 * blkB;
+  float aop0[4], aop1[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) {
+    aop0[kk] = (n16 / CQ == blkB) ? sa.w_pw[(4 * qB + kk) * CQ + n16 % CQ] : 0.f;
+    aop1[kk] = (n16 / CQ == blkB) ? sb.w_pw[(4 * qB + kk) * CQ + n16 % CQ] : 0.f;
+  }
+  const int qC = wave % NQ, itc0 = wave / NQ;
+  f32x4 acc0[NT0], acc1[NT1];
+  int toff0[NT0], toff1[NT1];
+#pragma unroll
+  for (int t = 0; t < NT0; t++) {
+    acc0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tap = (t * RK + itc0) < K0 * K0 ? t * RK + itc0 : K0 * K0 - 1;
+    toff0[t] = (DIL * (tap / K0) + P1 - P0) * IW + DIL * (tap % K0) + P1 - P0;
+  }
+#pragma unroll
+  for (int t = 0; t < NT1; t++) {
+    acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tap = (t * RK + itc0) < K1 * K1 ? t * RK + itc0 : K1 * K1 - 1;
+    toff1[t] = (DIL * (tap / K1)) * IW + DIL * (tap % K1);
+  }
+  f32x4 accp0 = {0.f, 0.f, 0.f, 0.f}, accp1 = accp0;
+  const int Ho = H / S, Wo = W / S;
+  const int tiles_y = (Ho + TH - 1) / TH, tiles_x = (Wo + TW - 1) / TW;
+  const long ntiles = (long)B * tiles_y * tiles_x;
+  for (long tidx = blockIdx.x; tidx < ntiles; tidx += gridDim.x) {
+    const int n = (int)(tidx / (tiles_y * tiles_x));
+    const int tr = (int)(tidx % (tiles_y * tiles_x));
+    const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+    __syncthreads();
+    int tid = threadIdx.x, slot = slotB, ln = lane;
+    asm volatile("" : "+v"(tid), "+v"(slot), "+v"(ln));
+    // ---- phase B of both stages (their loads are requested before the input tile) ----
+    auto phase_b = [&](auto hbc, auto dwc, auto dnc, const StageArgs& st, const float* cst, const float* aop, f32x4* ddt, float* Gs, bool with_tile) {
+      constexpr int HB = decltype(hbc)::value, DW = decltype(dwc)::value, DN = decltype(dnc)::value;
+      constexpr int NITB = (DN + PPW - 1) / PPW, ITB = (NITB + NW - 1) / NW, UB = ITB < 4 ? ITB : 4;
+      f32x4 dv[UB], uv[UB];
+      bool inb[UB];
+      auto request = [&](int b0) {
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+          const int idx = (wave + (b0 + u) * NW) * PPW + slot;
+          const int oy = ty0 - HB + idx / DW, ox = tx0 - HB + idx % DW;
+          inb[u] = (b0 + u < ITB) && idx < DN && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
+          dv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          uv[u] = dv[u];
+          if (inb[u]) {
+            const long q = ((long)n * Ho + oy) * Wo + ox;
+            dv[u] = *(const f32x4*)(st.gsrc + q * CQ + 4 * qB);
+            uv[u] = *(const f32x4*)(st.usrc + q * CQ + 4 * qB);
+          }
+        }
+      };
+      request(0);
+      if (with_tile) load_tile<NQ, 1, IH, IW, TPB>(rt, in, ldin, n, H, W, S * ty0 - PAD, S * tx0 - PAD, nullptr, nullptr, tid);
+      const f32x4 mn = *(const f32x4*)(cst + 4 * qB), is = *(const f32x4*)(cst + CQ + 4 * qB);
+      const f32x4 c0 = *(const f32x4*)(cst + 2 * CQ + 4 * qB), c1 = *(const f32x4*)(cst + 3 * CQ + 4 * qB), c2 = *(const f32x4*)(cst + 4 * CQ + 4 * qB);
+#pragma unroll
+      for (int b0 = 0; b0 < ITB; b0 += UB) {
+        if (b0) request(b0);
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+          if (b0 + u < ITB && wave + (b0 + u) * NW < NITB) {
+            const int idx = (wave + (b0 + u) * NW) * PPW + slot;
+            f32x4 g;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const float xh = (uv[u][e] - mn[e]) * is[e];
+              g[e] = inb[u] ? c0[e] * (dv[u][e] - c1[e] - xh * c2[e]) : 0.f;
+            }
+            f32x4 dd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) dd = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[kk], g[kk], dd, 0, 0, 0);
+            if (idx < DN) {
+              ddt[qB * DN + idx] = dd;
+              const int py = idx / DW - HB, px = idx % DW - HB;
+              if (py >= 0 && py < TH && px >= 0 && px < TW) *(f32x4*)(Gs + (py * TW + px) * CQ + 4 * qB) = g;
+            }
+          }
+        }
+      }
+    };
+    phase_b(std::integral_constant<int, HB1>{}, std::integral_constant<int, DW1>{}, std::integral_constant<int, DN1>{}, sb, cst1, aop1, ddt1, Gs1, true);
+    phase_b(std::integral_constant<int, HB0>{}, std::integral_constant<int, DW0>{}, std::integral_constant<int, DN0>{}, sa, cst0, aop0, ddt0, Gs0, false);
+    __syncthreads();
+    // ---- phase C: both stages of an (item, quad) pair, one write of dx1c ----
+    auto stage_c = [&](auto kc, auto pc, auto hbc, auto dwc, auto dnc, const float* w_taps, const f32x4* ddt, float* Ds, int p, int ly, int lx, f32x4* sacc /* [S*S] */) {
+      constexpr int K = decltype(kc)::value, PS = decltype(pc)::value, HB = decltype(hbc)::value, DW = decltype(dwc)::value, DN = decltype(dnc)::value;
+      unsigned long wqa = (unsigned long)(uintptr_t)(w_taps + 4 * qC);
+      asm volatile("" : "+s"(wqa));
+      const const_f32x4_ptr wq = (const_f32x4_ptr)wqa;
+      const f32x4* rp = rt + qC * IN + (S * ly + P1 - PS) * IW + S * lx + P1 - PS;
+      const f32x4* dq = ddt + qC * DN + (ly + HB) * DW + lx + HB;
+      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < K; j++)
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+          const f32x4 v = rp[(DIL * j) * IW + DIL * i];
+          const f32x4 w4 = wq[(j * K + i) * NQ];
+#pragma unroll
+          for (int e = 0; e < 4; e++) d[e] = fmaf(w4[e], v[e], d[e]);
+        }
+      *(f32x4*)(Ds + p * CQ + 4 * qC) = d;
+#pragma unroll
+      for (int a = 0; a < S; a++)
+#pragma unroll
+        for (int b = 0; b < S; b++) {
+          f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            const int ty = a + PS - DIL * j;
+            if (ty % S != 0) continue;
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+              const int tx = b + PS - DIL * i;
+              if (tx % S != 0) continue;
+              const f32x4 v = dq[(ty / S) * DW + tx / S];
+              const f32x4 w4 = wq[(j * K + i) * NQ];
+#pragma unroll
+              for (int e = 0; e < 4; e++) sc[e] = fmaf(w4[e], v[e], sc[e]);
+            }
+          }
+          sacc[a * S + b] += sc;
+        }
+    };
+#pragma unroll 1
+    for (int t = 0; t < ITC; t++) {
+      const int p = (itc0 + t * (NW / NQ)) * 64 + ln;
+      const int ly = p / TW, lx = p % TW;
+      const int oy = ty0 + ly, ox = tx0 + lx;
+      const bool live = oy < Ho && ox < Wo;
+      f32x4 prev[S * S], sacc[S * S];
+#pragma unroll
+      for (int ab = 0; ab < S * S; ab++) {
+        prev[ab] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sacc[ab] = prev[ab];
+        const int iy = S * oy + ab / S, ix = S * ox + ab % S;
+        if (accumulate && live && iy < H && ix < W) prev[ab] = *(const f32x4*)(dst + (((long)n * H + iy) * W + ix) * CQ + 4 * qC);
+      }
+      stage_c(std::integral_constant<int, K0>{}, std::integral_constant<int, P0>{}, std::integral_constant<int, HB0>{}, std::integral_constant<int, DW0>{},
+              std::integral_constant<int, DN0>{}, sa.w_taps, ddt0, Ds0, p, ly, lx, sacc);
+      stage_c(std::integral_constant<int, K1>{}, std::integral_constant<int, P1>{}, std::integral_constant<int, HB1>{}, std::integral_constant<int, DW1>{},
+              std::integral_constant<int, DN1>{}, sb.w_taps, ddt1, Ds1, p, ly, lx, sacc);
+      const f32x4* rc = rt + qC * IN + (S * ly + P1) * IW + S * lx + P1;
+#pragma unroll
+      for (int a = 0; a < S; a++)
+#pragma unroll
+        for (int b = 0; b < S; b++) {
+          const f32x4 r = rc[a * IW + b];
+          f32x4 din;
+#pragma unroll
+          for (int e = 0; e < 4; e++) din[e] = r[e] > 0.f ? sacc[a * S + b][e] : 0.f;
+          const int iy = S * oy + a, ix = S * ox + b;
+          if (live && iy < H && ix < W) *(f32x4*)(dst + (((long)n * H + iy) * W + ix) * CQ + 4 * qC) = din + prev[a * S + b];
+        }
+    }
+    // depthwise weight gradients of both stages: every wave walks all items for its quad with its own taps
+#pragma unroll 1
+    for (int it = 0; it < NITC; it++) {
+      const int p = it * 64 + ln;
+      const int ly = p / TW, lx = p % TW;
+      const f32x4* rp = rt + qC * IN + (S * ly) * IW + S * lx;
+      const f32x4 dd0 = ddt0[qC * DN0 + (ly + HB0) * DW0 + lx + HB0], dd1 = ddt1[qC * DN1 + (ly + HB1) * DW1 + lx + HB1];
+#pragma unroll
+      for (int t = 0; t < NT0; t++) {
+        const f32x4 v = rp[toff0[t]];
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc0[t][e] = fmaf(dd0[e], v[e], acc0[t][e]);
+      }
+#pragma unroll
+      for (int t = 0; t < NT1; t++) {
+        const f32x4 v = rp[toff1[t]];
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc1[t][e] = fmaf(dd1[e], v[e], acc1[t][e]);
+      }
+    }
+    __syncthreads();
+    // ---- phase D ----
+#pragma unroll
+    for (int m = 0; m < MPW; m++) {
+      const int pix = (wave * MPW + m) * (4 * NBK) + 4 * (n16 / CQ) + jg;
+      accp0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs0[pix * CQ + n16 % CQ], Ds0[pix * CQ + n16 % CQ], accp0, 0, 0, 0);
+      accp1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs1[pix * CQ + n16 % CQ], Ds1[pix * CQ + n16 % CQ], accp1, 0, 0, 0);
+    }
+  }
+  // ---- per-workgroup partial weight gradients (fixed order) ----
+  __syncthreads();
+  float* wrow = wpart + (long)blockIdx.x * wtot;
+  float* fin0 = (float*)smem;                                   // [NW][16][NT0*4], [NW][16][NT1*4], 2 x [NW][16][16]
+  float* fin1 = fin0 + NW * 16 * NT0 * 4;
+  float* finp = fin1 + NW * 16 * NT1 * 4;
+#pragma unroll
+  for (int t = 0; t < NT0; t++) {
+    f32x4 v = acc0[t];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { v[e] += __shfl_xor(v[e], 32, 64); v[e] += __shfl_xor(v[e], 16, 64); }
+    if (lane < 16) *(f32x4*)(fin0 + ((wave * 16 + lane) * NT0 + t) * 4) = v;
+  }
+#pragma unroll
+  for (int t = 0; t < NT1; t++) {
+    f32x4 v = acc1[t];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { v[e] += __shfl_xor(v[e], 32, 64); v[e] += __shfl_xor(v[e], 16, 64); }
+    if (lane < 16) *(f32x4*)(fin1 + ((wave * 16 + lane) * NT1 + t) * 4) = v;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    finp[wave * 256 + (4 * jg + r) * 16 + n16] = accp0[r];
+    finp[NW * 256 + wave * 256 + (4 * jg + r) * 16 + n16] = accp1[r];
+  }
+  __syncthreads();
+  for (int ent = threadIdx.x; ent < CQ * (K0 * K0 + K1 * K1); ent += TPB) {
+    const bool second = ent >= CQ * K0 * K0;
+    const int KK = second ? K1 * K1 : K0 * K0, NT = second ? NT1 : NT0, en = second ? ent - CQ * K0 * K0 : ent;
+    const float* fin = second ? fin1 : fin0;
+    const int c = en / KK, tap = en % KK;
+    const int w = c / 4 + NQ * (tap % RK), t = tap / RK;
+    float a = 0.f;
+    for (int l = 0; l < 16; l++) a += fin[((w * 16 + l) * NT + t) * 4 + c % 4];
+    wrow[(second ? sb.dw_off : sa.dw_off) + en] = a;
+  }
+  for (int ent = threadIdx.x; ent < 2 * CQ * CQ; ent += TPB) {
+    const bool second = ent >= CQ * CQ;
+    const int en = second ? ent - CQ * CQ : ent;
+    const int oc = en / CQ, c = en % CQ;
+    const float* f2 = finp + (second ? NW * 256 : 0);
+    float a = 0.f;
+    for (int w = 0; w < NW; w++)
+      for (int b = 0; b < NBK; b++) a += f2[w * 256 + (b * CQ + oc) * 16 + b * CQ + c];
+    wrow[(second ? sb.pw_off : sa.pw_off) + en] = a;
+  }
+}
+
 // out[col] = sum over the partial rows of the kernel that produced the column (fixed order, fp64).  Column sections: the
 // depthwise gradients of conv 0..5 (9, 25, 9, 25, 9, 25 taps x Cq), their 1x1 gradients (Cq x Cq each), FactorizedReduce;
 // nb.n[i] = workgroups of conv kernel i (i = 0..5), nb.n[6] = of the pooling kernel.
@@ -1512,6 +1794,16 @@ size_t bwd_conv2_lds() {
   constexpr int IN = (S * (TH - 1) + 2 * PAD + 1) * (S * (TW - 1) + 2 * PAD + 1), DN = (TH + 2 * HB) * (TW + 2 * HB);
   const size_t tile = (size_t)NQ * IN * 4 + NQ * DN * 4 + 2 * NPX * CQ + 7 * CQ;
   const size_t fin = (size_t)NW * 16 * KK * 4 + NW * 256 + NW * 8;
+  return (tile > fin ? tile : fin) * 4 + 16;
+}
+
+template <int CQ, int DIL, int S, int TH, int TW, int NW>
+size_t bwd_conv2_pair_lds() {
+  constexpr int NPX = TH * TW, NQ = CQ / 4, RK = NW / NQ, P0 = DIL, P1 = 2 * DIL, HB0 = (P0 + S - 1) / S, HB1 = (P1 + S - 1) / S;
+  constexpr int IN = (S * (TH - 1) + 2 * P1 + 1) * (S * (TW - 1) + 2 * P1 + 1);
+  constexpr int DN0 = (TH + 2 * HB0) * (TW + 2 * HB0), DN1 = (TH + 2 * HB1) * (TW + 2 * HB1), NT0 = (9 + RK - 1) / RK, NT1 = (25 + RK - 1) / RK;
+  const size_t tile = (size_t)NQ * IN * 4 + NQ * (DN0 + DN1) * 4 + 4 * NPX * CQ + 10 * CQ;
+  const size_t fin = (size_t)NW * 16 * (NT0 + NT1) * 4 + 2 * NW * 256;
   return (tile > fin ? tile : fin) * 4 + 16;
 }
 
@@ -1747,12 +2039,60 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
                        dw_off[ci], pw_off[ci]);                                                                            \
   }
 #endif
+  // PAIR(CQ, DIL, S, MODE, TH, TW, conv index of the 3x3 / of the 5x5 stage, their output-BN slots, their gradient sources, accumulate)
+#define STAGE_ARGS(ci, slot, gs) StageArgs{gs, pre + (long)(slot) * P * CQ, mean + (slot) * CQ, invstd + (slot) * CQ, coef + (slot) * COEF, \
+                                           wtaps + dw_off[ci], ew.pw[ci], dw_off[ci], pw_off[ci]}
+#define PAIR(CQv, DILv, Sv, MODEv, THv, TWv, c0, c1, s0, s1, gs0, gs1, accv)                                                \
+  {                                                                                                                        \
+    constexpr int NWv = EDGE_NW(CQv, THv, TWv);                                                                            \
+    const size_t lds = bwd_conv2_pair_lds<CQv, DILv, Sv, THv, TWv, NWv>();                                                 \
+    grid = tile_grid((const void*)edge_bwd_conv2_pair_kernel<CQv, DILv, Sv, MODEv, THv, TWv, NWv, 2>, 64 * NWv, lds,      \
+                     TILES(H / Sv, W / Sv, THv, TWv), G);                                                                  \
+    rows.n[c0] = grid; rows.n[c1] = grid;                                                                                  \
+    hipLaunchKernelGGL((edge_bwd_conv2_pair_kernel<CQv, DILv, Sv, MODEv, THv, TWv, NWv, 2>), dim3(grid), dim3(64 * NWv), lds, st, x1d, (long)CQv, \
+                       STAGE_ARGS(c0, s0, gs0), STAGE_ARGS(c1, s1, gs1), B, H, W, dx1c, accv, wpart, wtot);                \
+  }
+#define DIL_SINGLES(CQv, Sv, THv, TWv)                                                                                     \
+    CONV(CQv, 3, 2, Sv, 0, THv, TWv, 2, 5, x1d, CQv, H, W, dY, dx1c, 0, (double*)nullptr)                                  \
+    if ((rc = lct_check_launch("edge_bwd_conv(dil3)"))) return rc;                                                         \
+    CONV(CQv, 5, 2, Sv, 0, THv, TWv, 3, 6, x1d, CQv, H, W, dY, dx1c, 1, (double*)nullptr)                                  \
+    if ((rc = lct_check_launch("edge_bwd_conv(dil5)"))) return rc;
+#define SEPA_SINGLES(CQv, Sv, THv, TWv)                                                                                    \
+    CONV(CQv, 3, 1, Sv, 2, THv, TWv, 0, 3, x1d, CQv, H, W, dBN, dx1c, 1, (double*)nullptr)                                 \
+    if ((rc = lct_check_launch("edge_bwd_conv(sep3a)"))) return rc;                                                        \
+    CONV(CQv, 5, 1, Sv, 2, THv, TWv, 1, 4, x1d, CQv, H, W, dBN + P * CQv, dx1c, 1, (double*)nullptr)                       \
+    if ((rc = lct_check_launch("edge_bwd_conv(sep5a)"))) return rc;
+#define DIL_PAIR(CQv, Sv, THv, TWv)                                                                                        \
+    PAIR(CQv, 2, Sv, 0, THv, TWv, 2, 3, 5, 6, dY, dY, 0)                                                                   \
+    if ((rc = lct_check_launch("edge_bwd_conv_pair(dil)"))) return rc;
+#define SEPA_PAIR(CQv, Sv, THv, TWv)                                                                                       \
+    PAIR(CQv, 1, Sv, 2, THv, TWv, 0, 1, 3, 4, dBN, dBN + P * CQv, 1)                                                       \
+    if ((rc = lct_check_launch("edge_bwd_conv_pair(sep.a)"))) return rc;
+  // the pair form at Cq = 8 (measured: -6 % of the stride-2 edge's backward, -2 % stride 1); at Cq = 4 its 196 registers take the third wave per
+  // SIMD that the single stages have (+3 %), at Cq = 16 it spills and the dil pair's tiles do not fit the LDS
+#ifdef EDGE_NO_PAIR
+#define DIL_STAGES_4 DIL_SINGLES
+#define DIL_STAGES_8 DIL_SINGLES
+#define SEPA_STAGES_4 SEPA_SINGLES
+#define SEPA_STAGES_8 SEPA_SINGLES
+#else
+#define DIL_STAGES_4 DIL_SINGLES
+#define DIL_STAGES_8 DIL_PAIR
+#define SEPA_STAGES_4 SEPA_SINGLES
+#define SEPA_STAGES_8 SEPA_PAIR
+#endif
+#ifdef EDGE_PAIR16
+#define DIL_STAGES_16 DIL_PAIR
+#define SEPA_STAGES_16 SEPA_PAIR
+#else
+#define DIL_STAGES_16 DIL_SINGLES
+#define SEPA_STAGES_16 SEPA_SINGLES
+#endif
+#define DIL_STAGES(CQv, Sv, THv, TWv) DIL_STAGES_##CQv(CQv, Sv, THv, TWv)
+#define SEPA_STAGES(CQv, Sv, THv, TWv) SEPA_STAGES_##CQv(CQv, Sv, THv, TWv)
 #define STAGES(CQv, Sv, THv, TWv)                                                                                          \
   {                                                                                                                        \
-    CONV(CQv, 3, 2, Sv, 0, THv, TWv, 2, 5, x1d, CQv, H, W, dY, dx1c, 0, (double*)nullptr)                                      \
-    if ((rc = lct_check_launch("edge_bwd_conv(dil3)"))) return rc;                                                         \
-    CONV(CQv, 5, 2, Sv, 0, THv, TWv, 3, 6, x1d, CQv, H, W, dY, dx1c, 1, (double*)nullptr)                                      \
-    if ((rc = lct_check_launch("edge_bwd_conv(dil5)"))) return rc;                                                         \
+    DIL_STAGES(CQv, Sv, THv, TWv)                                                                                          \
     CONV(CQv, 3, 1, 1, 1, 8, 32, 4, 7, pre + 3L * P * CQv, CQv, Ho, Wo, dY, dBN, 0, spart)                                 \
     g3b = grid;                                                                                                            \
     if ((rc = lct_check_launch("edge_bwd_conv(sep3b)"))) return rc;                                                        \
@@ -1761,10 +2101,7 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
     if ((rc = lct_check_launch("edge_bwd_conv(sep5b)"))) return rc;                                                        \
     hipLaunchKernelGGL(edge_bwd_coef_a_kernel, dim3(2 * CQv), dim3(64), 0, st, spart, G, g3b, g5b, CQv, P, training, invstd, coef); \
     if ((rc = lct_check_launch("edge_bwd_coef_a"))) return rc;                                                             \
-    CONV(CQv, 3, 1, Sv, 2, THv, TWv, 0, 3, x1d, CQv, H, W, dBN, dx1c, 1, (double*)nullptr)                                     \
-    if ((rc = lct_check_launch("edge_bwd_conv(sep3a)"))) return rc;                                                        \
-    CONV(CQv, 5, 1, Sv, 2, THv, TWv, 1, 4, x1d, CQv, H, W, dBN + P * CQv, dx1c, 1, (double*)nullptr)                           \
-    if ((rc = lct_check_launch("edge_bwd_conv(sep5a)"))) return rc;                                                        \
+    SEPA_STAGES(CQv, Sv, THv, TWv)                                                                                         \
     {                                                                                                                      \
       const size_t lds = bwd_pools_lds<CQv, Sv, 8, 32>();                                                                  \
       grid = tile_grid((const void*)edge_bwd_pools_kernel<CQv, Sv, 8, 32>, 256, lds, TILES(H, W, 8, 32), G);               \
@@ -1784,6 +2121,10 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
   hipLaunchKernelGGL(edge_wgrad_finish_kernel, dim3(ncols), dim3(64), 0, st, wpart, rows, wtot, CQ, wgrad);
   return lct_check_launch("edge_wgrad_finish");
 #undef STAGES
+#undef DIL_STAGES
+#undef SEPA_STAGES
+#undef PAIR
+#undef STAGE_ARGS
 #undef CONV
 #undef TILES
 }
