@@ -96,7 +96,7 @@ class MixedOp(nn.Module):
             self.__dict__['_plan'] = plan
         return plan or None
 
-    def forward(self, x, weights, state=None, beta=None, selected=False, slot=None):
+    def forward(self, x, weights, state=None, beta=None, selected=False, slot=None, x1d=None):
         """``state (+)= beta * shuffle(cat(sum_k w_k op_k(x[:C/4]), bypass(x[C/4:])))``; with the defaults this is the
         reference's ``MixedOp.forward(x, weights)``.  ``selected``: ``weights`` already holds the live primitives only."""
         if selected:
@@ -115,7 +115,7 @@ class MixedOp(nn.Module):
             bns, mods = plan
             modes = {b.training or not b.track_running_stats for b in bns if b is not None}
             if len(modes) == 1:                                   # one kernel, one mode: every BatchNorm of the edge agrees
-                return D.MixedEdgeFn.apply(state, x, wsel, beta.reshape(1), self.stride, bns, modes.pop(), slot, *[m.weight for m in mods])
+                return D.MixedEdgeFn.apply(state, x, wsel, beta.reshape(1), self.stride, bns, modes.pop(), slot, x1d, *[m.weight for m in mods])
         outs, _ = self.branches(x)
         return D.MixedCombineFn.apply(state, x, wsel, beta.reshape(1), self.stride == 2, *outs)
 
@@ -145,7 +145,17 @@ class Cell(nn.Module):
         nstates = self._steps + 2
         readers = [sum(1 for first, last in _node_slices(self._steps) if last - first > i) + (1 if i >= nstates - self._multiplier else 0)
                    for i in range(nstates)]
-        taps, slots = {}, {}
+        taps, slots, dense = {}, {}, {}
+        edge_readers = [sum(1 for first, last in _node_slices(self._steps) if last - first > i) for i in range(nstates)]
+
+        def x1_of(i):
+            """dense x[..., :C/4] of state i when at least two fused edges read it (one strided pass instead of one per reader)"""
+            if not (D.FUSED_EDGE and parts is not None) or edge_readers[i] < 2:
+                return None
+            if i not in dense:
+                with torch.no_grad():
+                    dense[i] = D.dense_x1(states[i])
+            return dense[i]
 
         def tap(i):
             if not fan or readers[i] < 2:
@@ -160,7 +170,7 @@ class Cell(nn.Module):
             for e in range(first, last):                           # edge e reads state e - first; the kernel accumulates
                 x, slot = tap(e - first)
                 if parts is not None:
-                    node = self._ops[e](x, parts[2 * e], node, parts[2 * e + 1], selected=True, slot=slot)
+                    node = self._ops[e](x, parts[2 * e], node, parts[2 * e + 1], selected=True, slot=slot, x1d=x1_of(e - first))
                 else:
                     node = self._ops[e](x, weights[e], node, weights2[e])
             states.append(node)

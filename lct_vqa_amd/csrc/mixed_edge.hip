@@ -192,7 +192,7 @@ __device__ __forceinline__ void store_row(float* __restrict__ dst, const float* 
 // Input tile origin (S*ty0 - 4, S*tx0 - 4): halo 4 = the reach of dil_conv_5x5 (padding 4, dilation 2).
 // ------------------------------------------------------------------------------------------------------------------
 template <int CQ, int S, int TH, int TW>
-__global__ __launch_bounds__(TH * TW) void edge_fwd_a_kernel(const float* __restrict__ x, int B, int H, int W, EdgeW wts,
+__global__ __launch_bounds__(TH * TW) void edge_fwd_a_kernel(const float* __restrict__ x /* x1 rows */, long ldx, int B, int H, int W, EdgeW wts,
                                                              float* __restrict__ pre /* [9][P][CQ] */,
                                                              double* __restrict__ part /* [grid][7*CQ][2] */) {
   constexpr int TPB = TH * TW, NQ = CQ / 4, C = 4 * CQ;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(TH * TW) void edge_fwd_a_kernel(const float* __rest
     const int tr = (int)(tidx % (tiles_y * tiles_x));
     const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
     __syncthreads();                                           // previous tile's readers are done (also orders the weight staging)
-    load_tile<NQ, 0, IH, IW, TPB>(tile, x, C, n, H, W, S * ty0 - 4, S * tx0 - 4, nullptr, nullptr);
+    load_tile<NQ, 0, IH, IW, TPB>(tile, x, ldx, n, H, W, S * ty0 - 4, S * tx0 - 4, nullptr, nullptr);
     __syncthreads();
     const int oy = ty0 + ly, ox = tx0 + lx;
     const bool live = oy < Ho && ox < Wo;
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void edge_bwd_sums_kernel(const float* __restr
     if (S == 1) {
       const float* xp = x + q * C + 4 * q4;
       const f32x4 x1v = *(const f32x4*)xp;
-      *(f32x4*)(x1d + q * CQ + 4 * q4) = x1v;
+      if (x1d) *(f32x4*)(x1d + q * CQ + 4 * q4) = x1v;
 #pragma unroll
       for (int e = 0; e < 4; e++) acc[2][e] = fmaf(dy[e], x1v[e], acc[2][e]);
 #pragma unroll
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void edge_bwd_sums_kernel(const float* __restr
       const int W = 2 * Wo, H = 2 * Ho;
       const long base = (((long)n * H + 2 * oy) * W + 2 * ox) * C + 4 * q4;
       const long rs = (long)W * C;
-      {   // the four x1 quads of the window (same rows as the bypass channels read below)
+      if (x1d) {   // the four x1 quads of the window (same rows as the bypass channels read below)
         const long pix = ((long)n * H + 2 * oy) * W + 2 * ox;
         *(f32x4*)(x1d + pix * CQ + 4 * q4) = *(const f32x4*)(x + base);
         *(f32x4*)(x1d + (pix + 1) * CQ + 4 * q4) = *(const f32x4*)(x + base + C);
@@ -1892,7 +1892,7 @@ long lctvqa_mixed_edge_bwd_scratch_floats(int B, int H, int W, int C, int stride
 // out row stride ldo.
 int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride, const void* const* w, void* const* bn,
                           float* pre, float* mean, float* invstd, double* part, const float* wsel, const float* beta,
-                          float* out, long ldo, int accumulate, int training, float momentum, float eps, void* stream) {
+                          float* out, long ldo, int accumulate, int training, float momentum, float eps, const float* x1d, void* stream) {
   LCT_REQUIRE(lctvqa_mixed_edge_supported(B, H, W, C, stride), "mixed_edge_fwd: unsupported shape B=%d H=%d W=%d C=%d s=%d", B, H, W, C, stride);
   LCT_REQUIRE((((uintptr_t)x | (uintptr_t)pre | (uintptr_t)out | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0 && (ldo & 3) == 0,
               "mixed_edge_fwd: tensors must be 16-B aligned");
@@ -1912,7 +1912,7 @@ int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride
   {                                                                                                                        \
     const size_t lds = fwd_a_lds<CQv, Sv, THv, TWv>();                                                                     \
     grid = tile_grid((const void*)edge_fwd_a_kernel<CQv, Sv, THv, TWv>, THv * TWv, lds, TILES(THv, TWv), rows);           \
-    hipLaunchKernelGGL((edge_fwd_a_kernel<CQv, Sv, THv, TWv>), dim3(grid), dim3(THv * TWv), lds, st, x, B, H, W, ew, pre, part); \
+    hipLaunchKernelGGL((edge_fwd_a_kernel<CQv, Sv, THv, TWv>), dim3(grid), dim3(THv * TWv), lds, st, x1d ? x1d : x, (long)(x1d ? CQv : C), B, H, W, ew, pre, part); \
   }
 #define EDGE_B(CQv, THv, TWv)                                                                                              \
   {                                                                                                                        \
@@ -1957,7 +1957,8 @@ int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride
 // lctvqa_mixed_edge_bwd_scratch_floats floats, 16-byte aligned.
 int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, int H, int W, int C, int stride, const void* const* w,
                           const float* pre, const float* mean, const float* invstd, const float* wsel, const float* beta, float* dx,
-                          float* dwsel, float* dbeta, float* wgrad, float* scratch, int training, int accumulate_dx, void* stream) {
+                          float* dwsel, float* dbeta, float* wgrad, float* scratch, int training, int accumulate_dx, const float* x1d_in,
+                          void* stream) {
   LCT_REQUIRE(lctvqa_mixed_edge_supported(B, H, W, C, stride), "mixed_edge_bwd: unsupported shape B=%d H=%d W=%d C=%d s=%d", B, H, W, C, stride);
   LCT_REQUIRE((((uintptr_t)dout | (uintptr_t)x | (uintptr_t)pre | (uintptr_t)dx | (uintptr_t)scratch | (uintptr_t)wgrad) & 15) == 0 && (ldd & 3) == 0,
               "mixed_edge_bwd: tensors must be 16-B aligned");
@@ -1975,8 +1976,9 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
   float* dY = scratch;
   float* dBN = dY + P * CQ;                                    // [2][P][CQ]
   float* dx1c = dBN + 2 * P * CQ;                              // [B][H][W][CQ]: what the conv stages send to x1
-  float* x1d = dx1c + (long)B * H * W * CQ;                    // [B][H][W][CQ]: dense x[..., :CQ] (a 16..64-byte slice of every NHWC row of x otherwise)
-  float* part1 = x1d + (long)B * H * W * CQ;                   // [<=1536][8*CQ+1]
+  float* x1s = dx1c + (long)B * H * W * CQ;                    // [B][H][W][CQ]: dense x[..., :CQ] (a 16..64-byte slice of every NHWC row of x otherwise),
+  const float* x1d = x1d_in ? x1d_in : x1s;                    // written by the sums pass unless the caller kept the forward's copy
+  float* part1 = x1s + (long)B * H * W * CQ;                   // [<=1536][8*CQ+1]
   float* coef = part1 + 1536L * (8 * CQ + 1);
   coef += (4 - ((coef - scratch) & 3)) & 3;
   float* wtaps = coef + 9 * COEF;                              // tap-major copies of the depthwise weights (16-byte aligned), offsets dw_off
@@ -1991,9 +1993,9 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
     long nb = (P * (CQ / 4) + 255) / 256;
     if (nb > 1536) nb = 1536;                                    // six workgroups per CU hide the load latency; one partial row each
     if (stride == 1)
-      hipLaunchKernelGGL(edge_bwd_sums_kernel<1>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, part1, x1d);
+      hipLaunchKernelGGL(edge_bwd_sums_kernel<1>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, part1, x1d_in ? nullptr : x1s);
     else
-      hipLaunchKernelGGL(edge_bwd_sums_kernel<2>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, part1, x1d);
+      hipLaunchKernelGGL(edge_bwd_sums_kernel<2>, dim3((int)nb), dim3(256), 0, st, dout, ldd, x, pre, mean, invstd, beta, B, Ho, Wo, CQ, dY, part1, x1d_in ? nullptr : x1s);
     if ((rc = lct_check_launch("edge_bwd_sums"))) return rc;
     hipLaunchKernelGGL(edge_bwd_coef_kernel, dim3(1), dim3(1024), 0, st, part1, (int)nb, CQ, P, stride, training, wsel, beta, invstd, coef, dwsel, dbeta, ew, wtaps);
     if ((rc = lct_check_launch("edge_bwd_coef"))) return rc;

@@ -415,6 +415,16 @@ class FanoutFn(torch.autograd.Function):
         return buf, None, None
 
 
+def dense_x1(x):
+    """x[..., :C/4] of an NHWC state as a dense tensor, outside autograd: made once per state that several fused edges read, so that
+    their forward and backward tile loads read whole cache lines (the x1 slice is 16..64 bytes of every 64..256-byte row of x)."""
+    x = _chk(x)
+    B, H, W, C = x.shape
+    y = torch.empty((B, H, W, C // 4), dtype=torch.float32, device=x.device)
+    lib('slice_channels', x, C, 0, y, C // 4, B * H * W)
+    return y
+
+
 class MixedEdgeFn(torch.autograd.Function):
     """One MixedOp + its edge accumulation as ONE autograd node on the fused tile kernels:
     ``state (+)= beta * shuffle(cat(sum_k w_k bn_k(op_k(x[..., :C/4])), bypass(x[..., C/4:])))`` (model_search.py:41-55,87).
@@ -423,9 +433,9 @@ class MixedEdgeFn(torch.autograd.Function):
     views of one flat buffer.  ``bns``: the BatchNorm2d holder per slot (None for the identity skip)."""
 
     @staticmethod
-    def forward(ctx, prev, x, wsel, beta, stride, bns, training, slot, *weights):
+    def forward(ctx, prev, x, wsel, beta, stride, bns, training, slot, x1d, *weights):
         x, wsel, beta = _chk(x), _chk(wsel), _chk(beta)
-        ctx.slot = slot
+        ctx.slot, ctx.x1d = slot, x1d
         weights = [_chk(w) for w in weights]
         B, H, W, C = x.shape
         Cq = C // 4
@@ -451,7 +461,7 @@ class MixedEdgeFn(torch.autograd.Function):
             if bn.track_running_stats:
                 bnp[slot], bnp[9 + slot], bnp[18 + slot] = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()
         lib('mixed_edge_fwd', x, B, H, W, C, stride, wptr, (ctypes.c_void_p * 27)(*bnp), pre, stats[0], stats[1], part, wsel, beta,
-            out, out.stride(2), acc, int(training), float(momentum), float(eps))
+            out, out.stride(2), acc, int(training), float(momentum), float(eps), x1d)
         ctx.save_for_backward(x, wsel, beta, pre, stats, *weights)
         ctx.cfg = (stride, int(training), prev is not None)
         return out
@@ -481,12 +491,12 @@ class MixedEdgeFn(torch.autograd.Function):
         scratch = _scratch(lib.query('mixed_edge_bwd_scratch_floats', B, H, W, C, stride), torch.float32, dev)
         wptr = (ctypes.c_void_p * 14)(*([w.data_ptr() for w in weights] + [None] * (14 - len(weights))))
         lib('mixed_edge_bwd', dout, ldd, x, B, H, W, C, stride, wptr, pre, stats[0], stats[1], wsel, beta, dx, dw, dbeta,
-            wgrad, scratch, training, acc_dx)
+            wgrad, scratch, training, acc_dx, ctx.x1d)
         grads, o = [], 0
         for w in weights:
             grads.append(wgrad[o:o + w.numel()].view_as(w))
             o += w.numel()
-        return (dout if has_prev else None, None if ctx.slot is not None else dx, dw, dbeta, None, None, None, None) + tuple(grads)
+        return (dout if has_prev else None, None if ctx.slot is not None else dx, dw, dbeta, None, None, None, None, None) + tuple(grads)
 
 # ------------------------------------------------------------------------------------------ interpreter
 def _bn_args(bn):
