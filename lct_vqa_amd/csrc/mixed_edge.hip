@@ -93,9 +93,16 @@ __device__ __forceinline__ void load_tile(f32x4* __restrict__ tile, const float*
 // TAPS: weights staged tap-major [K*K][CQ] (stage_weights_taps: one 16-byte broadcast read per tap and channel quad) or
 // channel-major [CQ][K*K] as the parameter stores them (four 4-byte reads).  Same accumulation order either way (bit-identical);
 // measured per kernel: the forward kernels gain from the tap-major form at Cq = 4 and lose at Cq = 8 / 16, the backward kernel gains.
-template <int CQ, int K, int DIL, bool RELU, bool TAPS>
+typedef const __attribute__((address_space(4))) float* const_f32_ptr;   // constant address space: uniform loads become s_load (SGPR operands)
+__device__ __forceinline__ const_f32_ptr scalar_ptr(const float* p) {     // per use site: the loads are re-issued there instead of held in SGPRs
+  unsigned long a = (unsigned long)(uintptr_t)p;
+  asm volatile("" : "+s"(a));
+  return (const_f32_ptr)a;
+}
+
+template <int CQ, int K, int DIL, bool RELU, bool TAPS, typename WP = const float*>
 __device__ __forceinline__ void dw_at(const f32x4* __restrict__ tile, int npos, int tw, int cy, int cx,
-                                      const float* __restrict__ wl, float* __restrict__ out) {
+                                      WP wl, float* __restrict__ out) {
 #pragma unroll
   for (int q = 0; q < CQ / 4; q++) {
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -105,7 +112,7 @@ __device__ __forceinline__ void dw_at(const f32x4* __restrict__ tile, int npos, 
       for (int i = 0; i < K; i++) {
         f32x4 v = tile[q * npos + (cy + DIL * j) * tw + cx + DIL * i];
         if (RELU) v = relu4(v);
-        if (TAPS) {
+        if constexpr (TAPS) {
           const f32x4 w4 = *(const f32x4*)(wl + (j * K + i) * CQ + 4 * q);
 #pragma unroll
           for (int e = 0; e < 4; e++) a[e] = fmaf(w4[e], v[e], a[e]);
@@ -120,8 +127,8 @@ __device__ __forceinline__ void dw_at(const f32x4* __restrict__ tile, int npos, 
 }
 
 // out[oc] = sum_c w[oc][c] * in[c]  (w in LDS, uniform address across the wave: broadcast reads)
-template <int NO, int NI>
-__device__ __forceinline__ void pw_at(const float* __restrict__ wl, const float* __restrict__ in, float* __restrict__ out) {
+template <int NO, int NI, typename WP = const float*>
+__device__ __forceinline__ void pw_at(WP wl, const float* __restrict__ in, float* __restrict__ out) {
 #pragma unroll
   for (int oc = 0; oc < NO; oc++) {            // one accumulation chain per output in channel order (the compiler merges the weight
     float a = 0.f;                             // reads into 8-byte pairs): splitting it into four partial sums changes the rounding
@@ -269,8 +276,13 @@ __global__ __launch_bounds__(TH * TW) void edge_fwd_a_kernel(const float* __rest
 #pragma unroll
           for (int e = 0; e < 4; e++) { r0[4 * q + e] = a[e]; r1[4 * q + e] = b[e]; }
         }
+#ifndef EDGE_FWD_SCALARW   // measured: scalar-loaded weights lose 7-15 % in the forward kernels at Cq = 4, 8 (tools/ab_edge.py), -6 % only on the stride-2 Cq = 16 edge
         pw_at<CQ / 2, CQ>(w_fr, r0, &u[2][0]);
         pw_at<CQ / 2, CQ>(w_fr + CQ / 2 * CQ, r1, &u[2][CQ / 2]);
+#else
+        pw_at<CQ / 2, CQ>(scalar_ptr(wts.fr[0]), r0, &u[2][0]);
+        pw_at<CQ / 2, CQ>(scalar_ptr(wts.fr[1]), r1, &u[2][CQ / 2]);
+#endif
       } else {
 #pragma unroll
         for (int c = 0; c < CQ; c++) u[2][c] = 0.f;
@@ -284,19 +296,33 @@ __global__ __launch_bounds__(TH * TW) void edge_fwd_a_kernel(const float* __rest
     }
     {   // ---- first stages of sep_conv_3x3 / sep_conv_5x5: relu -> depthwise (stride S) -> 1x1 ----
       float u[2][CQ], d[CQ];
+#ifndef EDGE_FWD_SCALARW   // measured: scalar-loaded weights lose 7-15 % in the forward kernels at Cq = 4, 8 (tools/ab_edge.py), -6 % only on the stride-2 Cq = 16 edge
       dw_at<CQ, 3, 1, true, TAPS>(tile, NPOS, IW, cy - 1, cx - 1, w_dw3a, d);
       pw_at<CQ, CQ>(w_pw, d, u[0]);
       dw_at<CQ, 5, 1, true, TAPS>(tile, NPOS, IW, cy - 2, cx - 2, w_dw5a, d);
       pw_at<CQ, CQ>(w_pw + CQ * CQ, d, u[1]);
+#else
+      dw_at<CQ, 3, 1, true, false>(tile, NPOS, IW, cy - 1, cx - 1, scalar_ptr(wts.dw[0]), d);
+      pw_at<CQ, CQ>(scalar_ptr(wts.pw[0]), d, u[0]);
+      dw_at<CQ, 5, 1, true, false>(tile, NPOS, IW, cy - 2, cx - 2, scalar_ptr(wts.dw[1]), d);
+      pw_at<CQ, CQ>(scalar_ptr(wts.pw[1]), d, u[1]);
+#endif
       if (live) { store_row<CQ>(pre + (3 * P + qo) * CQ, u[0]); store_row<CQ>(pre + (4 * P + qo) * CQ, u[1]); }
       phase_stats<CQ, 2, 7, TPB>(u, live, red, seg, acc, 3);
     }
     {   // ---- dil_conv_3x3 / dil_conv_5x5: relu -> depthwise (stride S, dilation 2) -> 1x1 ----
       float u[2][CQ], d[CQ];
+#ifndef EDGE_FWD_SCALARW   // measured: scalar-loaded weights lose 7-15 % in the forward kernels at Cq = 4, 8 (tools/ab_edge.py), -6 % only on the stride-2 Cq = 16 edge
       dw_at<CQ, 3, 2, true, TAPS>(tile, NPOS, IW, cy - 2, cx - 2, w_dd3, d);
       pw_at<CQ, CQ>(w_pw + 2 * CQ * CQ, d, u[0]);
       dw_at<CQ, 5, 2, true, TAPS>(tile, NPOS, IW, cy - 4, cx - 4, w_dd5, d);
       pw_at<CQ, CQ>(w_pw + 3 * CQ * CQ, d, u[1]);
+#else
+      dw_at<CQ, 3, 2, true, false>(tile, NPOS, IW, cy - 2, cx - 2, scalar_ptr(wts.dw[2]), d);
+      pw_at<CQ, CQ>(scalar_ptr(wts.pw[2]), d, u[0]);
+      dw_at<CQ, 5, 2, true, false>(tile, NPOS, IW, cy - 4, cx - 4, scalar_ptr(wts.dw[3]), d);
+      pw_at<CQ, CQ>(scalar_ptr(wts.pw[3]), d, u[1]);
+#endif
       if (live) { store_row<CQ>(pre + (5 * P + qo) * CQ, u[0]); store_row<CQ>(pre + (6 * P + qo) * CQ, u[1]); }
       phase_stats<CQ, 2, 7, TPB>(u, live, red, seg, acc, 5);
     }
@@ -355,10 +381,18 @@ __global__ __launch_bounds__(TH * TW) void edge_fwd_b_kernel(int B, int Ho, int 
     const int oy = ty0 + ly, ox = tx0 + lx;
     const bool live = oy < Ho && ox < Wo;
     float u[2][CQ], d[CQ];
+#ifndef EDGE_FWD_SCALARW   // measured: scalar-loaded weights lose 7-15 % in the forward kernels at Cq = 4, 8 (tools/ab_edge.py), -6 % only on the stride-2 Cq = 16 edge
     dw_at<CQ, 3, 1, false, TAPS>(tile3, NPOS, IW, ly + 1, lx + 1, w_dw3, d);
     pw_at<CQ, CQ>(w_pw, d, u[0]);
     dw_at<CQ, 5, 1, false, TAPS>(tile5, NPOS, IW, ly, lx, w_dw5, d);
     pw_at<CQ, CQ>(w_pw + CQ * CQ, d, u[1]);
+#else
+    // every lane needs the same weights: scalar loads from the parameters themselves (same arithmetic, same order; no LDS reads for them)
+    dw_at<CQ, 3, 1, false, false>(tile3, NPOS, IW, ly + 1, lx + 1, scalar_ptr(wts.dw[4]), d);
+    pw_at<CQ, CQ>(scalar_ptr(wts.pw[4]), d, u[0]);
+    dw_at<CQ, 5, 1, false, false>(tile5, NPOS, IW, ly, lx, scalar_ptr(wts.dw[5]), d);
+    pw_at<CQ, CQ>(scalar_ptr(wts.pw[5]), d, u[1]);
+#endif
     const long qo = ((long)n * Ho + oy) * Wo + ox;
     if (live) {
 #pragma unroll
