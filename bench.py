@@ -276,7 +276,7 @@ def bench_darts_vqa(args, rank, world, dev, img, qst, lab):
                           'global_batch': world * B, 'seq_len': 14, 'parallelism': f'dp{world}',
                           'architect_step_ms': None if arch_ms is None else round(arch_ms, 1)},
                'loss': round(float(loss.item()), 5),
-               'roofline': {'bound': 'hbm', 'kernel': 'edge_fwd_* / edge_bwd_* (fused MixedOp edge kernels, 56 edges x 17 launches)',
+               'roofline': {'bound': 'hbm', 'kernel': 'edge_fwd_* / edge_bwd_* (fused MixedOp edge kernels, 56 edges x 5 forward + 10..12 backward launches)',
                             'achieved': round(enc_bytes * B / (ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
                             'frac': round(enc_bytes * B / (ms * 1e-3) / 8e12, 4), 'traffic': None,
                             'algorithmic_bytes_per_pair': enc_bytes,
