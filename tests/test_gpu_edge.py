@@ -266,3 +266,49 @@ def test_darts_vqa_model_at_224(hip_lib):
     assert rel_err(l0, lp) < 1e-5
     for a, b in zip(g0, gp):
         assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + 1e-12
+
+
+@pytest.mark.parametrize('C,stride,B,H,W', [(16, 1, 2, 40, 72), (32, 2, 1, 20, 68), (64, 1, 1, 18, 50), (64, 2, 2, 36, 44)])
+def test_two_readers_of_one_state_share_a_gradient_buffer_and_a_dense_x1(hip_lib, C, stride, B, H, W):
+    """Cell.forward's plumbing for a state that several edges read (darts_ops.FanoutFn / GradSlot / dense_x1): every reader gets its own
+    alias of the state, the fused edges add their input gradients into ONE buffer inside edge_bwd_pools (accumulate_dx) and read the x1
+    slice from a dense copy.  Against the same two edges run the plain way (own dx tensors summed by autograd, x1 read from x): the
+    state's gradient must be the bit-identical sum (a + b either way), every other gradient bit-identical, also on a second backward
+    pass through a fresh graph (the slot is tied to the backward pass)."""
+    from lct_vqa_amd import darts_ops as D
+    from lct_vqa_amd.basic_vqa import config
+    from lct_vqa_amd.basic_vqa.pcdarts import model_search as MS
+    config.DEVICE = torch.device(DEV)
+    torch.manual_seed(C + stride)
+    ops = [MS.MixedOp(C, stride).to(DEV).train() for _ in range(2)]
+    x = torch.randn(B, H, W, C, device=DEV)
+    ws = [torch.softmax(torch.randn(8, device=DEV), 0).requires_grad_() for _ in range(2)]
+    bs = [(torch.rand(1, device=DEV) + 0.5).requires_grad_() for _ in range(2)]
+    gout = torch.randn(B, H // stride, W // stride, C, device=DEV)
+    params = [p for op in ops for p in op.parameters()]
+
+    def run(shared):
+        leaf = x.clone().requires_grad_()
+        state = leaf * 1.0                                          # a non-leaf state, as in the cell
+        if shared:
+            slot, x1d = D.GradSlot(), D.dense_x1(state.detach())
+            a, b, c = D.FanoutFn.apply(state, 3, slot)
+            node = ops[0](a, ws[0], None, bs[0], slot=slot, x1d=x1d)
+            node = ops[1](b, ws[1], node, bs[1], slot=slot, x1d=x1d)
+            tail = c                                                # a third, ordinary reader (the cell's concatenation)
+        else:
+            node = ops[0](state, ws[0], None, bs[0])
+            node = ops[1](state, ws[1], node, bs[1])
+            tail = state
+        loss = (node * gout).sum() + (tail * tail).sum() * 0.5
+        return torch.autograd.grad(loss, [leaf] + ws + bs + params)
+
+    plain = run(False)
+    for rnd in range(2):
+        shared = run(True)
+        assert len(shared) == len(plain)
+        for i, (g, r) in enumerate(zip(shared, plain)):
+            if i == 0:                                              # dx: a + b + tail in either association; the sums differ by rounding only
+                assert rel_err(g, r) < 1e-6, (rnd, rel_err(g, r))
+            else:
+                assert torch.equal(g, r), (rnd, i, rel_err(g, r))
