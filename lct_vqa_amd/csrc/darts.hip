@@ -515,6 +515,79 @@ __global__ __launch_bounds__(256) void pwconv_wgrad_quad_kernel(const float* __r
   }
 }
 
+// dW[co][ci] = sum_p dY[p][co] * (relu) X[p][ci] for the preprocess 1x1 convolutions (16..64 outputs, 48..256 inputs, P = 0.2 .. 3.2 M
+// pixels): a reduction over the pixels, not a GEMM shape -- as a split-K TN GEMM it ran at 1.2 TB/s of its operands.  Workgroup = a slice of
+// the pixels, staged TP rows at a time in LDS (whole rows, 16-byte loads); thread = a 4 x RBI block of dW (its RBI inputs interleaved in
+// groups of four NBI*4 apart: neighbouring lanes read neighbouring 16-byte words) x a pixel lane; one 16-byte read of dY and RBI/4 of X
+// per 4*RBI multiply-adds.  Per-workgroup partials, summed in a fixed order by colsum_partials_kernel.
+template <int RBI>
+__global__ __launch_bounds__(256) void pwconv_wgrad_blk_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+                                                               long P, int Cout, int Cin, int relu_in, long per_blk, int TP) {
+  extern __shared__ __align__(16) float smw[];
+  f32x4* sdy = (f32x4*)smw;                       // [TP][Cout/4]
+  f32x4* sx = sdy + TP * (Cout / 4);              // [TP][Cin/4]
+  const int NO4 = Cout / 4, NI4 = Cin / 4, NBI = Cin / RBI, NBT = NO4 * NBI, PL = 256 / NBT;
+  const int bt = threadIdx.x % NBT, pl = threadIdx.x / NBT;
+  const int bo = bt / NBI, bi = bt % NBI;
+  const bool live = pl < PL;
+  f32x4 acc[RBI];                                  // acc[4k + j][a]: dW[4 bo + a][4 (bi + NBI k) + j]
+#pragma unroll
+  for (int i = 0; i < RBI; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long q0 = blockIdx.x * per_blk, q1 = min(P, q0 + per_blk);
+  for (long qb = q0; qb < q1; qb += TP) {
+    const int np = (int)min((long)TP, q1 - qb);
+    __syncthreads();
+    const f32x4* gd = (const f32x4*)(dy + qb * Cout);
+    const f32x4* gx = (const f32x4*)(x + qb * Cin);
+    for (int t = threadIdx.x; t < np * NO4; t += 256) sdy[t] = gd[t];
+    for (int t = threadIdx.x; t < np * NI4; t += 256) {
+      f32x4 v = gx[t];
+      if (relu_in) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+      sx[t] = v;
+    }
+    __syncthreads();
+    if (live)
+      for (int pp = pl; pp < np; pp += PL) {
+        const f32x4 g4 = sdy[pp * NO4 + bo];
+#pragma unroll
+        for (int k = 0; k < RBI / 4; k++) {
+          const f32x4 x4 = sx[pp * NI4 + bi + NBI * k];
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) acc[4 * k + j][a] = fmaf(g4[a], x4[j], acc[4 * k + j][a]);
+        }
+      }
+  }
+  // fold the pixel lanes (fixed order) and write this workgroup's partial row
+  float* prow = part + (long)blockIdx.x * Cout * Cin;
+  if (PL == 1) {
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < RBI / 4; k++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int a = 0; a < 4; a++) prow[(4 * bo + a) * Cin + 4 * (bi + NBI * k) + j] = acc[4 * k + j][a];
+    }
+    return;
+  }
+  __syncthreads();
+  float* red = smw;                               // [PL][NBT][4 * RBI]   (fits: checked on the host)
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < RBI; i++) *(f32x4*)(red + ((pl * NBT + bt) * RBI + i) * 4) = acc[i];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NBT * RBI * 4; e += 256) {
+    float sum = 0.f;
+    for (int l = 0; l < PL; l++) sum += red[l * NBT * RBI * 4 + e];
+    const int b = e / (RBI * 4), i = (e / 4) % RBI, a = e % 4;
+    const int eo = b / NBI, ei = b % NBI;
+    prow[(4 * eo + a) * Cin + 4 * (ei + NBI * (i / 4)) + i % 4] = sum;
+  }
+}
+
 // out[t] = sum_blk part[blk][t]   (one wave per output)
 __global__ __launch_bounds__(64) void colsum_partials_kernel(const float* __restrict__ part, int nblk, int NO, float* __restrict__ out) {
   const int t = blockIdx.x;
@@ -1081,7 +1154,19 @@ long lctvqa_pwconv_wgrad_small_scratch_elems(long P, int Cout, int Cin) {
   int nb = red_blocks(P, &per);
   return (long)nb * Cout * Cin;
 }
+// the register-blocked form: which input block size, 0 = not this shape
+static int pw_wgrad_rbi(int Cout, int Cin) {
+  if (Cout % 4 || Cin % 16 || Cout > 64 || Cin > 256) return 0;
+  for (int rbi = 4; rbi <= 16; rbi *= 2)
+    if (Cin % rbi == 0 && (Cout / 4) * (Cin / rbi) <= 256) return rbi;
+  return 0;
+}
+static int pw_wgrad_tp(int Cout, int Cin) {        // rows staged at a time: about 32 KB of LDS
+  int tp = 8192 / (Cout + Cin);
+  return tp > 256 ? 256 : (tp < 8 ? 8 : tp);
+}
 int lctvqa_pwconv_wgrad_small_supported(long P, int Cout, int Cin) {
+  if (P >= 1 && pw_wgrad_rbi(Cout, Cin)) return 1;
   return P >= 1 && Cout >= 1 && Cin >= 1 && (long)Cout * Cin <= 4096 && (Cout + Cin) * 256 * 4 <= 60 * 1024;
 }
 int lctvqa_pwconv_wgrad_small(const float* dy, const float* x, float* dw, float* scratch, long P, int Cout, int Cin, int relu_in,
@@ -1097,7 +1182,18 @@ int lctvqa_pwconv_wgrad_small(const float* dy, const float* x, float* dw, float*
     if (Cin == 4) hipLaunchKernelGGL(pwconv_wgrad_quad_kernel<4>, dim3(nb), dim3(256), 0, st, dy, x, scratch, (int)P, Cout, relu_in);
     else if (Cin == 8) hipLaunchKernelGGL(pwconv_wgrad_quad_kernel<8>, dim3(nb), dim3(256), 0, st, dy, x, scratch, (int)P, Cout, relu_in);
     else hipLaunchKernelGGL(pwconv_wgrad_quad_kernel<16>, dim3(nb), dim3(256), 0, st, dy, x, scratch, (int)P, Cout, relu_in);
+  } else if (const int rbi = pw_wgrad_rbi(Cout, Cin); rbi && (((uintptr_t)dy | (uintptr_t)x) & 15) == 0) {
+    const int tp = pw_wgrad_tp(Cout, Cin);
+    const int nbt = (Cout / 4) * (Cin / rbi), pl = 256 / nbt;
+    size_t lds = (size_t)tp * (Cout + Cin) * sizeof(float);
+    const size_t red = pl > 1 ? (size_t)pl * nbt * rbi * 4 * sizeof(float) : 0;
+    if (red > lds) lds = red;
+    hipStream_t st = (hipStream_t)stream;
+    if (rbi == 4) hipLaunchKernelGGL(pwconv_wgrad_blk_kernel<4>, dim3(nb), dim3(256), lds, st, dy, x, scratch, P, Cout, Cin, relu_in, per, tp);
+    else if (rbi == 8) hipLaunchKernelGGL(pwconv_wgrad_blk_kernel<8>, dim3(nb), dim3(256), lds, st, dy, x, scratch, P, Cout, Cin, relu_in, per, tp);
+    else hipLaunchKernelGGL(pwconv_wgrad_blk_kernel<16>, dim3(nb), dim3(256), lds, st, dy, x, scratch, P, Cout, Cin, relu_in, per, tp);
   } else {
+    LCT_REQUIRE((long)Cout * Cin <= 4096 && (Cout + Cin) * 256 * 4 <= 60 * 1024, "pwconv_wgrad_small: unaligned operands for Cout=%d Cin=%d", Cout, Cin);
     size_t lds = (size_t)(Cout + Cin) * 256 * sizeof(float);
     hipLaunchKernelGGL(pwconv_wgrad_small_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, dy, x, scratch, P, Cout, Cin, relu_in, per);
   }

@@ -54,3 +54,21 @@ def test_pointwise_weight_gradient_vs_torch(hip_lib, Cin, Cout, relu):
     scratch = torch.empty(hip_lib.query('pwconv_wgrad_small_scratch_elems', P, Cout, Cin), device=DEV)
     hip_lib('pwconv_wgrad_small', dy.to(DEV), x.to(DEV), dw, scratch, P, Cout, Cin, relu)
     assert rel_err(dw.double(), ref) < 1e-5
+
+
+@pytest.mark.parametrize('Cout,Cin', [(16, 48), (32, 48), (32, 64), (64, 128), (64, 256), (8, 16), (64, 16), (4, 256)])
+@pytest.mark.parametrize('relu', [0, 1])
+def test_pointwise_weight_gradient_blocked_kernel_vs_torch(hip_lib, Cout, Cin, relu):
+    """The preprocess layers' shapes (ReLUConvBN C_prev -> C of every cell, operations.py:24-33): register-blocked reduction kernel
+    (pwconv_wgrad_blk_kernel) instead of a split-K TN GEMM; a pixel count that is not a multiple of anything, and one larger than a
+    workgroup's slice."""
+    torch.manual_seed(3 * Cin + Cout + relu)
+    for P in (3 * 37 * 29, 70001):
+        x = torch.randn(P, Cin)
+        dy = torch.randn(P, Cout)
+        ref = dy.double().t() @ (torch.relu(x) if relu else x).double()
+        assert hip_lib.query('pwconv_wgrad_small_supported', P, Cout, Cin)
+        dw = torch.full((Cout, Cin), float('nan'), device=DEV)
+        scratch = torch.empty(hip_lib.query('pwconv_wgrad_small_scratch_elems', P, Cout, Cin), device=DEV)
+        hip_lib('pwconv_wgrad_small', dy.to(DEV), x.to(DEV), dw, scratch, P, Cout, Cin, relu)
+        assert rel_err(dw.double(), ref) < 1e-5, (P, rel_err(dw.double(), ref))
