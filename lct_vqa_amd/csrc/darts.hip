@@ -777,6 +777,64 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     part[((long)blockIdx.x * 2 + 1) * C + threadIdx.x] = tb;
   }
 }
+// The same sums with 16-byte loads, four rows in flight per thread (thread = (row lane, channel quad); C % 4 == 0, 16-byte aligned rows):
+// the scalar form above issued one 4-byte load per dependent iteration and ran at 1.5 TB/s.  Same fp64 accumulation; the row lanes are
+// folded in the same fixed order.  MODE 0: sum x, sum x^2;  MODE 1: sum dy, sum dy * xhat.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_sums_vec_kernel(const float* __restrict__ a_, long lda, const float* __restrict__ x, long ldx,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd, long P, int C,
+                                                          long per_blk, double* __restrict__ part) {
+  __shared__ double s1[256 * 4 / 4 * 4], s2[256 * 4 / 4 * 4];    // [row lane][C]
+  const int CQ = C / 4, nrl = 256 / CQ;
+  const int q4 = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+  const long q0 = blockIdx.x * per_blk, q1 = min(P, q0 + per_blk);
+  double sa[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
+  if (rl < nrl) {
+    f32x4 m = {0.f, 0.f, 0.f, 0.f}, is = m;
+    if (MODE == 1) { m = *(const f32x4*)(mean + 4 * q4); is = *(const f32x4*)(invstd + 4 * q4); }
+    long q = q0 + rl;
+    for (; q + 3L * nrl < q1; q += 4L * nrl) {
+      f32x4 va[4], vx[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        va[u] = *(const f32x4*)(a_ + (q + (long)u * nrl) * lda + 4 * q4);
+        if (MODE == 1) vx[u] = *(const f32x4*)(x + (q + (long)u * nrl) * ldx + 4 * q4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const double g = va[u][e];
+          sa[e] += g;
+          sb[e] += MODE == 1 ? g * (double)((vx[u][e] - m[e]) * is[e]) : g * g;
+        }
+    }
+    for (; q < q1; q += nrl) {
+      const f32x4 va = *(const f32x4*)(a_ + q * lda + 4 * q4);
+      f32x4 vx = va;
+      if (MODE == 1) vx = *(const f32x4*)(x + q * ldx + 4 * q4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const double g = va[e];
+        sa[e] += g;
+        sb[e] += MODE == 1 ? g * (double)((vx[e] - m[e]) * is[e]) : g * g;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) { s1[rl * C + 4 * q4 + e] = sa[e]; s2[rl * C + 4 * q4 + e] = sb[e]; }
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double ta = 0.0, tb = 0.0;
+    for (int r = 0; r < nrl; r++) { ta += s1[r * C + threadIdx.x]; tb += s2[r * C + threadIdx.x]; }
+    part[((long)blockIdx.x * 2 + 0) * C + threadIdx.x] = ta;
+    part[((long)blockIdx.x * 2 + 1) * C + threadIdx.x] = tb;
+  }
+}
+static bool bn_vec_ok(const float* a, long lda, const float* x, long ldx, int C) {
+  return C % 4 == 0 && C <= 256 && 256 % (C / 4) == 0 && lda % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)a | (uintptr_t)x) & 15) == 0;
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -1254,7 +1312,10 @@ int lctvqa_batchnorm_fwd(const float* x, long ldx, float* y, long ldy, long P, i
   if (training) {
     long per;
     int nb = red_blocks(P, &per);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(256), 0, st, x, ldx, P, C, per, scratch);
+    if (bn_vec_ok(x, ldx, x, ldx, C))
+      hipLaunchKernelGGL(bn_sums_vec_kernel<0>, dim3(nb), dim3(256), 0, st, x, ldx, x, ldx, (const float*)nullptr, (const float*)nullptr, P, C, per, scratch);
+    else
+      hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(256), 0, st, x, ldx, P, C, per, scratch);
     int rc = lct_check_launch("bn_stats_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(C), dim3(64), 0, st, scratch, nb, C, P, eps, momentum, mean, invstd, run_mean,
@@ -1276,7 +1337,10 @@ int lctvqa_batchnorm_bwd(const float* dy, long lddy, const float* x, long ldx, c
   LCT_REQUIRE(C >= 1 && C <= 256, "batchnorm_bwd: need 1 <= C <= 256");
   long per;
   int nb = red_blocks(P, &per);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(256), 0, st, dy, lddy, x, ldx, mean, invstd, P, C, per, scratch);
+  if (bn_vec_ok(dy, lddy, x, ldx, C) && (((uintptr_t)mean | (uintptr_t)invstd) & 15) == 0)
+    hipLaunchKernelGGL(bn_sums_vec_kernel<1>, dim3(nb), dim3(256), 0, st, dy, lddy, x, ldx, mean, invstd, P, C, per, scratch);
+  else
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(256), 0, st, dy, lddy, x, ldx, mean, invstd, P, C, per, scratch);
   int rc = lct_check_launch("bn_bwd_partial");
   if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(C), dim3(64), 0, st, scratch, nb, C, sums, sums + C);
