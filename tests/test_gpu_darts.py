@@ -40,6 +40,25 @@ def test_dwconv(D, K, stride, pad, dil):
     assert rel_err(nchw(dx), gx) < 1e-5 and rel_err(dw, gw) < 1e-4
 
 
+@pytest.mark.parametrize('Cout,Cin', [(16, 48), (32, 48), (32, 64), (64, 128), (64, 256)])
+@pytest.mark.parametrize('relu', [True, False])
+def test_preprocess_pointwise_conv_shapes_vs_torch(D, Cout, Cin, relu):
+    """ReLUConvBN's 1x1 convolution at the channel counts of the search network's preprocess layers (operations.py:24-33: 3C = 48 stem
+    channels and 4C cell outputs into C): forward, input gradient (with the ReLU mask) and weight gradient, each on the kernel the
+    dispatch picks for that shape (GEMM / pwconv_small / pwconv_wgrad_blk)."""
+    g = torch.Generator().manual_seed(Cout + Cin)
+    x = torch.randn(2, Cin, 13, 11, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) * 0.2).requires_grad_()
+    ref = F.conv2d(torch.relu(x) if relu else x, w)
+    gy = torch.randn_like(ref)
+    gx, gw = torch.autograd.grad(ref, [x, w], gy)
+    xd, wd = nhwc(x.detach()).requires_grad_(), w.detach().to(DEV).requires_grad_()
+    y = D.PwConvFn.apply(xd, wd, relu)
+    assert rel_err(nchw(y), ref) < 1e-5
+    dx, dw = torch.autograd.grad(y, [xd, wd], nhwc(gy))
+    assert rel_err(nchw(dx), gx) < 1e-5 and rel_err(dw, gw) < 1e-5
+
+
 def test_pwconv_and_bn(D):
     g = torch.Generator().manual_seed(2)
     x = torch.randn(3, 12, 9, 7, generator=g, requires_grad=True)
