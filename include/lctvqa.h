@@ -345,7 +345,8 @@ int lctvqa_conv7x7_s2_stem_bf16_mfma(const float* x_nchw, const float* w_oihw, c
  * sep3.a, sep5.a, dil3, dil5, sep3.b, sep5.b; their 1x1 weights [Cq][Cq]; FactorizedReduce conv_1 / conv_2 [Cq/2][Cq] (stride-2
  * edges, else NULL).  bn = 27 pointers: running_mean[9], running_var[9], num_batches_tracked[9] by slot (0 max-pool, 1 avg-pool,
  * 2 skip, 3 sep3.a, 4 sep5.a, 5 dil3, 6 dil5, 7 sep3.b, 8 sep5.b; NULL = none).  pre [9][P][Cq] receives every pre-BatchNorm
- * tensor (saved for the backward), mean / invstd [9][Cq] the statistics used; part = fp64 scratch, grid*7*Cq*2 doubles.
+ * tensor (saved for the backward), mean / invstd [9][Cq] the statistics used; part = fp64 scratch, grid*7*Cq*2 + 51*Cq doubles
+ * (the tail holds the forward kernels' regrouped depthwise weights).
  * wsel [7] = softmax(alpha) of the live primitives, beta [1].  Backward: dx [B,H,W,C] (written, or added to with accumulate_dx = 1:
  * the one gradient buffer of a state that several edges read), dwsel [7], dbeta [1], wgrad = flat weight gradients in the order of w.
  * x1d (both directions, may be NULL): a dense copy [B,H,W,C/4] of x[..., :C/4] (lctvqa_slice_channels), worth making once for a state

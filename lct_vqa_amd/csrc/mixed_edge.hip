@@ -94,6 +94,7 @@ __device__ __forceinline__ void load_tile(f32x4* __restrict__ tile, const float*
 // channel-major [CQ][K*K] as the parameter stores them (four 4-byte reads).  Same accumulation order either way (bit-identical);
 // measured per kernel: the forward kernels gain from the tap-major form at Cq = 4 and lose at Cq = 8 / 16, the backward kernel gains.
 typedef const __attribute__((address_space(4))) float* const_f32_ptr;   // constant address space: uniform loads become s_load (SGPR operands)
+typedef const __attribute__((address_space(4))) f32x4* const_f32x4_ptr;
 __device__ __forceinline__ const_f32_ptr scalar_ptr(const float* p) {     // per use site: the loads are re-issued there instead of held in SGPRs
   unsigned long a = (unsigned long)(uintptr_t)p;
   asm volatile("" : "+s"(a));
@@ -331,6 +332,398 @@ __global__ __launch_bounds__(TH * TW) void edge_fwd_a_kernel(const float* __rest
   for (int i = threadIdx.x; i < 7 * CQ; i += TPB) {
     part[((long)blockIdx.x * 7 * CQ + i) * 2 + 0] = acc[i];
     part[((long)blockIdx.x * 7 * CQ + i) * 2 + 1] = acc[7 * CQ + i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// edge_fwd_a2 / edge_fwd_b2 (Cq = 8, 16): the same results as edge_fwd_a / edge_fwd_b, BIT FOR BIT, in the lane layouts of
+// edge_bwd_conv2 (thread = pixel with all channels ran at 2.5 - 5x the bytes' time at these widths: every weight an LDS broadcast):
+//   * the tiles are stored in "strided quads": plane q holds channels q, q + NQ, q + 2 NQ, q + 3 NQ of a position;
+//   * depthwise phase: a wave owns one strided quad, a lane one pixel; the quad's weights are scalar loads from a tap-major copy
+//     (edge_fwd_prep_kernel), the per-channel tap order is the first version's;
+//   * 1x1 phase: lane = (pixel, strided quad) -- the B operand of v_mfma_f32_16x16x4_f32; instruction m consumes element m of every
+//     lane, i.e. input channels NQ*m .. NQ*m + NQ - 1 of its pixel block: with the k order of the instruction that is the first
+//     version's sequential chain over the input channels (zero A entries of other position blocks add exact zeros), and the result
+//     rows are the natural output quads;
+//   * BatchNorm partial sums: the values go through LDS as [pixel][channel] and are summed in exactly phase_stats' order (8 pixel
+//     segments per channel sequentially in fp32, the segments in fp64).
+// ------------------------------------------------------------------------------------------------------------------
+// wq[off(conv) + (tap * NQ + q) * 4 + e] = dw[conv][(q + NQ * e) * K*K + tap]   (conv = 0..5, off = cumulative taps * CQ)
+__global__ __launch_bounds__(256) void edge_fwd_prep_kernel(EdgeW wts, int CQ, float* __restrict__ wq) {
+  const int taps[6] = {9, 25, 9, 25, 9, 25};
+  const int NQ = CQ / 4;
+  int off = 0;
+  for (int i = 0; i < 6; i++) {
+    const int kk = taps[i];
+    for (int idx = threadIdx.x; idx < kk * CQ; idx += 256) {
+      const int e = idx % 4, q = (idx / 4) % NQ, tap = idx / CQ;
+      wq[off + idx] = wts.dw[i][(q + NQ * e) * kk + tap];
+    }
+    off += kk * CQ;
+  }
+}
+
+// one activated-on-read depthwise K x K at a pixel for one strided quad (weights: scalar loads); tap order = dw_at's
+template <int K, int DIL, bool RELU, int NQ>
+__device__ __forceinline__ f32x4 dw_quad(const f32x4* __restrict__ tp /* plane + top-left tap */, int tw, const float* __restrict__ wq_conv, int q) {
+  unsigned long wa = (unsigned long)(uintptr_t)(wq_conv + 4 * q);
+  asm volatile("" : "+s"(wa));
+  const const_f32x4_ptr wp = (const_f32x4_ptr)wa;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < K; j++)
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+      f32x4 v = tp[(DIL * j) * tw + DIL * i];
+      if (RELU) v = relu4(v);
+      const f32x4 w4 = wp[(j * K + i) * NQ];
+#pragma unroll
+      for (int e = 0; e < 4; e++) a[e] = fmaf(w4[e], v[e], a[e]);
+    }
+  return a;
+}
+
+// phase_stats' arithmetic on values staged as Us[k][pixel][channel] (zeros for pixels that are not live): NS slots starting at slot_base
+template <int CQ, int NPX, int TPB>
+__device__ __forceinline__ void stats_from_lds(const float* __restrict__ Us, int NS, float* __restrict__ seg, double* __restrict__ acc, int slot_base,
+                                               int NSTAT) {
+  const int NC = NS * CQ;
+  for (int idx = threadIdx.x; idx < NC * 8; idx += TPB) {
+    const int col = idx % NC, prt = idx / NC;
+    const float* r = Us + (long)(col / CQ) * NPX * CQ + (prt * (NPX / 8)) * CQ + col % CQ;
+    float a = 0.f, b = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < NPX / 8; i++) { const float v = r[i * CQ]; a += v; b = fmaf(v, v, b); }
+    seg[col * 8 + prt] = a;
+    seg[(NC + col) * 8 + prt] = b;
+  }
+  __syncthreads();
+  for (int col = threadIdx.x; col < NC; col += TPB) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int p = 0; p < 8; p++) { a += (double)seg[col * 8 + p]; b += (double)seg[(NC + col) * 8 + p]; }
+    acc[(slot_base + col / CQ) * CQ + col % CQ] += a;
+    acc[(NSTAT + slot_base + col / CQ) * CQ + col % CQ] += b;
+  }
+}
+
+template <int CQ, int S, int TH, int TW, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void edge_fwd_a2_kernel(const float* __restrict__ x /* x1 rows */, long ldx, int B, int H, int W, EdgeW wts,
+                                                                 const float* __restrict__ wq, float* __restrict__ pre /* [9][P][CQ] */,
+                                                                 double* __restrict__ part /* [grid][7*CQ][2] */) {
+  constexpr int TPB = 64 * NW, NPX = TH * TW, NQ = CQ / 4;
+  constexpr int IH = S * (TH - 1) + 9, IW = S * (TW - 1) + 9, NPOS = IH * IW;
+  constexpr int PPW = 64 / NQ, NITP = NPX / PPW, ITP = NITP / NW;          // 1x1 phase: items of PPW pixels
+  constexpr int NITC = NPX / 64, ITC = NITC * NQ / NW;                      // depthwise phase: (64-pixel item, quad) pairs per wave
+  static_assert(NW % NQ == 0 && (NITC * NQ) % NW == 0 && NITP % NW == 0 && NPX % 64 == 0 && (TW & (TW - 1)) == 0 && NPX % 8 == 0, "tile / wave split");
+  extern __shared__ __align__(16) unsigned char smem[];
+  f32x4* tile = (f32x4*)smem;                                   // [NQ][NPOS] strided quads
+  float* Ds = (float*)(tile + NQ * NPOS);                      // [2][NPX][NQ][4]: depthwise outputs, strided quads
+  float* Us = Ds + 2 * NPX * CQ;                               // [3][NPX][CQ]: pre-BN outputs, natural channel order (statistics, pooled stores)
+  float* seg = Us + 3 * NPX * CQ;                              // [2][3*CQ][8]
+  double* acc = (double*)(seg + 2 * 3 * CQ * 8);               // [2][7*CQ]
+  for (int i = threadIdx.x; i < 2 * 7 * CQ; i += TPB) acc[i] = 0.0;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n16 = lane & 15, jg = lane >> 4;
+  const int qB = jg % NQ, blkB = jg / NQ, slotB = n16 + 16 * blkB;
+  // A operands (block diagonal): A_m[i = (block, oc)][k-slot jg] = W[oc][in = qB + NQ m]
+  float aop[4][4], afr0[4], afr1[4];
+  {
+    const bool on = n16 / CQ == blkB;
+    const int oc = n16 % CQ;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int in = qB + NQ * m;
+#pragma unroll
+      for (int k = 0; k < 4; k++) aop[k][m] = on ? wts.pw[k][oc * CQ + in] : 0.f;
+      afr0[m] = (S == 2 && on && oc < CQ / 2) ? wts.fr[0][oc * CQ + in] : 0.f;
+      afr1[m] = (S == 2 && on && oc >= CQ / 2) ? wts.fr[1][(oc - CQ / 2) * CQ + in] : 0.f;
+    }
+  }
+  const int qC = wave % NQ, itc0 = wave / NQ;
+  const float* wq0 = wq, *wq1 = wq0 + 9 * CQ, *wq2 = wq1 + 25 * CQ, *wq3 = wq2 + 9 * CQ;
+  const int Ho = H / S, Wo = W / S;
+  const int tiles_y = (Ho + TH - 1) / TH, tiles_x = (Wo + TW - 1) / TW;
+  const long ntiles = (long)B * tiles_y * tiles_x;
+  const long P = (long)B * Ho * Wo;
+  for (long tidx = blockIdx.x; tidx < ntiles; tidx += gridDim.x) {
+    const int n = (int)(tidx / (tiles_y * tiles_x));
+    const int tr = (int)(tidx % (tiles_y * tiles_x));
+    const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+    __syncthreads();
+    int tid = threadIdx.x, slot = slotB, ln = lane;
+    asm volatile("" : "+v"(tid), "+v"(slot), "+v"(ln));
+    {   // ---- x1 halo tile (origin (S*ty0 - 4, S*tx0 - 4)) into strided-quad planes ----
+      constexpr int TOT = NPOS * NQ, ROUNDS = (TOT + TPB - 1) / TPB, BATCH = 4;
+      float* tf = (float*)tile;
+#pragma unroll
+      for (int r0 = 0; r0 < ROUNDS; r0 += BATCH) {
+        f32x4 v[BATCH];
+#pragma unroll
+        for (int r = 0; r < BATCH; r++) {
+          const int idx = tid + (r0 + r) * TPB;
+          const int q = idx % NQ, pos = idx / NQ;
+          const int ly = pos / IW, lx = pos - ly * IW;
+          const int y = S * ty0 - 4 + ly, xx = S * tx0 - 4 + lx;
+          v[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (r0 + r < ROUNDS && idx < TOT && y >= 0 && y < H && xx >= 0 && xx < W) v[r] = *(const f32x4*)(x + (((long)n * H + y) * W + xx) * ldx + 4 * q);
+        }
+#pragma unroll
+        for (int r = 0; r < BATCH; r++) {
+          const int idx = tid + (r0 + r) * TPB;
+          if (r0 + r < ROUNDS && idx < TOT) {
+            const int q = idx % NQ, pos = idx / NQ;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const int c = 4 * q + e;                           // channel c -> plane c % NQ, element c / NQ
+              tf[((c % NQ) * NPOS + pos) * 4 + c / NQ] = v[r][e];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- depthwise phase 1: pools (raw x1) and the first stages of sep_conv_3x3 / sep_conv_5x5 ----
+#pragma unroll 1
+    for (int t = 0; t < ITC; t++) {
+      const int p = (itc0 + t * (NW / NQ)) * 64 + ln;
+      const int ly = p / TW, lx = p % TW;
+      const int oy = ty0 + ly, ox = tx0 + lx;
+      const bool live = oy < Ho && ox < Wo;
+      const f32x4* tp = tile + qC * NPOS + (S * ly + 4) * IW + S * lx + 4;   // input pixel (S*oy, S*ox)
+      f32x4 mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sm = {0.f, 0.f, 0.f, 0.f};
+      int cnt = 0;
+#pragma unroll
+      for (int j = -1; j <= 1; j++)
+#pragma unroll
+        for (int i = -1; i <= 1; i++) {
+          const int iy = S * oy + j, ix = S * ox + i;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            const f32x4 v = tp[j * IW + i];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { mx[e] = fmaxf(mx[e], v[e]); sm[e] += v[e]; }
+            cnt++;
+          }
+        }
+      const float inv = 1.f / (float)max(cnt, 1);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        Us[p * CQ + qC + NQ * e] = live ? mx[e] : 0.f;
+        Us[NPX * CQ + p * CQ + qC + NQ * e] = live ? sm[e] * inv : 0.f;     // (the first version leaves sm * inv here too: zero padding sums to 0)
+      }
+      *(f32x4*)(Ds + (p * NQ + qC) * 4) = dw_quad<3, 1, true, NQ>(tp - IW - 1, IW, wq0, qC);
+      *(f32x4*)(Ds + NPX * CQ + (p * NQ + qC) * 4) = dw_quad<5, 1, true, NQ>(tp - 2 * IW - 2, IW, wq1, qC);
+    }
+    __syncthreads();
+    // ---- 1x1 phase 1: FactorizedReduce (stride 2), sep3.a, sep5.a ----
+    f32x4 ukeep[ITP][2];
+#pragma unroll
+    for (int t = 0; t < ITP; t++) {
+      const int pc = (wave + t * NW) * PPW + slot;
+      const int ly = pc / TW, lx = pc % TW;
+      const int oy = ty0 + ly, ox = tx0 + lx;
+      const bool live = oy < Ho && ox < Wo;
+      const long qo = ((long)n * Ho + oy) * Wo + ox;
+      f32x4 u2 = {0.f, 0.f, 0.f, 0.f};
+      if (S == 2) {
+        const f32x4* tp = tile + qB * NPOS + (S * ly + 4) * IW + S * lx + 4;
+        const f32x4 r0 = relu4(tp[0]), r1 = relu4(tp[IW + 1]);
+#pragma unroll
+        for (int m = 0; m < 4; m++) u2 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr0[m], r0[m], u2, 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; m++) u2 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr1[m], r1[m], u2, 0, 0, 0);
+      }
+      const f32x4 d3 = *(const f32x4*)(Ds + (pc * NQ + qB) * 4), d5 = *(const f32x4*)(Ds + NPX * CQ + (pc * NQ + qB) * 4);
+      f32x4 u3 = {0.f, 0.f, 0.f, 0.f}, u4 = u3;
+#pragma unroll
+      for (int m = 0; m < 4; m++) u3 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[0][m], d3[m], u3, 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; m++) u4 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[1][m], d5[m], u4, 0, 0, 0);
+      if (live) {
+        if (S == 2) *(f32x4*)(pre + (2 * P + qo) * CQ + 4 * qB) = u2;
+        *(f32x4*)(pre + (3 * P + qo) * CQ + 4 * qB) = u3;
+        *(f32x4*)(pre + (4 * P + qo) * CQ + 4 * qB) = u4;
+      }
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *(f32x4*)(Us + 2 * NPX * CQ + pc * CQ + 4 * qB) = live ? u2 : z;
+      ukeep[t][0] = live ? u3 : z;
+      ukeep[t][1] = live ? u4 : z;
+    }
+    __syncthreads();
+    // pooled outputs to memory (whole rows), statistics of slots 0..2
+    for (int idx = tid; idx < NPX * NQ; idx += TPB) {
+      const int pc = idx / NQ, q = idx % NQ;
+      const int oy = ty0 + pc / TW, ox = tx0 + pc % TW;
+      if (oy < Ho && ox < Wo) {
+        const long qo = ((long)n * Ho + oy) * Wo + ox;
+        *(f32x4*)(pre + (0 * P + qo) * CQ + 4 * q) = *(const f32x4*)(Us + pc * CQ + 4 * q);
+        *(f32x4*)(pre + (1 * P + qo) * CQ + 4 * q) = *(const f32x4*)(Us + NPX * CQ + pc * CQ + 4 * q);
+      }
+    }
+    stats_from_lds<CQ, NPX, TPB>(Us, 3, seg, acc, 0, 7);
+    __syncthreads();
+    // statistics of slots 3, 4; meanwhile the dilated depthwise outputs (Ds is free: its readers passed the barrier above)
+#pragma unroll
+    for (int t = 0; t < ITP; t++) {
+      const int pc = (wave + t * NW) * PPW + slot;
+      *(f32x4*)(Us + pc * CQ + 4 * qB) = ukeep[t][0];
+      *(f32x4*)(Us + NPX * CQ + pc * CQ + 4 * qB) = ukeep[t][1];
+    }
+#pragma unroll 1
+    for (int t = 0; t < ITC; t++) {
+      const int p = (itc0 + t * (NW / NQ)) * 64 + ln;
+      const int ly = p / TW, lx = p % TW;
+      const f32x4* tp = tile + qC * NPOS + (S * ly + 4) * IW + S * lx + 4;
+      *(f32x4*)(Ds + (p * NQ + qC) * 4) = dw_quad<3, 2, true, NQ>(tp - 2 * IW - 2, IW, wq2, qC);
+      *(f32x4*)(Ds + NPX * CQ + (p * NQ + qC) * 4) = dw_quad<5, 2, true, NQ>(tp - 4 * IW - 4, IW, wq3, qC);
+    }
+    __syncthreads();
+    stats_from_lds<CQ, NPX, TPB>(Us, 2, seg, acc, 3, 7);
+    // ---- 1x1 phase 2: dil3, dil5 (results stay in registers until the statistics above have read Us) ----
+#pragma unroll
+    for (int t = 0; t < ITP; t++) {
+      const int pc = (wave + t * NW) * PPW + slot;
+      const int oy = ty0 + pc / TW, ox = tx0 + pc % TW;
+      const bool live = oy < Ho && ox < Wo;
+      const long qo = ((long)n * Ho + oy) * Wo + ox;
+      const f32x4 d3 = *(const f32x4*)(Ds + (pc * NQ + qB) * 4), d5 = *(const f32x4*)(Ds + NPX * CQ + (pc * NQ + qB) * 4);
+      f32x4 u5 = {0.f, 0.f, 0.f, 0.f}, u6 = u5;
+#pragma unroll
+      for (int m = 0; m < 4; m++) u5 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[2][m], d3[m], u5, 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; m++) u6 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[3][m], d5[m], u6, 0, 0, 0);
+      if (live) {
+        *(f32x4*)(pre + (5 * P + qo) * CQ + 4 * qB) = u5;
+        *(f32x4*)(pre + (6 * P + qo) * CQ + 4 * qB) = u6;
+      }
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      ukeep[t][0] = live ? u5 : z;
+      ukeep[t][1] = live ? u6 : z;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < ITP; t++) {
+      const int pc = (wave + t * NW) * PPW + slot;
+      *(f32x4*)(Us + pc * CQ + 4 * qB) = ukeep[t][0];
+      *(f32x4*)(Us + NPX * CQ + pc * CQ + 4 * qB) = ukeep[t][1];
+    }
+    __syncthreads();
+    stats_from_lds<CQ, NPX, TPB>(Us, 2, seg, acc, 5, 7);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 7 * CQ; i += TPB) {
+    part[((long)blockIdx.x * 7 * CQ + i) * 2 + 0] = acc[i];
+    part[((long)blockIdx.x * 7 * CQ + i) * 2 + 1] = acc[7 * CQ + i];
+  }
+}
+
+template <int CQ, int TH, int TW, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void edge_fwd_b2_kernel(int B, int Ho, int Wo, EdgeW wts, const float* __restrict__ wq,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 float* __restrict__ pre, double* __restrict__ part /* [grid][2*CQ][2] */) {
+  constexpr int TPB = 64 * NW, NPX = TH * TW, NQ = CQ / 4;
+  constexpr int IH = TH + 4, IW = TW + 4, NPOS = IH * IW;
+  constexpr int PPW = 64 / NQ, NITP = NPX / PPW, ITP = NITP / NW, NITC = NPX / 64, ITC = NITC * NQ / NW;
+  static_assert(NW % NQ == 0 && (NITC * NQ) % NW == 0 && NITP % NW == 0 && NPX % 64 == 0 && (TW & (TW - 1)) == 0 && NPX % 8 == 0, "tile / wave split");
+  extern __shared__ __align__(16) unsigned char smem[];
+  f32x4* tile3 = (f32x4*)smem;                                  // [NQ][NPOS] strided quads of relu(bn(t3))
+  f32x4* tile5 = tile3 + NQ * NPOS;
+  float* Ds = (float*)(tile5 + NQ * NPOS);                     // [2][NPX][NQ][4]
+  float* Us = Ds + 2 * NPX * CQ;                               // [2][NPX][CQ]
+  float* ms = Us + 2 * NPX * CQ;                               // mean/invstd of slots 3, 4: [2][2][CQ]
+  float* seg = ms + 4 * CQ;                                    // [2][2*CQ][8]
+  double* acc = (double*)(seg + 2 * 2 * CQ * 8);               // [2][2*CQ]
+  for (int i = threadIdx.x; i < 2 * CQ; i += TPB) {
+    ms[i] = mean[3 * CQ + i];
+    ms[2 * CQ + i] = invstd[3 * CQ + i];
+  }
+  for (int i = threadIdx.x; i < 4 * CQ; i += TPB) acc[i] = 0.0;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n16 = lane & 15, jg = lane >> 4;
+  const int qB = jg % NQ, blkB = jg / NQ, slotB = n16 + 16 * blkB;
+  float aop[2][4];
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int k = 0; k < 2; k++) aop[k][m] = (n16 / CQ == blkB) ? wts.pw[4 + k][(n16 % CQ) * CQ + qB + NQ * m] : 0.f;
+  const int qC = wave % NQ, itc0 = wave / NQ;
+  const float* wq4 = wq + 68 * CQ, *wq5 = wq4 + 9 * CQ;
+  const int tiles_y = (Ho + TH - 1) / TH, tiles_x = (Wo + TW - 1) / TW;
+  const long ntiles = (long)B * tiles_y * tiles_x;
+  const long P = (long)B * Ho * Wo;
+  for (long tidx = blockIdx.x; tidx < ntiles; tidx += gridDim.x) {
+    const int n = (int)(tidx / (tiles_y * tiles_x));
+    const int tr = (int)(tidx % (tiles_y * tiles_x));
+    const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+    __syncthreads();
+    int tid = threadIdx.x, slot = slotB, ln = lane;
+    asm volatile("" : "+v"(tid), "+v"(slot), "+v"(ln));
+    {   // ---- halo tiles of t3 / t4 (origin (ty0 - 2, tx0 - 2)), normalised + ReLU'd on load, into strided-quad planes ----
+      constexpr int TOT = NPOS * NQ, ROUNDS = (TOT + TPB - 1) / TPB;
+#pragma unroll 2
+      for (int r = 0; r < ROUNDS; r++) {
+        const int idx = tid + r * TPB;
+        if (idx < TOT) {
+          const int q = idx % NQ, pos = idx / NQ;
+          const int ly = pos / IW, lx = pos - ly * IW;
+          const int y = ty0 - 2 + ly, xx = tx0 - 2 + lx;
+          const bool ok = y >= 0 && y < Ho && xx >= 0 && xx < Wo;
+          f32x4 v3 = {0.f, 0.f, 0.f, 0.f}, v5 = v3;
+          if (ok) {
+            const long qi = ((long)n * Ho + y) * Wo + xx;
+            v3 = *(const f32x4*)(pre + (3 * P + qi) * CQ + 4 * q);
+            v5 = *(const f32x4*)(pre + (4 * P + qi) * CQ + 4 * q);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int c = 4 * q + e;
+            float a = v3[e], b = v5[e];
+            if (ok) {
+              a = fmaxf((a - ms[c]) * ms[2 * CQ + c], 0.f);
+              b = fmaxf((b - ms[CQ + c]) * ms[3 * CQ + c], 0.f);
+            }
+            ((float*)tile3)[((c % NQ) * NPOS + pos) * 4 + c / NQ] = a;
+            ((float*)tile5)[((c % NQ) * NPOS + pos) * 4 + c / NQ] = b;
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < ITC; t++) {
+      const int p = (itc0 + t * (NW / NQ)) * 64 + ln;
+      const int ly = p / TW, lx = p % TW;
+      *(f32x4*)(Ds + (p * NQ + qC) * 4) = dw_quad<3, 1, false, NQ>(tile3 + qC * NPOS + (ly + 1) * IW + lx + 1, IW, wq4, qC);
+      *(f32x4*)(Ds + NPX * CQ + (p * NQ + qC) * 4) = dw_quad<5, 1, false, NQ>(tile5 + qC * NPOS + ly * IW + lx, IW, wq5, qC);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < ITP; t++) {
+      const int pc = (wave + t * NW) * PPW + slot;
+      const int oy = ty0 + pc / TW, ox = tx0 + pc % TW;
+      const bool live = oy < Ho && ox < Wo;
+      const long qo = ((long)n * Ho + oy) * Wo + ox;
+      const f32x4 d3 = *(const f32x4*)(Ds + (pc * NQ + qB) * 4), d5 = *(const f32x4*)(Ds + NPX * CQ + (pc * NQ + qB) * 4);
+      f32x4 u7 = {0.f, 0.f, 0.f, 0.f}, u8 = u7;
+#pragma unroll
+      for (int m = 0; m < 4; m++) u7 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[0][m], d3[m], u7, 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; m++) u8 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[1][m], d5[m], u8, 0, 0, 0);
+      if (live) {
+        *(f32x4*)(pre + (7 * P + qo) * CQ + 4 * qB) = u7;
+        *(f32x4*)(pre + (8 * P + qo) * CQ + 4 * qB) = u8;
+      }
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *(f32x4*)(Us + pc * CQ + 4 * qB) = live ? u7 : z;
+      *(f32x4*)(Us + NPX * CQ + pc * CQ + 4 * qB) = live ? u8 : z;
+    }
+    __syncthreads();
+    stats_from_lds<CQ, NPX, TPB>(Us, 2, seg, acc, 0, 2);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * CQ; i += TPB) {
+    part[((long)blockIdx.x * 2 * CQ + i) * 2 + 0] = acc[i];
+    part[((long)blockIdx.x * 2 * CQ + i) * 2 + 1] = acc[2 * CQ + i];
   }
 }
 
@@ -1243,7 +1636,6 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
 //            4-byte words, lane = channel), accumulated in 4 registers per lane over all tiles.
 // LDS bytes read per tile: about a third of the first version's; three barriers per tile instead of four.
 // ------------------------------------------------------------------------------------------------------------------
-typedef const __attribute__((address_space(4))) f32x4* const_f32x4_ptr;   // constant address space: uniform loads become s_load
 
 template <int CQ, int K, int DIL, int S, int MODE, int TH, int TW, int NW, int WPE>
 __global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_kernel(const float* __restrict__ in, long ldin, const float* __restrict__ gsrc /* dY or dBN */,
@@ -1842,6 +2234,19 @@ size_t bwd_conv2_pair_lds() {
 }
 
 template <int CQ, int S, int TH, int TW>
+size_t fwd_a2_lds() {
+  constexpr int NPX = TH * TW, NQ = CQ / 4, IH = S * (TH - 1) + 9, IW = S * (TW - 1) + 9;
+  size_t floats = (size_t)NQ * IH * IW * 4 + 5 * NPX * CQ + 2 * 3 * CQ * 8;
+  return floats * 4 + 2 * 7 * CQ * 8 + 16;
+}
+template <int CQ, int TH, int TW>
+size_t fwd_b2_lds() {
+  constexpr int NPX = TH * TW, NQ = CQ / 4, IH = TH + 4, IW = TW + 4;
+  size_t floats = (size_t)2 * NQ * IH * IW * 4 + 4 * NPX * CQ + 4 * CQ + 2 * 2 * CQ * 8;
+  return floats * 4 + 4 * CQ * 8 + 16;
+}
+
+template <int CQ, int S, int TH, int TW>
 size_t fwd_a_lds() {
   constexpr int TPB = TH * TW, NQ = CQ / 4, IH = S * (TH - 1) + 9, IW = S * (TW - 1) + 9;
   size_t floats = (size_t)NQ * IH * IW * 4 + CQ * 68 + 4 * CQ * CQ + CQ * CQ + 12 * (TPB + 1) + 2 * 12 * 8;
@@ -1954,8 +2359,39 @@ int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride
     grid = tile_grid((const void*)edge_fwd_b_kernel<CQv, THv, TWv>, THv * TWv, lds, TILES(THv, TWv), rows);               \
     hipLaunchKernelGGL((edge_fwd_b_kernel<CQv, THv, TWv>), dim3(grid), dim3(THv * TWv), lds, st, B, Ho, Wo, ew, mean, invstd, pre, part); \
   }
+  // Cq = 8, 16: the matrix-core / scalar-weight form (bit-identical results); Cq = 4 moves bytes at the HBM roof in the first form
+  float* wq = (float*)(part + (long)rows * 7 * CQ * 2);         // strided-quad tap-major depthwise weights (edge_fwd_prep_kernel)
+#define EDGE_A2(CQv, Sv, THv, TWv, NWv)                                                                                    \
+  {                                                                                                                        \
+    const size_t lds = fwd_a2_lds<CQv, Sv, THv, TWv>();                                                                    \
+    grid = tile_grid((const void*)edge_fwd_a2_kernel<CQv, Sv, THv, TWv, NWv>, 64 * NWv, lds, TILES(THv, TWv), rows);      \
+    hipLaunchKernelGGL((edge_fwd_a2_kernel<CQv, Sv, THv, TWv, NWv>), dim3(grid), dim3(64 * NWv), lds, st, x1d ? x1d : x, (long)(x1d ? CQv : C), B, H, W, ew, wq, pre, part); \
+  }
+#define EDGE_B2(CQv, THv, TWv, NWv)                                                                                        \
+  {                                                                                                                        \
+    const size_t lds = fwd_b2_lds<CQv, THv, TWv>();                                                                        \
+    grid = tile_grid((const void*)edge_fwd_b2_kernel<CQv, THv, TWv, NWv>, 64 * NWv, lds, TILES(THv, TWv), rows);          \
+    hipLaunchKernelGGL((edge_fwd_b2_kernel<CQv, THv, TWv, NWv>), dim3(grid), dim3(64 * NWv), lds, st, B, Ho, Wo, ew, wq, mean, invstd, pre, part); \
+  }
+  // measured (tools/ab_edge.py, B=64): the stride-2 edges gain 14 % / 28 % of their forward (Cq = 8 / 16); at stride 1 the first form's
+  // two or three workgroups per CU hide its barriers better than the new form's one (-DEDGE_FWD2_S1 runs it there on half tiles)
+#ifdef EDGE_FWD_V1
+  const bool v2 = false;
+#elif defined(EDGE_FWD2_S1)
+  const bool v2 = CQ >= 8;
+#else
+  const bool v2 = CQ >= 8 && stride == 2;
+#endif
+  if (v2) {
+    hipLaunchKernelGGL(edge_fwd_prep_kernel, dim3(1), dim3(256), 0, st, ew, CQ, wq);
+    if ((rc = lct_check_launch("edge_fwd_prep"))) return rc;
+  }
   if (CQ == 4 && stride == 1) EDGE_A(4, 1, 8, 32)
   else if (CQ == 4) EDGE_A(4, 2, 8, 32)
+  else if (v2 && CQ == 8 && stride == 1) EDGE_A2(8, 1, 8, 32, 4)
+  else if (v2 && CQ == 8) EDGE_A2(8, 2, 8, 32, 8)
+  else if (v2 && stride == 1) EDGE_A2(16, 1, 8, 16, 4)
+  else if (v2) EDGE_A2(16, 2, 8, 16, 8)
   else if (CQ == 8 && stride == 1) EDGE_A(8, 1, 8, 32)
   else if (CQ == 8) EDGE_A(8, 2, 8, 32)
   else if (stride == 1) EDGE_A(16, 1, 8, 32)
@@ -1966,6 +2402,10 @@ int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride
   if ((rc = lct_check_launch("edge_stats_finish(a)"))) return rc;
   const bool narrow = (stride == 2 && CQ == 16);
   if (CQ == 4) EDGE_B(4, 8, 32)
+  else if (v2 && CQ == 8 && stride == 1) EDGE_B2(8, 8, 32, 4)
+  else if (v2 && CQ == 8) EDGE_B2(8, 8, 32, 8)
+  else if (v2 && !narrow) EDGE_B2(16, 8, 16, 4)
+  else if (v2) EDGE_B2(16, 8, 16, 8)
   else if (CQ == 8) EDGE_B(8, 8, 32)
   else if (!narrow) EDGE_B(16, 8, 32)
   else EDGE_B(16, 8, 16)
@@ -1982,6 +2422,8 @@ int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride
   return lct_check_launch("edge_fwd_c");
 #undef EDGE_A
 #undef EDGE_B
+#undef EDGE_A2
+#undef EDGE_B2
 #undef TILES
 }
 

@@ -450,7 +450,7 @@ class MixedEdgeFn(torch.autograd.Function):
         pre = torch.empty((9, P, Cq), dtype=torch.float32, device=dev)
         stats = torch.empty((2, 9, Cq), dtype=torch.float32, device=dev)          # mean, invstd per slot
         grid = lib.query('mixed_edge_grid', B, H, W, C, stride)
-        part = _scratch(grid * 7 * Cq * 2, torch.float64, dev)
+        part = _scratch(grid * 7 * Cq * 2 + 51 * Cq, torch.float64, dev)      # + the forward kernels' regrouped depthwise weights
         wptr = (ctypes.c_void_p * 14)(*([w.data_ptr() for w in weights] + [None] * (14 - len(weights))))
         bnp = [None] * 27
         momentum, eps = 0.1, 1e-5

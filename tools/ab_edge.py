@@ -39,7 +39,7 @@ def main():
         pre = torch.empty(9, Pn, Cq, device=dev)
         stats = torch.empty(2, 9, Cq, device=dev)
         grid = max(d.lctvqa_mixed_edge_grid(B, H, H, C, s) for d in dlls)
-        part = torch.empty(grid * 7 * Cq * 2, dtype=torch.float64, device=dev)
+        part = torch.empty(grid * 7 * Cq * 2 + 51 * Cq, dtype=torch.float64, device=dev)
         wsel = torch.softmax(torch.randn(7, device=dev), 0)
         beta = torch.ones(1, device=dev)
         out = torch.empty(B, Ho, Ho, C, device=dev)
