@@ -1304,41 +1304,105 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_pools_kernel(const float* __
     store_row<CQ>(Xs + threadIdx.x * CQ, dxv);                   // the x1 chunks go through LDS
     __syncthreads();
     constexpr int NCH = 4 * NQ;                                  // chunks of a row: NQ of x1, then the bypass groups g = 1..3
-    for (int it = threadIdx.x; it < TPB * NCH; it += TPB) {
-      const int pix = it / NCH, ch = it % NCH;
-      const int g = ch / NQ, q4 = ch % NQ;
-      const int py = pix / TW, px = pix % TW;
-      const int jy = ty0 + py, jx = tx0 + px;
-      if (jy >= H || jx >= W) continue;
-      float* dp = dx + (((long)n * H + jy) * W + jx) * C + g * CQ + 4 * q4;
-      f32x4 v;
-      if (g == 0) {
-        v = *(const f32x4*)(Xs + pix * CQ + 4 * q4);
-      } else {
-        // bypass channel g*Cq + i <- beta * dOut[q][4i + g]
-        const long q = ((long)n * Ho + jy / S) * Wo + jx / S;
-        f32x4 D[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) D[e] = *(const f32x4*)(dout + q * ldd + 16 * q4 + 4 * e);
-#pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = (g == 1 ? D[e][1] : g == 2 ? D[e][2] : D[e][3]) * bt;
-        if (S == 2) {
-          const float* xr = x + (((long)n * H + (jy & ~1)) * W + (jx & ~1)) * C + g * CQ + 4 * q4;   // top-left of the 2x2 window
-          const int me = (jy & 1) * 2 + (jx & 1);
-          const f32x4 va = *(const f32x4*)xr, vb = *(const f32x4*)(xr + C);
-          const f32x4 vc = *(const f32x4*)(xr + (long)W * C), vd = *(const f32x4*)(xr + (long)W * C + C);
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            int best = 0; float bv = va[e];                     // first maximum in scan order, like MaxPool2d(2, 2)
-            if (vb[e] > bv) { bv = vb[e]; best = 1; }
-            if (vc[e] > bv) { bv = vc[e]; best = 2; }
-            if (vd[e] > bv) { bv = vd[e]; best = 3; }
-            if (best != me) v[e] = 0.f;
+    if constexpr (S == 1) {
+      // U items per thread at a time, every load of the batch requested before the first use (one item per iteration exposed a memory
+      // round trip per iteration: 16 per tile at Cq = 16, most of the kernel's time)
+      constexpr int UMAX = 8, U = NCH < UMAX ? NCH : UMAX;
+      for (int it0 = threadIdx.x; it0 < TPB * NCH; it0 += U * TPB) {
+        float dsc[U][4];
+        f32x4 xw[S == 2 ? U : 1][4], old[U];
+        bool ok[U];
+  #pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int it = it0 + u * TPB;
+          const int pix = it / NCH, ch = it % NCH;
+          const int g = ch / NQ, q4 = ch % NQ;
+          const int jy = ty0 + pix / TW, jx = tx0 + pix % TW;
+          ok[u] = it < TPB * NCH && jy < H && jx < W;
+          old[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+          for (int e = 0; e < 4; e++) dsc[u][e] = 0.f;
+          if (ok[u]) {
+            if (acc_dx) old[u] = *(const f32x4*)(dx + (((long)n * H + jy) * W + jx) * C + g * CQ + 4 * q4);
+            if (g > 0) {
+              const long q = ((long)n * Ho + jy / S) * Wo + jx / S;
+  #pragma unroll
+              for (int e = 0; e < 4; e++) dsc[u][e] = dout[q * ldd + 16 * q4 + 4 * e + g];     // bypass channel g*Cq + i <- beta * dOut[q][4i + g]
+              if (S == 2) {
+                const float* xr = x + (((long)n * H + (jy & ~1)) * W + (jx & ~1)) * C + g * CQ + 4 * q4;   // top-left of the 2x2 window
+                xw[S == 2 ? u : 0][0] = *(const f32x4*)xr; xw[S == 2 ? u : 0][1] = *(const f32x4*)(xr + C);
+                xw[S == 2 ? u : 0][2] = *(const f32x4*)(xr + (long)W * C); xw[S == 2 ? u : 0][3] = *(const f32x4*)(xr + (long)W * C + C);
+              }
+            }
           }
         }
+  #pragma unroll
+        for (int u = 0; u < U; u++) {
+          if (!ok[u]) continue;
+          const int it = it0 + u * TPB;
+          const int pix = it / NCH, ch = it % NCH;
+          const int g = ch / NQ, q4 = ch % NQ;
+          const int jy = ty0 + pix / TW, jx = tx0 + pix % TW;
+          f32x4 v;
+          if (g == 0) {
+            v = *(const f32x4*)(Xs + pix * CQ + 4 * q4);
+          } else {
+  #pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = dsc[u][e] * bt;
+            if (S == 2) {
+              const int me = (jy & 1) * 2 + (jx & 1);
+              const f32x4 va = xw[S == 2 ? u : 0][0], vb = xw[S == 2 ? u : 0][1], vc = xw[S == 2 ? u : 0][2], vd = xw[S == 2 ? u : 0][3];
+  #pragma unroll
+              for (int e = 0; e < 4; e++) {
+                int best = 0; float bv = va[e];                   // first maximum in scan order, like MaxPool2d(2, 2)
+                if (vb[e] > bv) { bv = vb[e]; best = 1; }
+                if (vc[e] > bv) { bv = vc[e]; best = 2; }
+                if (vd[e] > bv) { bv = vd[e]; best = 3; }
+                if (best != me) v[e] = 0.f;
+              }
+            }
+          }
+          if (acc_dx) v += old[u];
+          *(f32x4*)(dx + (((long)n * H + jy) * W + jx) * C + g * CQ + 4 * q4) = v;
+        }
       }
-      if (acc_dx) v += *(const f32x4*)dp;
-      *(f32x4*)dp = v;
+    } else {   // stride 2: one item per iteration (the batched form lost 10 % there: registers)
+      for (int it = threadIdx.x; it < TPB * NCH; it += TPB) {
+        const int pix = it / NCH, ch = it % NCH;
+        const int g = ch / NQ, q4 = ch % NQ;
+        const int py = pix / TW, px = pix % TW;
+        const int jy = ty0 + py, jx = tx0 + px;
+        if (jy >= H || jx >= W) continue;
+        float* dp = dx + (((long)n * H + jy) * W + jx) * C + g * CQ + 4 * q4;
+        f32x4 v;
+        if (g == 0) {
+          v = *(const f32x4*)(Xs + pix * CQ + 4 * q4);
+        } else {
+          // bypass channel g*Cq + i <- beta * dOut[q][4i + g]
+          const long q = ((long)n * Ho + jy / S) * Wo + jx / S;
+          f32x4 D[4];
+  #pragma unroll
+          for (int e = 0; e < 4; e++) D[e] = *(const f32x4*)(dout + q * ldd + 16 * q4 + 4 * e);
+  #pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = (g == 1 ? D[e][1] : g == 2 ? D[e][2] : D[e][3]) * bt;
+          if (S == 2) {
+            const float* xr = x + (((long)n * H + (jy & ~1)) * W + (jx & ~1)) * C + g * CQ + 4 * q4;   // top-left of the 2x2 window
+            const int me = (jy & 1) * 2 + (jx & 1);
+            const f32x4 va = *(const f32x4*)xr, vb = *(const f32x4*)(xr + C);
+            const f32x4 vc = *(const f32x4*)(xr + (long)W * C), vd = *(const f32x4*)(xr + (long)W * C + C);
+  #pragma unroll
+            for (int e = 0; e < 4; e++) {
+              int best = 0; float bv = va[e];                     // first maximum in scan order, like MaxPool2d(2, 2)
+              if (vb[e] > bv) { bv = vb[e]; best = 1; }
+              if (vc[e] > bv) { bv = vc[e]; best = 2; }
+              if (vd[e] > bv) { bv = vd[e]; best = 3; }
+              if (best != me) v[e] = 0.f;
+            }
+          }
+        }
+        if (acc_dx) v += *(const f32x4*)dp;
+        *(f32x4*)dp = v;
+      }
     }
   }
   if (S == 2 && threadIdx.x < CQ * CQ) wpart[(long)blockIdx.x * wtot + fr_off + threadIdx.x] = acc_fr;
