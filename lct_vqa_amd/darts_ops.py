@@ -90,6 +90,12 @@ class DwConvFn(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+# Cout * Cin from which a 1x1 convolution (forward and input gradient) goes to the MFMA GEMM instead of the thread-per-pixel kernel: the
+# preprocess layers' 64 -> 32 / 128 -> 64 products are LDS-bound there (every weight a broadcast read); encoder forward+backward at B=64
+# 73.0 -> 71.2 ms, at B=16 25.2 -> 24.9 ms (tools/bench_darts.py with LCTVQA_PW_GEMM_FROM = 2^30 / 1024)
+_PW_GEMM_FROM = int(os.environ.get('LCTVQA_PW_GEMM_FROM', 1024))
+
+
 class PwConvFn(torch.autograd.Function):
     """(ReLU ->) 1x1 conv, no bias (operations.py:28,42,57,61) as a strided GEMM over pixels."""
 
@@ -99,7 +105,7 @@ class PwConvFn(torch.autograd.Function):
         B, H, W, Cin = x.shape
         Cout = w.shape[0]
         P = B * H * W
-        if lib.query('pwconv_small_supported', P, Cout, Cin):
+        if lib.query('pwconv_small_supported', P, Cout, Cin) and Cout * Cin < _PW_GEMM_FROM:
             y = torch.empty((P, Cout), dtype=torch.float32, device=x.device)
             lib('pwconv_small', x, w, None, y, P, Cout, Cin, int(bool(relu_in)), 0)
         else:
@@ -117,7 +123,7 @@ class PwConvFn(torch.autograd.Function):
         P = B * H * W
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            if lib.query('pwconv_small_supported', P, Cout, Cin):
+            if lib.query('pwconv_small_supported', P, Cout, Cin) and Cout * Cin < _PW_GEMM_FROM:
                 dx = torch.empty((P, Cin), dtype=torch.float32, device=x.device)
                 lib('pwconv_small', dy, w, x if ctx.relu_in else None, dx, P, Cout, Cin, 0, 1)    # dY . W, * (x > 0) fused
             else:
