@@ -26,7 +26,6 @@ def main():
     B = args.batch
     st = lambda: P_(torch.cuda.current_stream().cuda_stream)
     tot = [[0.0, 0.0] for _ in dlls]
-    old = [os.path.basename(p).startswith(('edge_v1', 'edge_c1', 'edge_c3')) for p in args.libs]   # builds from before the x1d arguments
     for (C, s, H) in SHAPES:
         Cq, Ho = C // 4, H // s
         Pn = B * Ho * Ho
@@ -56,13 +55,13 @@ def main():
                 for _ in range(3):
                     rc = d.lctvqa_mixed_edge_fwd(P_(x.data_ptr()), B, H, H, C, s, wptr, bn, P_(pre.data_ptr()), P_(stats[0].data_ptr()), P_(stats[1].data_ptr()),
                                                  P_(part.data_ptr()), P_(wsel.data_ptr()), P_(beta.data_ptr()), P_(out.data_ptr()), ctypes.c_long(C), 0, 1,
-                                                 ctypes.c_float(0.1), ctypes.c_float(1e-5), *(() if old[i] else (None,)), st())
+                                                 ctypes.c_float(0.1), ctypes.c_float(1e-5), None, st())
                     assert rc == 0
                 ev[1].record()
                 for _ in range(3):
                     rc = d.lctvqa_mixed_edge_bwd(P_(dout.data_ptr()), ctypes.c_long(C), P_(x.data_ptr()), B, H, H, C, s, wptr, P_(pre.data_ptr()),
                                                  P_(stats[0].data_ptr()), P_(stats[1].data_ptr()), P_(wsel.data_ptr()), P_(beta.data_ptr()), P_(dx.data_ptr()),
-                                                 P_(dw.data_ptr()), P_(dbeta.data_ptr()), P_(wgrad.data_ptr()), P_(scratch.data_ptr()), 1, *(() if os.path.basename(args.libs[i]).startswith(('edge_v1', 'edge_c1')) else ((0,) if old[i] else (0, None))), st())
+                                                 P_(dw.data_ptr()), P_(dbeta.data_ptr()), P_(wgrad.data_ptr()), P_(scratch.data_ptr()), 1, 0, None, st())
                     assert rc == 0
                 ev[2].record()
                 torch.cuda.synchronize()
