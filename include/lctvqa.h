@@ -350,7 +350,9 @@ int lctvqa_conv7x7_s2_stem_bf16_mfma(const float* x_nchw, const float* w_oihw, c
  * wsel [7] = softmax(alpha) of the live primitives, beta [1].  Backward: dx [B,H,W,C] (written, or added to with accumulate_dx = 1:
  * the one gradient buffer of a state that several edges read), dwsel [7], dbeta [1], wgrad = flat weight gradients in the order of w.
  * x1d (both directions, may be NULL): a dense copy [B,H,W,C/4] of x[..., :C/4] (lctvqa_slice_channels), worth making once for a state
- * that several edges read -- the kernels otherwise read a 16..64-byte slice of every NHWC row of x. */
+ * that several edges read -- the kernels otherwise read a 16..64-byte slice of every NHWC row of x.
+ * need_wgrad = 0: dx, dwsel, dbeta only -- the conv stages skip their weight-gradient work and wgrad is not written (the finite-difference
+ * passes of the architects, architect_vqa.py:75-88, differentiate w.r.t. alpha / beta only). */
 int lctvqa_mixed_edge_supported(int B, int H, int W, int C, int stride);
 int lctvqa_mixed_edge_grid(int B, int H, int W, int C, int stride);
 int lctvqa_mixed_edge_wgrad_elems(int C);
@@ -361,7 +363,7 @@ int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride
 int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, int H, int W, int C, int stride, const void* const* w,
                           const float* pre, const float* mean, const float* invstd, const float* wsel, const float* beta, float* dx,
                           float* dwsel, float* dbeta, float* wgrad, float* scratch, int training, int accumulate_dx, const float* x1d,
-                          void* stream);
+                          int need_wgrad, void* stream);
 
 /* ---- input pipeline, device side (data_loader_v2.py:53-55,82-86: ToTensor + Normalize done per sample on the host):
  *      uint8 HWC rows of the image store -> fp32 NCHW, y = (x/255 - mean[c]) / std[c] ---------------------------- */

@@ -43,7 +43,7 @@ class Architect(object):
         g = bilevel.grads(ahead._loss(img_valid, qst_valid, label_valid), ahead_alphas + ahead_weights)
         dalpha, v = g[:len(ahead_alphas)], g[len(ahead_alphas):]
         implicit = bilevel.fd_grad(weights, v, lambda: bilevel.grads(model._loss(img_train, qst_train, label_train),
-                                                                    model.arch_parameters()))
+                                                                    model.arch_parameters(), weight_grads=False))
         if self.trace is not None:
             self.trace.update(dalpha_direct=dalpha, v=v, implicit=implicit)
         return [d - eta * i for d, i in zip(dalpha, implicit)]

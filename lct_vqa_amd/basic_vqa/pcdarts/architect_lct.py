@@ -70,7 +70,7 @@ class ArchitectLct(object):
 
         kappa = bilevel.fd_grad(w_weights, v, soft_loss_grad_wrt_examiner)
         gamma = bilevel.fd_grad(ef_weights, kappa,
-                                lambda: bilevel.grads(ef._loss(img_train, qst_train, label_train), ef.arch_parameters(), 0))
+                                lambda: bilevel.grads(ef._loss(img_train, qst_train, label_train), ef.arch_parameters(), 0, weight_grads=False))
         if self.trace is not None:
             self.trace.update(kappa=kappa, gamma=gamma)
         return gamma, val_loss

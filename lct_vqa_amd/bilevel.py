@@ -56,12 +56,18 @@ def _average_over_ranks(tensors):
     return out
 
 
-def grads(loss, tensors, expect_unused=None):
+def grads(loss, tensors, expect_unused=None, weight_grads=True):
     """Gradients of ``loss`` w.r.t. ``tensors`` as a list; tensors the graph does not reach get zeros.  When
     ``expect_unused`` is given, the number of unreached tensors must equal it (the reference asserts these counts).
-    Averaged over the ranks when ``data_parallel`` is on."""
+    Averaged over the ranks when ``data_parallel`` is on.  ``weight_grads=False``: ``tensors`` holds architecture parameters only, the
+    PC-DARTS ops skip their convolution-weight gradients in this backward pass (darts_ops.weight_grads)."""
     tensors = list(tensors)
-    got = torch.autograd.grad(loss, tensors, allow_unused=True)
+    if weight_grads:
+        got = torch.autograd.grad(loss, tensors, allow_unused=True)
+    else:
+        from . import darts_ops
+        with darts_ops.weight_grads(False):
+            got = torch.autograd.grad(loss, tensors, allow_unused=True)
     unused = sum(g is None for g in got)
     if expect_unused is not None and unused != expect_unused:
         raise AssertionError(f'{unused} tensors received no gradient, expected {expect_unused}')

@@ -1710,7 +1710,8 @@ __global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_kernel(const floa
                                                                  const float* __restrict__ w_pw, int B, int H, int W,
                                                                  float* __restrict__ dst /* dx1c [B,H,W,CQ] (MODE 0, 2) or dBN [P][CQ] (MODE 1) */,
                                                                  int accumulate, double* __restrict__ spart /* MODE 1: [grid][2*CQ][2] */,
-                                                                 float* __restrict__ wpart, int wtot, int dw_off, int pw_off) {
+                                                                 float* __restrict__ wpart, int wtot, int dw_off, int pw_off,
+                                                                 int need_w /* 0: input gradient only (no weight-gradient work, wpart untouched) */) {
   constexpr int TPB = 64 * NW, NPX = TH * TW, NQ = CQ / 4, KK = K * K, PAD = DIL * (K - 1) / 2, HB = (PAD + S - 1) / S;
   constexpr int IH = S * (TH - 1) + 2 * PAD + 1, IW = S * (TW - 1) + 2 * PAD + 1, IN = IH * IW;
   constexpr int DH = TH + 2 * HB, DW = TW + 2 * HB, DN = DH * DW;
@@ -1891,7 +1892,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_kernel(const floa
     // depthwise weight gradient: every wave walks ALL items of the tile for its quad with its own NT taps (K*K accumulators per lane
     // cost K = 5 its occupancy: 256 registers and spills; split over the RK waves of the quad they are 28 / 52 registers)
 #pragma unroll 1
-    for (int it = 0; it < NITC; it++) {
+    for (int it = 0; it < (need_w ? NITC : 0); it++) {
       const int p = it * 64 + ln;
       const int ly = p / TW, lx = p % TW;
       const f32x4* rp = rt + qC * IN + (S * ly) * IW + S * lx;
@@ -1906,14 +1907,17 @@ __global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_kernel(const floa
 #endif
     __syncthreads();
     // ---- phase D ----
+    if (need_w) {
 #pragma unroll
-    for (int m = 0; m < MPW; m++) {
-      const int pix = (wave * MPW + m) * (4 * NBK) + 4 * (n16 / CQ) + jg;
-      accp = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[pix * CQ + n16 % CQ], Ds[pix * CQ + n16 % CQ], accp, 0, 0, 0);
+      for (int m = 0; m < MPW; m++) {
+        const int pix = (wave * MPW + m) * (4 * NBK) + 4 * (n16 / CQ) + jg;
+        accp = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[pix * CQ + n16 % CQ], Ds[pix * CQ + n16 % CQ], accp, 0, 0, 0);
+      }
     }
   }
   // ---- per-workgroup partial weight gradients (fixed order) ----
   __syncthreads();
+  if (!need_w && MODE != 1) return;
   float* wrow = wpart + (long)blockIdx.x * wtot;
   float* fin = (float*)smem;                                    // [NW][16][NT*4] then [NW][16][16] then [NW][8]
   float* fin2 = fin + NW * 16 * NT * 4;
@@ -1935,14 +1939,14 @@ __global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_kernel(const floa
     }
   }
   __syncthreads();
-  for (int ent = threadIdx.x; ent < CQ * KK; ent += TPB) {
+  for (int ent = threadIdx.x; ent < (need_w ? CQ * KK : 0); ent += TPB) {
     const int c = ent / KK, tap = ent % KK;
     const int w = c / 4 + NQ * (tap % RK), t = tap / RK;           // the one wave that owns (quad, tap)
     float a = 0.f;
     for (int l = 0; l < 16; l++) a += fin[((w * 16 + l) * NT + t) * 4 + c % 4];
     wrow[dw_off + ent] = a;
   }
-  for (int ent = threadIdx.x; ent < CQ * CQ; ent += TPB) {
+  for (int ent = threadIdx.x; ent < (need_w ? CQ * CQ : 0); ent += TPB) {
     const int oc = ent / CQ, c = ent % CQ;
     float a = 0.f;
     for (int w = 0; w < NW; w++)
@@ -1977,7 +1981,8 @@ struct StageArgs {
 
 template <int CQ, int DIL, int S, int MODE, int TH, int TW, int NW, int WPE>
 __global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_pair_kernel(const float* __restrict__ in, long ldin, StageArgs sa, StageArgs sb, int B, int H, int W,
-                                                                      float* __restrict__ dst, int accumulate, float* __restrict__ wpart, int wtot) {
+                                                                      float* __restrict__ dst, int accumulate, float* __restrict__ wpart, int wtot,
+                                                                      int need_w) {
   static_assert(MODE == 0 || MODE == 2, "stages that read x1");
   constexpr int TPB = 64 * NW, NPX = TH * TW, NQ = CQ / 4;
   constexpr int PAD = 2 * DIL;                                   // the 5x5 stage's reach: the shared input tile
@@ -2166,7 +2171,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_pair_kernel(const
     }
     // depthwise weight gradients of both stages: every wave walks all items for its quad with its own taps
 #pragma unroll 1
-    for (int it = 0; it < NITC; it++) {
+    for (int it = 0; it < (need_w ? NITC : 0); it++) {
       const int p = it * 64 + ln;
       const int ly = p / TW, lx = p % TW;
       const f32x4* rp = rt + qC * IN + (S * ly) * IW + S * lx;
@@ -2186,15 +2191,18 @@ __global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_pair_kernel(const
     }
     __syncthreads();
     // ---- phase D ----
+    if (need_w) {
 #pragma unroll
-    for (int m = 0; m < MPW; m++) {
-      const int pix = (wave * MPW + m) * (4 * NBK) + 4 * (n16 / CQ) + jg;
-      accp0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs0[pix * CQ + n16 % CQ], Ds0[pix * CQ + n16 % CQ], accp0, 0, 0, 0);
-      accp1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs1[pix * CQ + n16 % CQ], Ds1[pix * CQ + n16 % CQ], accp1, 0, 0, 0);
+      for (int m = 0; m < MPW; m++) {
+        const int pix = (wave * MPW + m) * (4 * NBK) + 4 * (n16 / CQ) + jg;
+        accp0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs0[pix * CQ + n16 % CQ], Ds0[pix * CQ + n16 % CQ], accp0, 0, 0, 0);
+        accp1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs1[pix * CQ + n16 % CQ], Ds1[pix * CQ + n16 % CQ], accp1, 0, 0, 0);
+      }
     }
   }
   // ---- per-workgroup partial weight gradients (fixed order) ----
   __syncthreads();
+  if (!need_w) return;
   float* wrow = wpart + (long)blockIdx.x * wtot;
   float* fin0 = (float*)smem;                                   // [NW][16][NT0*4], [NW][16][NT1*4], 2 x [NW][16][16]
   float* fin1 = fin0 + NW * 16 * NT0 * 4;
@@ -2498,7 +2506,7 @@ int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride
 int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, int H, int W, int C, int stride, const void* const* w,
                           const float* pre, const float* mean, const float* invstd, const float* wsel, const float* beta, float* dx,
                           float* dwsel, float* dbeta, float* wgrad, float* scratch, int training, int accumulate_dx, const float* x1d_in,
-                          void* stream) {
+                          int need_wgrad, void* stream) {
   LCT_REQUIRE(lctvqa_mixed_edge_supported(B, H, W, C, stride), "mixed_edge_bwd: unsupported shape B=%d H=%d W=%d C=%d s=%d", B, H, W, C, stride);
   LCT_REQUIRE((((uintptr_t)dout | (uintptr_t)x | (uintptr_t)pre | (uintptr_t)dx | (uintptr_t)scratch | (uintptr_t)wgrad) & 15) == 0 && (ldd & 3) == 0,
               "mixed_edge_bwd: tensors must be 16-B aligned");
@@ -2566,7 +2574,7 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
     hipLaunchKernelGGL((edge_bwd_conv2_kernel<CQv, Kv, DILv, Sv, MODEv, THv, TWv, NWv, EDGE_WPE(CQv, Kv)>), dim3(grid), dim3(64 * NWv), lds, st, inp, (long)(ldv), gs, \
                        pre + (long)(slot) * P * CQ, mean + (slot) * CQ, invstd + (slot) * CQ, coef + (slot) * COEF,       \
                        mean + ((slot) - 4) * CQ, invstd + ((slot) - 4) * CQ, wtaps + dw_off[ci], ew.pw[ci], B, Hv, Wv, dstp, accv, spp, wpart, wtot, \
-                       dw_off[ci], pw_off[ci]);                                                                            \
+                       dw_off[ci], pw_off[ci], need_wgrad);                                                                \
   }
 #else
 #define CONV(CQv, Kv, DILv, Sv, MODEv, THv, TWv, ci, slot, inp, ldv, Hv, Wv, gs, dstp, accv, spp)                           \
@@ -2592,7 +2600,7 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
                      TILES(H / Sv, W / Sv, THv, TWv), G);                                                                  \
     rows.n[c0] = grid; rows.n[c1] = grid;                                                                                  \
     hipLaunchKernelGGL((edge_bwd_conv2_pair_kernel<CQv, DILv, Sv, MODEv, THv, TWv, NWv, 2>), dim3(grid), dim3(64 * NWv), lds, st, x1d, (long)CQv, \
-                       STAGE_ARGS(c0, s0, gs0), STAGE_ARGS(c1, s1, gs1), B, H, W, dx1c, accv, wpart, wtot);                \
+                       STAGE_ARGS(c0, s0, gs0), STAGE_ARGS(c1, s1, gs1), B, H, W, dx1c, accv, wpart, wtot, need_wgrad);    \
   }
 #define DIL_SINGLES(CQv, Sv, THv, TWv)                                                                                     \
     CONV(CQv, 3, 2, Sv, 0, THv, TWv, 2, 5, x1d, CQv, H, W, dY, dx1c, 0, (double*)nullptr)                                  \
@@ -2659,6 +2667,7 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
   else if (CQ == 8) STAGES(8, 2, 8, 32)
   else if (stride == 1) STAGES(16, 1, 8, 32)
   else STAGES(16, 2, 8, 16)
+  if (!need_wgrad) return LCT_OK;                              // (the architects' finite-difference passes: gradients of alpha / beta only)
   const int ncols = stride == 2 ? wtot : fr_off;               // stride-1 edges have no FactorizedReduce
   hipLaunchKernelGGL(edge_wgrad_finish_kernel, dim3(ncols), dim3(64), 0, st, wpart, rows, wtot, CQ, wgrad);
   return lct_check_launch("edge_wgrad_finish");

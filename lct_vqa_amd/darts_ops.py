@@ -2,6 +2,7 @@
 [B,H,W,C], plus ``run_seq`` which executes a reference-shaped ``nn.Sequential`` of standard torch
 modules (ReLU / Conv2d / BatchNorm2d / AvgPool2d / MaxPool2d used purely as parameter+buffer holders,
 so state_dict keys equal the reference's) through those Functions."""
+import contextlib
 import ctypes
 import os
 
@@ -133,7 +134,7 @@ class PwConvFn(torch.autograd.Function):
                     lib('act_bwd', dx, x, None, 1.0, out, dx.numel(), 1)      # * (x > 0)
                     dx = out
             dx = dx.reshape(B, H, W, Cin)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and _WEIGHT_GRADS:
             if lib.query('pwconv_wgrad_small_supported', P, Cout, Cin):
                 dw = torch.empty_like(w)
                 scratch = _scratch(lib.query('pwconv_wgrad_small_scratch_elems', P, Cout, Cin), torch.float32, x.device)
@@ -376,6 +377,22 @@ class EdgeWeightsFn(torch.autograd.Function):
         return gw, torch.cat(gbs), None, None
 
 
+_WEIGHT_GRADS = True
+
+
+@contextlib.contextmanager
+def weight_grads(on):
+    """Inside ``weight_grads(False)`` the backward passes of the PC-DARTS ops compute input / alpha / beta gradients only and return None
+    for their convolution weights: the finite-difference passes of the architects differentiate w.r.t. the architecture parameters alone
+    (architect_vqa.py:75-88, architect.py:40-55), yet ``requires_grad`` of the weights -- all autograd tells a Function -- stays True."""
+    global _WEIGHT_GRADS
+    prev, _WEIGHT_GRADS = _WEIGHT_GRADS, bool(on)
+    try:
+        yield
+    finally:
+        _WEIGHT_GRADS = prev
+
+
 class GradSlot:
     """The one gradient buffer of a state that several fused edges read.  Each consuming edge's backward adds its dx into it
     inside the kernel (``accumulate_dx``) and returns no gradient of its own; ``FanoutFn.backward`` -- which autograd runs after
@@ -497,10 +514,10 @@ class MixedEdgeFn(torch.autograd.Function):
         scratch = _scratch(lib.query('mixed_edge_bwd_scratch_floats', B, H, W, C, stride), torch.float32, dev)
         wptr = (ctypes.c_void_p * 14)(*([w.data_ptr() for w in weights] + [None] * (14 - len(weights))))
         lib('mixed_edge_bwd', dout, ldd, x, B, H, W, C, stride, wptr, pre, stats[0], stats[1], wsel, beta, dx, dw, dbeta,
-            wgrad, scratch, training, acc_dx, ctx.x1d)
+            wgrad, scratch, training, acc_dx, ctx.x1d, int(_WEIGHT_GRADS))
         grads, o = [], 0
         for w in weights:
-            grads.append(wgrad[o:o + w.numel()].view_as(w))
+            grads.append(wgrad[o:o + w.numel()].view_as(w) if _WEIGHT_GRADS else None)
             o += w.numel()
         return (dout if has_prev else None, None if ctx.slot is not None else dx, dw, dbeta, None, None, None, None, None) + tuple(grads)
 

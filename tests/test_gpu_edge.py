@@ -326,3 +326,31 @@ def test_two_readers_of_one_state_share_a_gradient_buffer_and_a_dense_x1(hip_lib
                 assert rel_err(g, r) < 1e-6, (rnd, rel_err(g, r))
             else:
                 assert torch.equal(g, r), (rnd, i, rel_err(g, r))
+
+
+@pytest.mark.parametrize('C,stride,B,H,W', [(16, 1, 2, 40, 72), (32, 2, 1, 20, 68), (32, 1, 2, 20, 68), (64, 1, 1, 18, 50), (64, 2, 2, 36, 44)])
+def test_backward_without_weight_gradients_leaves_the_others_unchanged(hip_lib, C, stride, B, H, W):
+    """darts_ops.weight_grads(False) -- what the architects' finite-difference passes run under (bilevel.grads(..., weight_grads=False)):
+    dx, d alpha, d beta bit-identical to the full backward, no gradient for the convolution weights."""
+    from lct_vqa_amd import darts_ops as D
+    from lct_vqa_amd.basic_vqa import config
+    from lct_vqa_amd.basic_vqa.pcdarts import model_search as MS
+    config.DEVICE = torch.device(DEV)
+    torch.manual_seed(C + 7 * stride)
+    op = MS.MixedOp(C, stride).to(DEV).train()
+    x = torch.randn(B, H, W, C, device=DEV, requires_grad=True)
+    w = torch.softmax(torch.randn(8, device=DEV), 0).requires_grad_()
+    beta = (torch.rand(1, device=DEV) + 0.5).requires_grad_()
+    gout = torch.randn(B, H // stride, W // stride, C, device=DEV)
+    params = list(op.parameters())
+
+    def run(full):
+        y = op(x, w, None, beta)
+        with D.weight_grads(full):
+            return torch.autograd.grad(y, [x, w, beta] + params, gout, allow_unused=True)
+
+    full, lean = run(True), run(False)
+    assert all(g is not None for g in full)
+    for a, b in zip(lean[:3], full[:3]):
+        assert torch.equal(a, b)
+    assert all(g is None for g in lean[3:])

@@ -61,7 +61,7 @@ def main():
                 for _ in range(3):
                     rc = d.lctvqa_mixed_edge_bwd(P_(dout.data_ptr()), ctypes.c_long(C), P_(x.data_ptr()), B, H, H, C, s, wptr, P_(pre.data_ptr()),
                                                  P_(stats[0].data_ptr()), P_(stats[1].data_ptr()), P_(wsel.data_ptr()), P_(beta.data_ptr()), P_(dx.data_ptr()),
-                                                 P_(dw.data_ptr()), P_(dbeta.data_ptr()), P_(wgrad.data_ptr()), P_(scratch.data_ptr()), 1, 0, None, st())
+                                                 P_(dw.data_ptr()), P_(dbeta.data_ptr()), P_(wgrad.data_ptr()), P_(scratch.data_ptr()), 1, 0, None, 1, st())
                     assert rc == 0
                 ev[2].record()
                 torch.cuda.synchronize()
