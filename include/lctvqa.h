@@ -261,6 +261,8 @@ int lctvqa_mixed_combine_bwd_scalars(const float* dout, long ldd, const float* c
  *      v_mfma_f32_32x32x16_bf16, fused bias + ReLU (+ 2x2 max pool): csrc/conv3x3_bf16.hip ---- */
 int lctvqa_conv3x3_bf16_supported(int B, int H, int W, int Cin, int Cout, int pool);
 int lctvqa_conv3x3_bf16_pack_weights(const float* w_oihw, void* w_packed /* Cout*Cin*9 bf16 */, int Cout, int Cin, void* stream);
+/* packed weights of the data-gradient convolution (channels transposed, taps flipped) of a layer with OIHW weights [Cout][Cin][3][3] */
+int lctvqa_conv3x3_bf16_pack_weights_dgrad(const float* w_oihw, void* w_packed, int Cout, int Cin, void* stream);
 int lctvqa_conv3x3_bf16_nhwc(const void* x_bf16, const void* w_packed, const float* bias, void* y_bf16, int B, int H, int W, int Cin,
                              int Cout, int relu, int pool, void* stream);
 int lctvqa_conv3x3_first_nchw_bf16(const float* x_nchw, const float* w_oihw, const float* bias, void* y_nhwc_bf16, int B, int H, int W,
@@ -292,6 +294,7 @@ int lctvqa_global_avgpool_nhwc_bwd(const float* dy, float* dx, int B, int HW, in
 /* weight gradient of the 7x7 / stride-2 stem: per-workgroup partials [blocks][147 (c,ky,kx)][64 cout] */
 int lctvqa_conv7x7_s2_stem_wgrad_blocks(int B, int H);
 int lctvqa_conv7x7_s2_stem_wgrad(const float* x_nchw, const float* dz_nhwc, float* part, int B, int H, int W, void* stream);
+int lctvqa_conv7x7_s2_stem_wgrad_bf16(const float* x_nchw, const void* dz_nhwc_bf16, float* part, int B, int H, int W, void* stream);
 /* dst[n][oy+y][ox+x][:] = relu?(src[n][sy+y][sx+x][:]) for an h x w window of NHWC tensors (pad a small map / crop it back) */
 int lctvqa_copy_window_nhwc(const float* src, float* dst, int B, int Hs, int Ws, int Hd, int Wd, int C, int sy, int sx, int oy, int ox,
                             int h, int w, int relu, void* stream);
@@ -364,6 +367,46 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
                           const float* pre, const float* mean, const float* invstd, const float* wsel, const float* beta, float* dx,
                           float* dwsel, float* dbeta, float* wgrad, float* scratch, int training, int accumulate_dx, const float* x1d,
                           int need_wgrad, void* stream);
+
+/* ---- bf16-native TRAINABLE convolution trunk (BASELINE.json configs[2] "bf16 ... encoder trainable"; trainable-trunk semantics of
+ *      basic_vqa/models_lct.py:56-63): bf16 NHWC activations and activation gradients, fp32 master weights / statistics / weight
+ *      gradients, fp32 accumulation on v_mfma_f32_32x32x16_bf16: csrc/train_bf16.hip ----
+ * conv_gemm_bf16: C[M][N] bf16 = sum_tap sum_ci A[row + tap][ci] * B[n][tap * Cin + ci] (taps 1: a 1x1 convolution / plain NT
+ * product; taps 9: a 3x3 convolution, padding 1, on rows that are the pixels of [.,H,W] images), then out = mask > 0 ? out : 0
+ * (bf16 mask or NULL: the ReLU backward), out += addend (bf16 or NULL, may alias C).  stats (or NULL): per-slab column sums
+ * (sum, sum of squares) of the fp32 result, [stats_slabs][2][N]: the BatchNorm statistics of the layer's output. */
+int lctvqa_conv_gemm_bf16_supported(long M, int N, int Cin, int taps);
+long lctvqa_conv_gemm_bf16_stats_elems(long M, int N);
+int lctvqa_conv_gemm_bf16_stats_slabs(long M);
+int lctvqa_conv_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, long M, int N, int Cin, int taps, int H, int W,
+                          const void* addend, long ld_add, const void* mask, long ld_mask, float* stats, void* stream);
+/* weight gradient dW (+)= sum_p dz[p][co] * x[p + tap][ci] (bf16 operands [P][ld], both pixel-strided: hardware transpose reads);
+ * dW fp32 [Cout][Cin] (taps 1) or OIHW [Cout][Cin][3][3] (taps 9); split over the pixels into fp32 slabs in `workspace` */
+long lctvqa_wgrad_bf16_workspace_bytes(long P, int Cout, int Cin, int taps);
+int lctvqa_wgrad_bf16(const void* dz, long ldz, const void* x, long ldx, long P, int Cout, int Cin, int taps, int H, int W, float* dW,
+                      int accumulate, float* workspace, long workspace_bytes, void* stream);
+/* fp32 OIHW [Cout][Cin][3][3] -> bf16 [Cout][tap][Cin] (the B operand of conv_gemm_bf16 with taps 9); dgrad: [Cin][tap][Cout], taps flipped */
+int lctvqa_pack3x3_taps_bf16(const float* w_oihw, void* dst, int Cout, int Cin, int dgrad, void* stream);
+/* BatchNorm2d on bf16 rows [P][C] (C a power of two in 64..2048).  Forward: partial sums [blocks][2][C] (bn_bf16_stats, or the
+ * producer's conv_gemm_bf16 stats) -> optional colreduce_f32 to fp64 (and, under SyncBN, an all-reduce of it) -> fwd_final: coef
+ * [4][C] = mean, invstd, scale, shift (+ running statistics) -> apply: y = relu?(z scale + shift (+ res)).  Backward: bwd_sums
+ * (sum g, sum g z with g = dy * (ymask > 0); g optionally stored) -> bwd_final: dgamma, dbeta, bcoef [3][C] -> bwd_apply. */
+int lctvqa_bn_bf16_blocks(long P, int C);
+int lctvqa_bn_bf16_stats(const void* z, long P, int C, float* part, void* stream);
+int lctvqa_bn_bf16_bwd_sums(const void* dy, const void* ymask, const void* z, void* g_out, long P, int C, float* part, void* stream);
+int lctvqa_colreduce_f32(const float* in, int n, int W2, int chunks, double* out, void* stream);
+int lctvqa_bn_bf16_fwd_final(const void* part, int part_f64, int n, int C, double count, float eps, float momentum, const float* gamma,
+                             const float* beta, float* run_mean, float* run_var, long* tracked, int training, float* coef, void* stream);
+int lctvqa_bn_bf16_bwd_final(const void* loc, int loc_f64, int n, const double* glob, int C, double count, const float* coef, const float* gamma,
+                             int training, float* dgamma, float* dbeta, int accumulate, float* bcoef, void* stream);
+int lctvqa_bn_bf16_apply(const void* z, const void* res, void* y, const float* coef, long P, int C, int relu, void* stream);
+int lctvqa_bn_bf16_bwd_apply(const void* dy, const void* ymask, const void* z, void* dz, const float* bcoef, long P, int C, void* stream);
+/* MaxPool2d(3,2,1) recording the winning window position (first maximum in scan order), its backward, the backward of a 2x
+ * subsample (zeros at the odd pixels) and of the global average pool (fp32 dy -> bf16 dx) */
+int lctvqa_maxpool3x3_s2_bf16_idx(const void* x, void* y, void* idx_u8, int B, int H, int W, int C, void* stream);
+int lctvqa_maxpool3x3_s2_bf16_bwd(const void* dy, const void* idx_u8, void* dx, int B, int H, int W, int C, void* stream);
+int lctvqa_upsample2_zero_bf16(const void* src, void* dst, int B, int H, int W, int C, void* stream);
+int lctvqa_global_avgpool_bf16_bwd(const float* dy, void* dx, int B, int HW, int C, void* stream);
 
 /* ---- input pipeline, device side (data_loader_v2.py:53-55,82-86: ToTensor + Normalize done per sample on the host):
  *      uint8 HWC rows of the image store -> fp32 NCHW, y = (x/255 - mean[c]) / std[c] ---------------------------- */

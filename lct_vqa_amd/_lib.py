@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get('LCTVQA_LIB') or os.path.join(HERE, '_C', 'liblctvqa_h
 
 _CT = {
     'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float,
-    'unsigned long long': ctypes.c_ulonglong,
+    'unsigned long long': ctypes.c_ulonglong, 'double': ctypes.c_double,
 }
 
 

@@ -37,6 +37,8 @@ __device__ __forceinline__ unsigned short f2bf(float v) {
 }
 
 // OIHW fp32 [Cout][Cin][3][3] -> bf16 [Cout/32][S = (Cin/32)*9][4 planes][32 cout][8 ch]
+// DGRAD: the packed weights of the convolution that maps dz to dx: W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] (Cout, Cin are W''s)
+template <bool DGRAD>
 __global__ void conv3x3_bf16_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cout, int Cin) {
   const long total = (long)Cout * Cin * 9;
   const int S = (Cin / 32) * 9;
@@ -50,7 +52,7 @@ __global__ void conv3x3_bf16_pack_kernel(const float* __restrict__ w, unsigned s
     const int chunk = s / 9, tap = s % 9;
     const int co = nt * 32 + j;
     const int ci = chunk * 32 + c * 8 + e;
-    wp[o] = f2bf(w[((long)co * Cin + ci) * 9 + tap]);
+    wp[o] = DGRAD ? f2bf(w[((long)ci * Cout + co) * 9 + (8 - tap)]) : f2bf(w[((long)co * Cin + ci) * 9 + tap]);
   }
 }
 
@@ -571,8 +573,18 @@ int lctvqa_conv3x3_bf16_pack_weights(const float* w_oihw, void* w_packed, int Co
   const long total = (long)Cout * Cin * 9;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(conv3x3_bf16_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, (unsigned short*)w_packed, Cout, Cin);
+  hipLaunchKernelGGL(conv3x3_bf16_pack_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, (unsigned short*)w_packed, Cout, Cin);
   return lct_check_launch("conv3x3_bf16_pack");
+}
+// packed weights of the data-gradient convolution of a layer with fp32 OIHW weights [Cout][Cin][3][3]: a [Cin]-output,
+// [Cout]-input 3x3 convolution with transposed channels and flipped taps (the backward of models_lct.py:62-63's trainable trunk)
+int lctvqa_conv3x3_bf16_pack_weights_dgrad(const float* w_oihw, void* w_packed, int Cout, int Cin, void* stream) {
+  LCT_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3x3_bf16_pack_weights_dgrad: need Cin%%32==0, Cout%%32==0 (got %d,%d)", Cin, Cout);
+  const long total = (long)Cout * Cin * 9;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(conv3x3_bf16_pack_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, (unsigned short*)w_packed, Cin, Cout);
+  return lct_check_launch("conv3x3_bf16_pack_dgrad");
 }
 
 // x bf16 NHWC [B,H,W,Cin] -> y bf16 NHWC [B,H,W,Cout] (or [B,H/2,W/2,Cout] when pool); bias fp32; fp32 accumulation

@@ -275,7 +275,8 @@ __global__ void global_avgpool_bwd_kernel(const float* __restrict__ dy, float* _
 // Persistent workgroups over output rows; lane = output channel, wave w owns the taps k = w, w+4, ... (37 of the 147), one
 // register accumulator each; the input rows of an output row sit zero-padded in LDS (wave-uniform broadcast reads).
 // part[blk][147][64] per-workgroup partials, summed by the caller (colsum).
-__global__ __launch_bounds__(256) void conv7x7_s2_stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ part,
+template <bool DZ_BF16>
+__global__ __launch_bounds__(256) void conv7x7_s2_stem_wgrad_kernel(const float* __restrict__ x, const void* __restrict__ dzv, float* __restrict__ part,
                                                                     int B, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
@@ -296,7 +297,8 @@ __global__ __launch_bounds__(256) void conv7x7_s2_stem_wgrad_kernel(const float*
     }
     __syncthreads();
     for (int ox = 0; ox < Wo; ox++) {
-      const float g = dz[(((long)n * Ho + oy) * Wo + ox) * 64 + lane];
+      const long go = (((long)n * Ho + oy) * Wo + ox) * 64 + lane;
+      const float g = DZ_BF16 ? __builtin_bit_cast(float, (unsigned int)((const unsigned short*)dzv)[go] << 16) : ((const float*)dzv)[go];
 #pragma unroll
       for (int i = 0; i < 37; i++) {
         const int k = wave + 4 * i;                                // tap index (c, ky, kx) = k / 7 (row cr) and k % 7
@@ -441,9 +443,18 @@ int lctvqa_conv7x7_s2_stem_wgrad(const float* x_nchw, const float* dz_nhwc, floa
   LCT_REQUIRE(B > 0 && H >= 7 && W >= 7, "conv7x7_s2_stem_wgrad: bad shape");
   const size_t lds = (size_t)21 * (W + 6) * sizeof(float);
   LCT_REQUIRE(lds <= 64 * 1024, "conv7x7_s2_stem_wgrad: W too large");
-  hipLaunchKernelGGL(conv7x7_s2_stem_wgrad_kernel, dim3(lctvqa_conv7x7_s2_stem_wgrad_blocks(B, H)), dim3(256), lds, (hipStream_t)stream,
-                     x_nchw, dz_nhwc, part, B, H, W);
+  hipLaunchKernelGGL(conv7x7_s2_stem_wgrad_kernel<false>, dim3(lctvqa_conv7x7_s2_stem_wgrad_blocks(B, H)), dim3(256), lds, (hipStream_t)stream,
+                     x_nchw, (const void*)dz_nhwc, part, B, H, W);
   return lct_check_launch("conv7x7_s2_stem_wgrad");
+}
+// the same with a bf16 output gradient (the bf16-native trainable trunk, train_bf16.hip)
+int lctvqa_conv7x7_s2_stem_wgrad_bf16(const float* x_nchw, const void* dz_nhwc_bf16, float* part, int B, int H, int W, void* stream) {
+  LCT_REQUIRE(B > 0 && H >= 7 && W >= 7, "conv7x7_s2_stem_wgrad_bf16: bad shape");
+  const size_t lds = (size_t)21 * (W + 6) * sizeof(float);
+  LCT_REQUIRE(lds <= 64 * 1024, "conv7x7_s2_stem_wgrad_bf16: W too large");
+  hipLaunchKernelGGL(conv7x7_s2_stem_wgrad_kernel<true>, dim3(lctvqa_conv7x7_s2_stem_wgrad_blocks(B, H)), dim3(256), lds, (hipStream_t)stream,
+                     x_nchw, dz_nhwc_bf16, part, B, H, W);
+  return lct_check_launch("conv7x7_s2_stem_wgrad_bf16");
 }
 
 }  // extern "C"

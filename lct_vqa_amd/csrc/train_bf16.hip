@@ -1,0 +1,862 @@
+// bf16-native TRAINABLE convolution trunk (BASELINE.json configs[2]: "ResNet-152+GRU bf16 ... encoder trainable"; the reference's
+// trainable-trunk semantics are basic_vqa/models_lct.py:56-63 -- a trunk without no_grad whose every layer gets a gradient).
+// Activations and their gradients live in HBM as bf16 NHWC rows [P = B*H*W][C]; weights are fp32 masters converted per step;
+// every product accumulates in fp32 on v_mfma_f32_32x32x16_bf16; BatchNorm statistics and parameter gradients are fp32 / fp64.
+//
+//   conv_gemm_bf16   z[P][N] = sum_tap sum_ci x[p + tap][ci] * w[n][tap][ci]          (1x1: taps = 1; 3x3 on any map: taps = 9)
+//                    NT product, operand tiles by LDS-DMA (rows outside the image read a zero page), epilogue: per-workgroup
+//                    column (sum, sum of squares) of the fp32 accumulators = the BatchNorm statistics of the layer's output,
+//                    bf16 addend (residual gradient) and bf16 ReLU mask (out = mask > 0 ? out : 0) for the data-gradient use.
+//   wgrad_bf16_tn    dW[tap][co][ci] = sum_p dz[p][co] * x[p + tap][ci]                 (both operands K(=pixel)-strided)
+//                    tiles [32 pixels][64 channels] by LDS-DMA in 16-row x 64-byte sub-tiles, MFMA operands by the hardware
+//                    transpose read ds_read_b64_tr_b16, split over the pixels into fp32 slabs, fixed-order reduction.
+//   bn_*             BatchNorm2d (batch statistics) on bf16 rows: statistics (when the producer did not take them), coefficient
+//                    finish in fp64, apply fused with residual add + ReLU; backward sums (ReLU mask applied on the fly, masked
+//                    gradient written once for the residual branch), coefficient finish, apply.  HBM-bound: 2 B per element and pass.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+__device__ __attribute__((aligned(64))) float g_zero_page_tb[64];
+
+__device__ __forceinline__ unsigned short f2bf(float v) {
+  const __bf16 b = (__bf16)v;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned int)u << 16); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// NT product with taps: the structure of gemm_bf16_kernel (gemm_bf16.hip: 256 x 128|64 tile, 2 x 2 waves of 4 x NT2 32x32
+// accumulators, K steps of 32 in 64-byte swizzled LDS rows, double buffered LDS-DMA, one barrier per step).
+// ------------------------------------------------------------------------------------------------------------------
+struct CgArgs {
+  const unsigned short* A; long lda;          // [M][lda] bf16 rows (NHWC pixels), Cin channels used
+  const unsigned short* B; long ldb;          // [N][ldb] bf16, k = tap * Cin + ci
+  unsigned short* C; long ldc;                // [M][ldc] bf16
+  int M, N, Cin, taps, H, W;
+  const unsigned short* addend; long ld_add;  // bf16 [M][ld_add] or null (may alias C)
+  const unsigned short* mask; long ld_mask;   // bf16 [M][ld_mask] or null: out = mask > 0 ? out : 0
+  float* stats;                               // [2 * ceil(M/256)][2][N] or null
+};
+
+template <int NT2>
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const CgArgs a) {
+  constexpr int BM = 256, BN = 64 * NT2, MT = 4;
+  constexpr int APL = BM * 4, BPL = BN * 4;
+  constexpr int ASZ = 4 * APL, BSZ = 4 * BPL;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* abuf = smem;
+  float* bbuf = smem + 2 * ASZ;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int j = lane & 31, h = lane >> 5;
+  const int NTL = a.N / BN;
+  const int n_tile = blockIdx.x % NTL, m_tile = blockIdx.x / NTL;
+  const long m0 = (long)m_tile * BM;
+  const int n0 = n_tile * BN;
+  const int spt = a.Cin >> 5;                                    // K steps per tap
+  const int S = a.taps * spt;
+  const int rl = lane >> 2, sq = (lane & 3) ^ ((rl >> 2) & 3);
+  int arow[4], ay[4], ax[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const long row = m0 + 16 * (wave + 4 * r) + rl;
+    arow[r] = row < a.M ? (int)row : -1;
+    ax[r] = ay[r] = 0;
+    if (a.taps == 9) { ax[r] = (int)(row % a.W); ay[r] = (int)((row / a.W) % a.H); }
+  }
+  long boff[NT2];
+#pragma unroll
+  for (int r = 0; r < NT2; r++) boff[r] = (long)(n0 + 16 * (wave + 4 * r) + rl) * a.ldb + sq * 8;
+  auto stage = [&](int tap, int ks, float* ad, float* bd) {
+    int dy = 0, dx = 0;
+    if (a.taps == 9) { dy = tap / 3 - 1; dx = tap - 3 * (tap / 3) - 1; }
+    const int dro = dy * a.W + dx;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      bool ok = arow[r] >= 0;
+      if (a.taps == 9) ok = ok && (unsigned)(ay[r] + dy) < (unsigned)a.H && (unsigned)(ax[r] + dx) < (unsigned)a.W;
+      const float* src = ok ? (const float*)(a.A + (long)(arow[r] + dro) * a.lda + sq * 8 + ks * 32) : g_zero_page_tb;
+      glds16(src, ad + (wave + 4 * r) * 256);
+    }
+#pragma unroll
+    for (int r = 0; r < NT2; r++) glds16((const float*)(a.B + boff[r] + (long)(tap * spt + ks) * 32), bd + (wave + 4 * r) * 256);
+  };
+  f32x16 acc[MT][NT2];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int nn = 0; nn < NT2; nn++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][nn][r] = 0.f;
+  stage(0, 0, abuf, bbuf);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int swz = (j >> 2) & 3;
+  const int fo[2] = {((0 + h) ^ swz) << 2, ((2 + h) ^ swz) << 2};
+  const int abase = (wm * MT * 32 + j) * 16;
+  const int bbase = (wn * NT2 * 32 + j) * 16;
+  int ntap = 0, nks = 0;
+  for (int s = 0; s < S; s++) {
+    if (++nks == spt) { nks = 0; ntap++; }
+    if (s + 1 < S) stage(ntap, nks, abuf + ((s + 1) & 1) * ASZ, bbuf + ((s + 1) & 1) * BSZ);
+    const float* ab = abuf + (s & 1) * ASZ + abase;
+    const float* bb = bbuf + (s & 1) * BSZ + bbase;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      bf16x8 bf[NT2];
+#pragma unroll
+      for (int nn = 0; nn < NT2; nn++) bf[nn] = __builtin_bit_cast(bf16x8, *(const f32x4*)(bb + nn * 512 + fo[kk]));
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+        const bf16x8 af = __builtin_bit_cast(bf16x8, *(const f32x4*)(ab + m * 512 + fo[kk]));
+#pragma unroll
+        for (int nn = 0; nn < NT2; nn++) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nn], acc[m][nn], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // BatchNorm statistics of the layer output: column sums of the fp32 accumulators of this wave's 128 rows (rows beyond M are
+  // products of the zero page: they add nothing).  Slab (2 m_tile + wm) of [slabs][2][N].
+  if (a.stats) {
+#pragma unroll
+    for (int nn = 0; nn < NT2; nn++) {
+      float cs = 0.f, cq = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const float v = acc[m][nn][r]; cs += v; cq = fmaf(v, v, cq); }
+      cs += __shfl_xor(cs, 32, 64);
+      cq += __shfl_xor(cq, 32, 64);
+      if (h == 0) {
+        float* sp = a.stats + ((long)(m_tile * 2 + wm) * 2) * a.N + n0 + (wn * NT2 + nn) * 32 + j;
+        sp[0] = cs;
+        sp[a.N] = cq;
+      }
+    }
+  }
+  // bf16 output through the wave's private LDS tile: 16-byte stores of consecutive channels (gemm_bf16_kernel's epilogue)
+  constexpr int TC = 32 * NT2, TS = TC + 1;
+  constexpr int LPP = TC / 8, PPI = 64 / LPP;
+  float* T = smem + wave * 32 * TS;
+  const int tq = lane % LPP, tp = lane / LPP;
+  const int col0 = n0 + wn * TC + 8 * tq;
+#pragma unroll
+  for (int m = 0; m < MT; m++) {
+    __syncthreads();
+#pragma unroll
+    for (int nn = 0; nn < NT2; nn++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) T[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + nn * 32 + j] = acc[m][nn][r];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 32 / PPI; c++) {
+      const int pr = tp + PPI * c;
+      const long row = m0 + wm * 128 + m * 32 + pr;
+      if (row < a.M) {
+        us8 av = {0, 0, 0, 0, 0, 0, 0, 0}, mv = av;
+        if (a.addend) av = *(const us8*)(a.addend + row * a.ld_add + col0);
+        if (a.mask) mv = *(const us8*)(a.mask + row * a.ld_mask + col0);
+        us8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          float v = T[pr * TS + 8 * tq + e];
+          if (a.mask) v = bf2f(mv[e]) > 0.f ? v : 0.f;
+          if (a.addend) v += bf2f(av[e]);
+          ov[e] = f2bf(v);
+        }
+        *(us8*)(a.C + row * a.ldc + col0) = ov;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// TN product (weight gradient).  Workgroup = 4 waves as WM x WN, wave tile 64 (co) x 64 (one column block: a tap and 64 input
+// channels); K step = 32 pixels.  LDS image of a step: 1-KB sub-tiles [16 pixels][32 channels] (one LDS-DMA instruction each: lane
+// = (pixel lane>>2, 16-byte slot lane&3)), which the transposed read consumes conflict-free (a 32-lane half reads 4 pixel rows x
+// 64 B = 256 contiguous bytes).  A (dz) sub-tile index ((mb * 2 + rh) * 2 + c32), B (x) likewise behind them.
+// ------------------------------------------------------------------------------------------------------------------
+struct WgArgs {
+  const unsigned short* dZ; long ldz;         // [P][ldz] bf16
+  const unsigned short* X; long ldx;          // [P][ldx] bf16
+  float* slabs;                               // [splits][taps][Cout][Cin] fp32
+  int P, Cout, Cin, taps, H, W;
+  int steps_per_split;                        // 32-pixel steps per split
+  int ncb;                                    // column blocks = taps * Cin / 64
+  int ntile_m, ntile_n;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* sub, int lane_off) {
+  // rows 8h + 0..3 and 8h + 4..7 of the sub-tile, transposed: element e = pixel 8h + e of this lane's channel
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sub + lane_off));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sub + lane_off + 256));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_tn_kernel(const WgArgs a) {
+  static_assert(WM * WN == 4, "four waves");
+  constexpr int NA = 4 * WM, NB = 4 * WN;                         // sub-tiles (= DMA instructions) per stage
+  constexpr int STAGE = (NA + NB) * 1024;                         // bytes
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntiles = a.ntile_m * a.ntile_n;
+  const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+  const int tile_m = tile % a.ntile_m, tile_n = tile / a.ntile_m;
+  const int cpb = a.Cin >> 6;                                     // column blocks per tap
+  const int steps_total = (a.P + 31) >> 5;
+  const int s_begin = split * a.steps_per_split;
+  const int s_end = min(steps_total, s_begin + a.steps_per_split);
+  const int S = s_end - s_begin;
+  // this lane's two pixel rows of a step (rh = 0, 1) and their image coordinates
+  const int prl = lane >> 2, slot = lane & 3;
+  long p_cur[2];
+  int py[2], px[2];
+#pragma unroll
+  for (int rh = 0; rh < 2; rh++) {
+    p_cur[rh] = (long)s_begin * 32 + 16 * rh + prl;
+    px[rh] = py[rh] = 0;
+    if (a.taps == 9) { px[rh] = (int)(p_cur[rh] % a.W); py[rh] = (int)((p_cur[rh] / a.W) % a.H); }
+  }
+  const int xinc = 32 % a.W, yinc = 32 / a.W;
+  const bool tiny = yinc + 1 > a.H;                               // maps of a few rows: one conditional subtract does not wrap y
+  auto stage = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < (NA + NB + 3) / 4; i++) {
+      const int idx = wave + 4 * i;                               // wave-uniform
+      if (idx >= NA + NB) break;
+      if (idx < NA) {
+        const int mb = idx >> 2, rh = (idx >> 1) & 1, c32 = idx & 1;
+        const float* src = p_cur[rh] < a.P
+            ? (const float*)(a.dZ + p_cur[rh] * a.ldz + ((tile_m * WM + mb) << 6) + 32 * c32 + 8 * slot) : g_zero_page_tb;
+        glds16(src, (float*)(buf + idx * 1024));
+      } else {
+        const int ib = idx - NA;
+        const int nb = ib >> 2, rh = (ib >> 1) & 1, c32 = ib & 1;
+        const int cb = tile_n * WN + nb;
+        if (cb < a.ncb) {
+          const int tap = cb / cpb, ci0 = (cb - tap * cpb) << 6;
+          int dy = 0, dx = 0;
+          if (a.taps == 9) { dy = tap / 3 - 1; dx = tap - 3 * (tap / 3) - 1; }
+          bool ok = p_cur[rh] < a.P;
+          if (a.taps == 9) ok = ok && (unsigned)(py[rh] + dy) < (unsigned)a.H && (unsigned)(px[rh] + dx) < (unsigned)a.W;
+          const float* src = ok ? (const float*)(a.X + (p_cur[rh] + dy * a.W + dx) * a.ldx + ci0 + 32 * c32 + 8 * slot) : g_zero_page_tb;
+          glds16(src, (float*)(buf + idx * 1024));
+        }
+      }
+    }
+  };
+  auto advance = [&]() {
+#pragma unroll
+    for (int rh = 0; rh < 2; rh++) {
+      p_cur[rh] += 32;
+      if (a.taps == 9) {
+        if (tiny) {
+          px[rh] = (int)(p_cur[rh] % a.W);
+          py[rh] = (int)((p_cur[rh] / a.W) % a.H);
+        } else {
+          px[rh] += xinc; py[rh] += yinc;
+          if (px[rh] >= a.W) { px[rh] -= a.W; py[rh]++; }
+          if (py[rh] >= a.H) py[rh] -= a.H;
+        }
+      }
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
+  const int cbw = tile_n * WN + wn;
+  const bool active = cbw < a.ncb;
+  // transposed-read lane offset inside a sub-tile: group g = lane>>4 -> (k half g>>1, 16-channel half g&1); lane 4q+pp of the
+  // group addresses pixel row q, channels 4pp..4pp+3
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int lane_off = (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * pp) * 2;
+  if (S > 0) stage(smem_raw);
+  advance();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int s = 0; s < S; s++) {
+    if (s + 1 < S) stage(smem_raw + ((s + 1) & 1) * STAGE);
+    advance();
+    if (active) {
+      const unsigned char* ab = smem_raw + (s & 1) * STAGE;
+      const unsigned char* bb = ab + NA * 1024;
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++) {
+        bf16x8 af[2], bf[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++) af[mi] = tr_frag(ab + (((wm * 2 + kk) * 2 + mi) << 10), lane_off);
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) bf[ni] = tr_frag(bb + (((wn * 2 + kk) * 2 + ni) << 10), lane_off);
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+          for (int ni = 0; ni < 2; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (active) {
+    const int tap = cbw / cpb, ci0 = (cbw - tap * cpb) << 6;
+    const int co0 = (tile_m * WM + wm) << 6;
+    const int j = lane & 31, h = lane >> 5;
+    float* out = a.slabs + ((long)split * a.taps + tap) * a.Cout * a.Cin;
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+      for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int co = co0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * h;
+          out[(long)co * a.Cin + ci0 + 32 * ni + j] = acc[mi][ni][r];
+        }
+  }
+}
+
+// out[co][ci][tap] (OIHW when taps == 9, [co][ci] when taps == 1) (+)= sum over splits of slabs[split][tap][co][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, int taps, int Cout, int Cin, float* __restrict__ out, int accumulate) {
+  const long per = (long)taps * Cout * Cin;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < per; o += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; k++) s += slabs[k * per + o];
+    const int ci = (int)(o % Cin);
+    const long t2 = o / Cin;
+    const int co = (int)(t2 % Cout), tap = (int)(t2 / Cout);
+    const long d = ((long)co * Cin + ci) * taps + tap;
+    out[d] = accumulate ? out[d] + s : s;
+  }
+}
+
+// fp32 OIHW [Cout][Cin][3][3] -> bf16 [Cout][tap][Cin] (forward) or, dgrad: [Cin][tap][Cout] with the taps flipped
+// (the weights of the convolution that maps dz to dx)
+__global__ void pack3x3_taps_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int Cout, int Cin, int dgrad) {
+  const long total = (long)Cout * Cin * 9;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    if (!dgrad) {
+      const int ci = (int)(o % Cin);
+      const long t = o / Cin;
+      const int tap = (int)(t % 9), co = (int)(t / 9);
+      dst[o] = f2bf(w[((long)co * Cin + ci) * 9 + tap]);
+    } else {
+      const int co = (int)(o % Cout);
+      const long t = o / Cout;
+      const int tap = (int)(t % 9), ci = (int)(t / 9);
+      dst[o] = f2bf(w[((long)co * Cin + ci) * 9 + (8 - tap)]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BatchNorm on bf16 rows [P][C], C in {64 .. 2048} a power of two.  thread = (row lane, 8-channel group).
+// ------------------------------------------------------------------------------------------------------------------
+// part[blk][2][C]: (sum z, sum z^2) of the block's rows;  BWD: (sum g, sum g z) with g = dy (* (ymask > 0)), g optionally stored
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_sums_bf16_kernel(const unsigned short* __restrict__ z, const unsigned short* __restrict__ dy,
+                                                           const unsigned short* __restrict__ ymask, unsigned short* __restrict__ gout,
+                                                           long P, int C, long per_blk, float* __restrict__ part) {
+  __shared__ float red[2][256 * 8];
+  const int CG = C >> 3, RPP = 256 / CG;
+  const int cg = threadIdx.x % CG, rlane = threadIdx.x / CG;
+  const long r0 = blockIdx.x * per_blk, r1 = min(P, r0 + per_blk);
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) s[e] = q[e] = 0.f;
+  auto add = [&](const us8 zv, const us8 dv, const us8 yv, long o) __attribute__((always_inline)) {
+    if (!BWD) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const float v = bf2f(zv[e]); s[e] += v; q[e] = fmaf(v, v, q[e]); }
+    } else {
+      us8 gv = dv;
+      if (ymask) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) gv[e] = bf2f(yv[e]) > 0.f ? dv[e] : (unsigned short)0;
+      }
+      if (gout) *(us8*)(gout + o) = gv;
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const float gg = bf2f(gv[e]); s[e] += gg; q[e] = fmaf(gg, bf2f(zv[e]), q[e]); }
+    }
+  };
+  const us8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  long r = r0 + rlane;
+  for (; r + 3L * RPP < r1; r += 4L * RPP) {                      // four rows in flight per thread
+    us8 zv[4], dv[4], yv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const long o = (r + (long)u * RPP) * C + 8 * cg;
+      zv[u] = *(const us8*)(z + o);
+      dv[u] = BWD ? *(const us8*)(dy + o) : z8;
+      yv[u] = (BWD && ymask) ? *(const us8*)(ymask + o) : z8;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) add(zv[u], dv[u], yv[u], (r + (long)u * RPP) * C + 8 * cg);
+  }
+  for (; r < r1; r += RPP) {
+    const long o = r * C + 8 * cg;
+    add(*(const us8*)(z + o), BWD ? *(const us8*)(dy + o) : z8, (BWD && ymask) ? *(const us8*)(ymask + o) : z8, o);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) { red[0][threadIdx.x * 8 + e] = s[e]; red[1][threadIdx.x * 8 + e] = q[e]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float sa = 0.f, sb = 0.f;
+    for (int k = 0; k < RPP; k++) {
+      const int i = (k * CG + (c >> 3)) * 8 + (c & 7);
+      sa += red[0][i];
+      sb += red[1][i];
+    }
+    part[((long)blockIdx.x * 2) * C + c] = sa;
+    part[((long)blockIdx.x * 2 + 1) * C + c] = sb;
+  }
+}
+
+// out[chunk][w] (fp64) = sum of in[r][w] over the chunk's rows; grid (ceil(W2 / 64), nch), block = 64 columns x 4 row lanes
+template <typename Tin>
+__global__ __launch_bounds__(256) void colreduce_kernel(const Tin* __restrict__ in, int n, int W2, int per, double* __restrict__ out) {
+  __shared__ double red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * per, r1 = min(n, r0 + per);
+  double acc = 0.0;
+  if (col < W2)
+    for (int r = r0 + rl; r < r1; r += 4) acc += (double)in[(long)r * W2 + col];
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && col < W2) out[(long)blockIdx.y * W2 + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// coef[0..3][C] = mean, invstd, scale = gamma * invstd, shift = beta - mean * scale.  training: from the partial sums (n rows of
+// [2][C]) and the element count; else from the running statistics.  Running statistics / batch counter updated when training.
+template <typename Tin>
+__global__ void bn_fwd_final_kernel(const Tin* __restrict__ part, int n, int C, double count, float eps, float momentum,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ run_mean,
+                                    float* __restrict__ run_var, long* __restrict__ tracked, int training, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double m, var;
+  if (training) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < n; k++) { a += (double)part[((long)k * 2) * C + c]; b += (double)part[((long)k * 2 + 1) * C + c]; }
+    m = a / count;
+    var = b / count - m * m;
+    if (var < 0.0) var = 0.0;
+    if (run_mean) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * m);
+      run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+    }
+    if (c == 0 && tracked) tracked[0] += 1;
+  } else {
+    m = run_mean[c];
+    var = run_var[c];
+  }
+  const double is = 1.0 / sqrt(var + (double)eps);
+  const double sc = (double)gamma[c] * is;
+  coef[c] = (float)m;
+  coef[C + c] = (float)is;
+  coef[2 * C + c] = (float)sc;
+  coef[3 * C + c] = (float)((double)beta[c] - m * sc);
+}
+
+// From the backward sums S0 = sum g, Sz = sum g z:  S1 = sum g xhat = invstd (Sz - mean S0);  dbeta (+)= S0_local, dgamma (+)= S1_local;
+// dz = A g + Bc z + Cc with  A = gamma invstd,  Bc = -A invstd S1 / count,  Cc = A (mean invstd S1 - S0) / count  (training; the
+// sums of `glob` and `count` are the whole batch's: all ranks' under SyncBN);  eval: A only.
+template <typename Tin>
+__global__ void bn_bwd_final_kernel(const Tin* __restrict__ loc, int nloc, const double* __restrict__ glob, int C, double count,
+                                    const float* __restrict__ coef, const float* __restrict__ gamma, int training,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, float* __restrict__ bcoef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, sz = 0.0;
+  for (int k = 0; k < nloc; k++) { s0 += (double)loc[((long)k * 2) * C + c]; sz += (double)loc[((long)k * 2 + 1) * C + c]; }
+  const double m = coef[c], is = coef[C + c];
+  const double s1 = is * (sz - m * s0);
+  dbeta[c] = (float)((accumulate ? (double)dbeta[c] : 0.0) + s0);
+  dgamma[c] = (float)((accumulate ? (double)dgamma[c] : 0.0) + s1);
+  double g0 = s0, g1 = s1;
+  if (glob) { g0 = glob[c]; g1 = is * (glob[C + c] - m * g0); }
+  const double A = (double)gamma[c] * is;
+  bcoef[c] = (float)A;
+  bcoef[C + c] = training ? (float)(-A * is * g1 / count) : 0.f;
+  bcoef[2 * C + c] = training ? (float)(A * (m * is * g1 - g0) / count) : 0.f;
+}
+
+// y = relu?(z * scale + shift (+ res));  thread = 8 channels, channel group fixed per thread (the grid stride is a multiple of C/8)
+__global__ __launch_bounds__(256) void bn_apply_bf16_kernel(const unsigned short* __restrict__ z, const unsigned short* __restrict__ res,
+                                                            unsigned short* __restrict__ y, const float* __restrict__ coef, long P, int C, int relu) {
+  const int CG = C >> 3;
+  const long total = P * CG;
+  const long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const int cg = (int)(t0 % CG);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { sc[e] = coef[2 * C + 8 * cg + e]; sh[e] = coef[3 * C + 8 * cg + e]; }
+  for (long o = t0; o < total; o += (long)gridDim.x * blockDim.x) {
+    const us8 zv = *(const us8*)(z + o * 8);
+    us8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (res) rv = *(const us8*)(res + o * 8);
+    us8 ov;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      float v = fmaf(bf2f(zv[e]), sc[e], sh[e]);
+      if (res) v += bf2f(rv[e]);
+      if (relu) v = fmaxf(v, 0.f);
+      ov[e] = f2bf(v);
+    }
+    *(us8*)(y + o * 8) = ov;
+  }
+}
+
+// dz = A g + Bc z + Cc, g = dy (* (ymask > 0))
+__global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ ymask,
+                                                                const unsigned short* __restrict__ z, unsigned short* __restrict__ dz,
+                                                                const float* __restrict__ bcoef, long P, int C) {
+  const int CG = C >> 3;
+  const long total = P * CG;
+  const long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const int cg = (int)(t0 % CG);
+  float ca[8], cb[8], cc[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { ca[e] = bcoef[8 * cg + e]; cb[e] = bcoef[C + 8 * cg + e]; cc[e] = bcoef[2 * C + 8 * cg + e]; }
+  for (long o = t0; o < total; o += (long)gridDim.x * blockDim.x) {
+    const us8 gv = *(const us8*)(dy + o * 8);
+    const us8 zv = *(const us8*)(z + o * 8);
+    us8 yv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ymask) yv = *(const us8*)(ymask + o * 8);
+    us8 ov;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      float gg = bf2f(gv[e]);
+      if (ymask) gg = bf2f(yv[e]) > 0.f ? gg : 0.f;
+      ov[e] = f2bf(fmaf(ca[e], gg, fmaf(cb[e], bf2f(zv[e]), cc[e])));
+    }
+    *(us8*)(dz + o * 8) = ov;
+  }
+}
+
+// ---- small bf16 helpers of the trainable trunk ----
+// MaxPool2d(3, 2, 1) that also records which of the 9 window positions won (first maximum in scan order, like PyTorch)
+__global__ void maxpool3x3_s2_bf16_idx_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, uint8_t* __restrict__ idx,
+                                              int B, int H, int W, int C8, int Ho, int Wo) {
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < (long)B * Ho * Wo * C8; o += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(o % C8);
+    long qq = o / C8;
+    const int ox = (int)(qq % Wo); qq /= Wo;
+    const int oy = (int)(qq % Ho);
+    const long n = qq / Ho;
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { best[e] = -INFINITY; bi[e] = 0; }
+    for (int ky = 0; ky < 3; ky++) {
+      const int iy = 2 * oy - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; kx++) {
+        const int ix = 2 * ox - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        const us8 v = *(const us8*)(x + (((n * H + iy) * W + ix) * C8 + c) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float f = bf2f(v[e]);
+          if (f > best[e]) { best[e] = f; bi[e] = ky * 3 + kx; }
+        }
+      }
+    }
+    us8 r;
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { r[e] = f2bf(best[e]); packed |= (unsigned long long)bi[e] << (8 * e); }
+    *(us8*)(y + o * 8) = r;
+    *(unsigned long long*)(idx + o * 8) = packed;
+  }
+}
+// thread = (input pixel, 8 channels): gathers dy of the (up to 4) windows whose recorded winner is this pixel
+__global__ void maxpool3x3_s2_bf16_bwd_kernel(const unsigned short* __restrict__ dy, const uint8_t* __restrict__ idx, unsigned short* __restrict__ dx,
+                                              int B, int H, int W, int C8, int Ho, int Wo) {
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < (long)B * H * W * C8; o += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(o % C8);
+    long qq = o / C8;
+    const int ix = (int)(qq % W); qq /= W;
+    const int iy = (int)(qq % H);
+    const long n = qq / H;
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) a[e] = 0.f;
+    for (int oy = iy >> 1; oy <= (iy + 1) >> 1; oy++) {           // windows with 2 oy - 1 <= iy <= 2 oy + 1
+      if (oy >= Ho) continue;
+      const int ky = iy - (2 * oy - 1);
+      for (int ox = ix >> 1; ox <= (ix + 1) >> 1; ox++) {
+        if (ox >= Wo) continue;
+        const int want = ky * 3 + (ix - (2 * ox - 1));
+        const long w = (((n * Ho + oy) * Wo + ox) * C8 + c) * 8;
+        const unsigned long long packed = *(const unsigned long long*)(idx + w);
+        const us8 g = *(const us8*)(dy + w);
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          if ((int)((packed >> (8 * e)) & 0xff) == want) a[e] += bf2f(g[e]);
+      }
+    }
+    us8 r;
+#pragma unroll
+    for (int e = 0; e < 8; e++) r[e] = f2bf(a[e]);
+    *(us8*)(dx + o * 8) = r;
+  }
+}
+// dst[n][y][x][:] = (y, x both even) ? src[n][y/2][x/2][:] : 0   (the backward of a 2x subsample)
+__global__ void upsample2_zero_bf16_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst, int B, int H, int W, int C8) {
+  const int Hs = H / 2, Ws = W / 2;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < (long)B * H * W * C8; o += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(o % C8);
+    long qq = o / C8;
+    const int x = (int)(qq % W); qq /= W;
+    const int y = (int)(qq % H);
+    const long n = qq / H;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!((x | y) & 1)) v = ((const f32x4*)src)[((n * Hs + (y >> 1)) * Ws + (x >> 1)) * C8 + c];
+    ((f32x4*)dst)[o] = v;
+  }
+}
+// dx[n][p][c] (bf16) = dy[n][c] (fp32) / HW
+__global__ void global_avgpool_bf16_bwd_kernel(const float* __restrict__ dy, unsigned short* __restrict__ dx, int B, int HW, int C8) {
+  const float s = 1.f / (float)HW;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < (long)B * HW * C8; o += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(o % C8);
+    const long n = o / ((long)HW * C8);
+    const f32x4 a = *(const f32x4*)(dy + (n * C8 + c) * 8), b = *(const f32x4*)(dy + (n * C8 + c) * 8 + 4);
+    const us8 r = {f2bf(a[0] * s), f2bf(a[1] * s), f2bf(a[2] * s), f2bf(a[3] * s), f2bf(b[0] * s), f2bf(b[1] * s), f2bf(b[2] * s), f2bf(b[3] * s)};
+    *(us8*)(dx + o * 8) = r;
+  }
+}
+
+int gs_blocks_tb(long n, int cap = 16384) {
+  long nb = (n + 255) / 256;
+  if (nb > cap) nb = cap;
+  return (int)(nb < 1 ? 1 : nb);
+}
+// grid of the channel-fixed elementwise kernels: a multiple of 256 threads keeps (thread % (C/8)) constant along the grid stride
+int apply_blocks(long groups) {
+  long nb = (groups + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  return (int)(nb < 1 ? 1 : nb);
+}
+bool bn_c_ok(int C) { return C >= 64 && C <= 2048 && (C & (C - 1)) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+// ---- conv_gemm_bf16 ----
+int lctvqa_conv_gemm_bf16_supported(long M, int N, int Cin, int taps) {
+  return (M >= 1 && M < (1L << 31) && N >= 64 && N % 64 == 0 && Cin >= 32 && Cin % 32 == 0 && (taps == 1 || taps == 9)) ? 1 : 0;
+}
+// floats of the statistics buffer: [2 * ceil(M / 256)][2][N]
+long lctvqa_conv_gemm_bf16_stats_elems(long M, int N) { return 2L * ((M + 255) / 256) * 2 * N; }
+int lctvqa_conv_gemm_bf16_stats_slabs(long M) { return (int)(2 * ((M + 255) / 256)); }
+// C[M][N] bf16 = sum_tap sum_ci A[row + tap][ci] * B[n][tap * Cin + ci]  (+ addend, * mask); taps = 9: rows are pixels of
+// [.,H,W] images, taps outside the image contribute zero.  stats (or NULL): per-slab column (sum, sum sq) of the fp32 result.
+int lctvqa_conv_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, long M, int N, int Cin, int taps, int H, int W,
+                          const void* addend, long ld_add, const void* mask, long ld_mask, float* stats, void* stream) {
+  LCT_REQUIRE(lctvqa_conv_gemm_bf16_supported(M, N, Cin, taps), "conv_gemm_bf16: need N %% 64 == 0, Cin %% 32 == 0, taps 1|9 (M=%ld N=%d Cin=%d taps=%d)", M, N, Cin, taps);
+  LCT_REQUIRE((lda & 7) == 0 && (ldb & 7) == 0 && (ldc & 7) == 0 && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0 && lda >= Cin &&
+              ldb >= (long)taps * Cin && ldc >= N, "conv_gemm_bf16: operands must be 16-byte aligned bf16 rows");
+  LCT_REQUIRE((!addend || ((ld_add & 7) == 0 && ((uintptr_t)addend & 15) == 0)) && (!mask || ((ld_mask & 7) == 0 && ((uintptr_t)mask & 15) == 0)),
+              "conv_gemm_bf16: addend / mask rows must be 16-byte aligned");
+  LCT_REQUIRE(taps == 1 || (H >= 1 && W >= 1 && M % ((long)H * W) == 0), "conv_gemm_bf16: taps = 9 needs M = B*H*W");
+  CgArgs a{(const unsigned short*)A, lda, (const unsigned short*)B, ldb, (unsigned short*)C, ldc, (int)M, N, Cin, taps, H, W,
+           (const unsigned short*)addend, ld_add, (const unsigned short*)mask, ld_mask, stats};
+  const long mt = (M + 255) / 256;
+  hipStream_t st = (hipStream_t)stream;
+  if (N % 128 == 0) {
+    const size_t lds = (size_t)(2 * 4 * 256 * 4 + 2 * 4 * 128 * 4) * sizeof(float);
+    auto k = conv_gemm_bf16_kernel<2>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)(mt * (N / 128))), dim3(256), lds, st, a);
+  } else {
+    const size_t lds = (size_t)(2 * 4 * 256 * 4 + 2 * 4 * 64 * 4) * sizeof(float);
+    auto k = conv_gemm_bf16_kernel<1>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)(mt * (N / 64))), dim3(256), lds, st, a);
+  }
+  return lct_check_launch("conv_gemm_bf16");
+}
+
+// ---- wgrad_bf16_tn ----
+static void wgrad_plan(long P, int Cout, int Cin, int taps, int* wm, int* ntm, int* ntn, int* splits, int* sps) {
+  *wm = Cout >= 128 ? 2 : 1;
+  const int wn = 4 / *wm;
+  const int ncb = taps * (Cin / 64);
+  *ntm = Cout / (64 * *wm);
+  *ntn = (ncb + wn - 1) / wn;
+  const long tiles = (long)*ntm * *ntn;
+  const int steps_total = (int)((P + 31) / 32);
+  long s = 1024 / tiles;
+  if (s > steps_total / 8) s = steps_total / 8;
+  if (s < 1) s = 1;
+  *sps = (int)((steps_total + s - 1) / s);
+  *splits = (steps_total + *sps - 1) / *sps;
+}
+long lctvqa_wgrad_bf16_workspace_bytes(long P, int Cout, int Cin, int taps) {
+  int wm, ntm, ntn, splits, sps;
+  wgrad_plan(P, Cout, Cin, taps, &wm, &ntm, &ntn, &splits, &sps);
+  return (long)splits * taps * Cout * Cin * (long)sizeof(float);
+}
+// dW (+)= sum_p dz[p][co] * x[p + tap][ci]: dW fp32 [Cout][Cin] (taps = 1) or OIHW [Cout][Cin][3][3] (taps = 9; rows are pixels
+// of [.,H,W] images).  workspace: lctvqa_wgrad_bf16_workspace_bytes.
+int lctvqa_wgrad_bf16(const void* dz, long ldz, const void* x, long ldx, long P, int Cout, int Cin, int taps, int H, int W, float* dW,
+                      int accumulate, float* workspace, long workspace_bytes, void* stream) {
+  LCT_REQUIRE(P >= 1 && P < (1L << 31) && Cout >= 64 && Cout % 64 == 0 && Cin >= 64 && Cin % 64 == 0 && (taps == 1 || taps == 9) &&
+              (Cout == 64 || Cout % 128 == 0), "wgrad_bf16: need Cout, Cin multiples of 64 (Cout 64 or a multiple of 128), taps 1|9");
+  LCT_REQUIRE((ldz & 7) == 0 && (ldx & 7) == 0 && (((uintptr_t)dz | (uintptr_t)x) & 15) == 0 && ldz >= Cout && ldx >= Cin,
+              "wgrad_bf16: operands must be 16-byte aligned bf16 rows");
+  LCT_REQUIRE(taps == 1 || (H >= 1 && W >= 1 && P % ((long)H * W) == 0), "wgrad_bf16: taps = 9 needs P = B*H*W");
+  int wm, ntm, ntn, splits, sps;
+  wgrad_plan(P, Cout, Cin, taps, &wm, &ntm, &ntn, &splits, &sps);
+  LCT_REQUIRE(workspace && workspace_bytes >= (long)splits * taps * Cout * Cin * (long)sizeof(float), "wgrad_bf16: workspace too small");
+  WgArgs a{(const unsigned short*)dz, ldz, (const unsigned short*)x, ldx, workspace, (int)P, Cout, Cin, taps, H > 0 ? H : 1, W > 0 ? W : 1, sps,
+           taps * (Cin / 64), ntm, ntn};
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((long)ntm * ntn * splits);
+  if (wm == 2) {
+    const size_t lds = 2 * (size_t)(8 + 8) * 1024;
+    auto k = wgrad_bf16_tn_kernel<2, 2>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
+  } else {
+    const size_t lds = 2 * (size_t)(4 + 16) * 1024;
+    auto k = wgrad_bf16_tn_kernel<1, 4>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
+  }
+  int rc = lct_check_launch("wgrad_bf16_tn");
+  if (rc) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gs_blocks_tb((long)taps * Cout * Cin, 4096)), dim3(256), 0, st, workspace, splits, taps, Cout, Cin, dW,
+                     accumulate);
+  return lct_check_launch("wgrad_reduce");
+}
+
+int lctvqa_pack3x3_taps_bf16(const float* w_oihw, void* dst, int Cout, int Cin, int dgrad, void* stream) {
+  LCT_REQUIRE(Cout > 0 && Cin > 0, "pack3x3_taps_bf16: bad shape");
+  hipLaunchKernelGGL(pack3x3_taps_kernel, dim3(gs_blocks_tb((long)Cout * Cin * 9, 4096)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                     (unsigned short*)dst, Cout, Cin, dgrad);
+  return lct_check_launch("pack3x3_taps_bf16");
+}
+
+// ---- BatchNorm on bf16 rows ----
+int lctvqa_bn_bf16_blocks(long P, int C) {
+  if (!bn_c_ok(C)) return 0;
+  const int rpp = 256 / (C / 8);
+  long nb = (P + 16L * rpp - 1) / (16L * rpp);                   // >= 16 rows per thread
+  if (nb > 2048) nb = 2048;
+  return (int)(nb < 1 ? 1 : nb);
+}
+// part [lctvqa_bn_bf16_blocks][2][C] = per-workgroup (sum z, sum z^2)
+int lctvqa_bn_bf16_stats(const void* z, long P, int C, float* part, void* stream) {
+  LCT_REQUIRE(bn_c_ok(C) && P >= 1 && ((uintptr_t)z & 15) == 0, "bn_bf16_stats: C must be a power of two in 64..2048");
+  const int nb = lctvqa_bn_bf16_blocks(P, C);
+  hipLaunchKernelGGL(bn_sums_bf16_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)z, (const unsigned short*)nullptr,
+                     (const unsigned short*)nullptr, (unsigned short*)nullptr, P, C, (P + nb - 1) / nb, part);
+  return lct_check_launch("bn_bf16_stats");
+}
+// part [blocks][2][C] = (sum g, sum g z), g = dy * (ymask > 0) (ymask NULL: g = dy); g_out (or NULL) receives g
+int lctvqa_bn_bf16_bwd_sums(const void* dy, const void* ymask, const void* z, void* g_out, long P, int C, float* part, void* stream) {
+  LCT_REQUIRE(bn_c_ok(C) && P >= 1 && (((uintptr_t)z | (uintptr_t)dy | (uintptr_t)ymask | (uintptr_t)g_out) & 15) == 0,
+              "bn_bf16_bwd_sums: C must be a power of two in 64..2048, tensors 16-byte aligned");
+  const int nb = lctvqa_bn_bf16_blocks(P, C);
+  hipLaunchKernelGGL(bn_sums_bf16_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)z, (const unsigned short*)dy,
+                     (const unsigned short*)ymask, (unsigned short*)g_out, P, C, (P + nb - 1) / nb, part);
+  return lct_check_launch("bn_bf16_bwd_sums");
+}
+// out [chunks][W2] fp64 = column sums of in [n][W2] (fp32) over `chunks` row ranges (fixed order)
+int lctvqa_colreduce_f32(const float* in, int n, int W2, int chunks, double* out, void* stream) {
+  LCT_REQUIRE(n >= 1 && W2 >= 1 && chunks >= 1, "colreduce: bad shape");
+  const int per = (n + chunks - 1) / chunks;
+  hipLaunchKernelGGL(colreduce_kernel<float>, dim3((W2 + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, in, n, W2, per, out);
+  return lct_check_launch("colreduce_f32");
+}
+// coef [4][C] = mean, invstd, scale, shift.  part: n rows of [2][C] (sum, sum sq), fp64 when part_f64 else fp32; count = elements
+// per channel behind those sums (all ranks' under SyncBN).  training = 0: running statistics, part unused.
+int lctvqa_bn_bf16_fwd_final(const void* part, int part_f64, int n, int C, double count, float eps, float momentum, const float* gamma,
+                             const float* beta, float* run_mean, float* run_var, long* tracked, int training, float* coef, void* stream) {
+  LCT_REQUIRE(C >= 1 && (training ? (part && n >= 1 && count >= 1.0) : (run_mean && run_var)), "bn_bf16_fwd_final: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (part_f64)
+    hipLaunchKernelGGL(bn_fwd_final_kernel<double>, dim3((C + 63) / 64), dim3(64), 0, st, (const double*)part, n, C, count, eps, momentum, gamma, beta,
+                       run_mean, run_var, tracked, training, coef);
+  else
+    hipLaunchKernelGGL(bn_fwd_final_kernel<float>, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)part, n, C, count, eps, momentum, gamma, beta,
+                       run_mean, run_var, tracked, training, coef);
+  return lct_check_launch("bn_bf16_fwd_final");
+}
+// bcoef [3][C] (A, Bc, Cc of dz = A g + Bc z + Cc); dgamma / dbeta (+)= from the LOCAL sums `loc` (n rows of [2][C]); glob
+// (or NULL = loc): fp64 [2][C] whole-batch sums with `count` elements per channel.
+int lctvqa_bn_bf16_bwd_final(const void* loc, int loc_f64, int n, const double* glob, int C, double count, const float* coef, const float* gamma,
+                             int training, float* dgamma, float* dbeta, int accumulate, float* bcoef, void* stream) {
+  LCT_REQUIRE(C >= 1 && loc && n >= 1 && count >= 1.0, "bn_bf16_bwd_final: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (loc_f64)
+    hipLaunchKernelGGL(bn_bwd_final_kernel<double>, dim3((C + 63) / 64), dim3(64), 0, st, (const double*)loc, n, glob, C, count, coef, gamma, training,
+                       dgamma, dbeta, accumulate, bcoef);
+  else
+    hipLaunchKernelGGL(bn_bwd_final_kernel<float>, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)loc, n, glob, C, count, coef, gamma, training,
+                       dgamma, dbeta, accumulate, bcoef);
+  return lct_check_launch("bn_bf16_bwd_final");
+}
+// y = relu?(z * coef.scale + coef.shift (+ res)) on bf16 rows [P][C]
+int lctvqa_bn_bf16_apply(const void* z, const void* res, void* y, const float* coef, long P, int C, int relu, void* stream) {
+  LCT_REQUIRE(bn_c_ok(C) && P >= 1 && (((uintptr_t)z | (uintptr_t)res | (uintptr_t)y) & 15) == 0, "bn_bf16_apply: bad shape / alignment");
+  hipLaunchKernelGGL(bn_apply_bf16_kernel, dim3(apply_blocks(P * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)z,
+                     (const unsigned short*)res, (unsigned short*)y, coef, P, C, relu);
+  return lct_check_launch("bn_bf16_apply");
+}
+// dz = A g + Bc z + Cc, g = dy * (ymask > 0) (ymask NULL: g = dy)
+int lctvqa_bn_bf16_bwd_apply(const void* dy, const void* ymask, const void* z, void* dz, const float* bcoef, long P, int C, void* stream) {
+  LCT_REQUIRE(bn_c_ok(C) && P >= 1 && (((uintptr_t)z | (uintptr_t)dy | (uintptr_t)ymask | (uintptr_t)dz) & 15) == 0, "bn_bf16_bwd_apply: bad shape / alignment");
+  hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3(apply_blocks(P * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
+                     (const unsigned short*)ymask, (const unsigned short*)z, (unsigned short*)dz, bcoef, P, C);
+  return lct_check_launch("bn_bf16_bwd_apply");
+}
+
+// ---- helpers ----
+int lctvqa_maxpool3x3_s2_bf16_idx(const void* x, void* y, void* idx_u8, int B, int H, int W, int C, void* stream) {
+  LCT_REQUIRE(C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)idx_u8) & 15) == 0, "maxpool3x3_s2_bf16_idx: need C %% 8 == 0, aligned tensors");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3_s2_bf16_idx_kernel, dim3(gs_blocks_tb((long)B * Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)x, (unsigned short*)y, (uint8_t*)idx_u8, B, H, W, C / 8, Ho, Wo);
+  return lct_check_launch("maxpool3x3_s2_bf16_idx");
+}
+int lctvqa_maxpool3x3_s2_bf16_bwd(const void* dy, const void* idx_u8, void* dx, int B, int H, int W, int C, void* stream) {
+  LCT_REQUIRE(C % 8 == 0 && (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)idx_u8) & 15) == 0, "maxpool3x3_s2_bf16_bwd: need C %% 8 == 0, aligned tensors");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3_s2_bf16_bwd_kernel, dim3(gs_blocks_tb((long)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)dy, (const uint8_t*)idx_u8, (unsigned short*)dx, B, H, W, C / 8, Ho, Wo);
+  return lct_check_launch("maxpool3x3_s2_bf16_bwd");
+}
+// dst [B][H][W][C] = src [B][H/2][W/2][C] at the even pixels, zero elsewhere
+int lctvqa_upsample2_zero_bf16(const void* src, void* dst, int B, int H, int W, int C, void* stream) {
+  LCT_REQUIRE(C % 8 == 0 && H % 2 == 0 && W % 2 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "upsample2_zero_bf16: need C %% 8 == 0, even H, W");
+  hipLaunchKernelGGL(upsample2_zero_bf16_kernel, dim3(gs_blocks_tb((long)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)src, (unsigned short*)dst, B, H, W, C / 8);
+  return lct_check_launch("upsample2_zero_bf16");
+}
+int lctvqa_global_avgpool_bf16_bwd(const float* dy, void* dx, int B, int HW, int C, void* stream) {
+  LCT_REQUIRE(C % 8 == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0, "global_avgpool_bf16_bwd: need C %% 8 == 0, aligned tensors");
+  hipLaunchKernelGGL(global_avgpool_bf16_bwd_kernel, dim3(gs_blocks_tb((long)B * HW * (C / 8))), dim3(256), 0, (hipStream_t)stream, dy,
+                     (unsigned short*)dx, B, HW, C / 8);
+  return lct_check_launch("global_avgpool_bf16_bwd");
+}
+
+}  // extern "C"

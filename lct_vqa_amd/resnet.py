@@ -234,6 +234,10 @@ class ResNet152Trunk(nn.Module):
     def forward(self, image):
         trainable = any(p.requires_grad for p in self.parameters())
         if torch.is_grad_enabled() and trainable:
+            if ops.get_compute_dtype() == 'bf16':
+                from . import resnet_bf16
+                if resnet_bf16.supported(self, image):                    # bf16 activations end to end (resnet_bf16.py)
+                    return resnet_bf16.forward_trainable(self, image)
             return self._forward_trainable(image)
         self._cache_ok = bool(self.cache_folded_weights)
         if not self._cache_ok and self._folded:

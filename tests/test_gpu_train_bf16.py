@@ -1,0 +1,339 @@
+"""bf16-native TRAINABLE trunk (csrc/train_bf16.hip, lct_vqa_amd/resnet_bf16.py): BASELINE.json configs[2] "bf16 ... encoder trainable",
+trainable-trunk semantics of the reference's basic_vqa/models_lct.py:56-63.  Kernel tests compare with float64 torch on the SAME
+bf16-rounded operands (fp32 results: 2e-5 of the largest entry; bf16 results: their own rounding, 2^-8 relative); model tests compare
+the whole trunk with oracle/resnet_oracle.py in fp32 (parity unpinned by the reference: it has no ResNet)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+BF = torch.bfloat16
+
+
+def _bf(t):
+    return t.to(BF).to(DEV)
+
+
+def _close_bf16(out, ref, what, extra=2e-5):
+    """out (bf16) equals ref (float64) up to bf16 rounding of the result (half an ulp = 2^-9 relative, gate 2^-8) plus `extra`
+    of the largest entry (the fp32 accumulation error of a sum whose terms are much larger than a near-zero result: 2e-5, the
+    gate of the fp32-output kernels)."""
+    o, r = out.double().cpu(), ref.double().cpu()
+    tol = r.abs() * 2.0 ** -8 + extra * r.abs().max() + 1e-30
+    bad = ((o - r).abs() > tol)
+    assert not bad.any(), f'{what}: {int(bad.sum())} of {bad.numel()} off, worst {((o - r).abs() / tol).max().item():.2f} tol'
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 64, 64), (1000, 128, 64), (777, 256, 512), (3136, 64, 256), (513, 2048, 512)])
+def test_conv_gemm_1x1_stats_addend_mask(hip_lib, M, N, K):
+    lib = hip_lib
+    g = torch.Generator().manual_seed(M + N + K)
+    A, Bm = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * 0.1)
+    ref = A.double() @ Bm.double().t()
+    slabs = lib.query('conv_gemm_bf16_stats_slabs', M)
+    st = torch.full((slabs, 2, N), float('nan'), device=DEV)
+    C = torch.full((M, N), float('nan'), dtype=BF, device=DEV)
+    lib('conv_gemm_bf16', A, K, Bm, K, C, N, M, N, K, 1, 0, 0, None, 0, None, 0, st)
+    _close_bf16(C, ref, 'gemm')
+    s = st.double().sum(0).cpu()
+    assert (s[0] - ref.sum(0).cpu()).abs().max() <= 2e-5 * ref.abs().sum(0).max().item()
+    assert rel_err(s[1], (ref * ref).sum(0)) < 2e-5
+    # data-gradient use: ReLU mask, then the residual gradient added (in place: addend aliases the output)
+    add = _bf(torch.randn(M, N, generator=g))
+    msk = _bf(torch.randn(M, N, generator=g))
+    C2 = add.clone()
+    lib('conv_gemm_bf16', A, K, Bm, K, C2, N, M, N, K, 1, 0, 0, C2, N, msk, N, None)
+    ref2 = torch.where(msk.double() > 0, ref, torch.zeros_like(ref)) + add.double()
+    _close_bf16(C2, ref2, 'gemm+mask+addend', extra=2.0 ** -9)
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(3, 7, 7, 64, 64), (2, 14, 14, 128, 64), (5, 7, 7, 512, 512), (1, 12, 20, 64, 128), (9, 2, 2, 64, 64)])
+def test_conv_gemm_3x3_taps_both_directions(hip_lib, B, H, W, Cin, Cout):
+    lib = hip_lib
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = _bf(torch.randn(B, H, W, Cin, generator=g))
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(DEV)
+    wq = w.to(BF).double()
+    P = B * H * W
+    wp = torch.empty(Cout * Cin * 9, dtype=BF, device=DEV)
+    lib('pack3x3_taps_bf16', w, wp, Cout, Cin, 0)
+    z = torch.full((B, H, W, Cout), float('nan'), dtype=BF, device=DEV)
+    slabs = lib.query('conv_gemm_bf16_stats_slabs', P)
+    st = torch.empty((slabs, 2, Cout), device=DEV)
+    lib('conv_gemm_bf16', x, Cin, wp, 9 * Cin, z, Cout, P, Cout, Cin, 9, H, W, None, 0, None, 0, st)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), wq, padding=1).permute(0, 2, 3, 1)
+    _close_bf16(z, ref, 'conv fwd', extra=2.0 ** -10)
+    assert rel_err(st.double().sum(0)[1], (ref * ref).sum((0, 1, 2))) < 2e-5
+    # data gradient: dx = conv_transpose(dz, w) through the dgrad packing, masked by relu's output
+    dz = _bf(torch.randn(B, H, W, Cout, generator=g))
+    msk = _bf(torch.randn(B, H, W, Cin, generator=g))
+    wd = torch.empty(Cout * Cin * 9, dtype=BF, device=DEV)
+    lib('pack3x3_taps_bf16', w, wd, Cout, Cin, 1)
+    dx = torch.full((B, H, W, Cin), float('nan'), dtype=BF, device=DEV)
+    lib('conv_gemm_bf16', dz, Cout, wd, 9 * Cout, dx, Cin, P, Cin, Cout, 9, H, W, None, 0, msk, Cin, None)
+    refd = F.conv_transpose2d(dz.double().permute(0, 3, 1, 2), wq, padding=1).permute(0, 2, 3, 1)
+    refd = torch.where(msk.double() > 0, refd, torch.zeros_like(refd))
+    _close_bf16(dx, refd, 'conv dgrad', extra=2.0 ** -10)
+
+
+@pytest.mark.parametrize('B,H,W,C', [(2, 56, 56, 64), (3, 28, 28, 128), (2, 14, 14, 256), (4, 56, 56, 128)])
+def test_tiled_conv3x3_dgrad_packing(hip_lib, B, H, W, C):
+    """conv3x3_bf16's tiled kernel on the dgrad-packed weights == conv_transpose2d (Cin != Cout where the tiling allows)."""
+    lib = hip_lib
+    Cout, Cin = (C, C) if C != 128 or H != 56 else (128, 64)
+    if not (lib.query('conv3x3_bf16_supported', B, H, W, Cout, Cin, 0) and lib.query('conv3x3_bf16_supported', B, H, W, Cin, Cout, 0)):
+        pytest.skip('no tiling')
+    g = torch.Generator().manual_seed(C + H)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(DEV)
+    dz = _bf(torch.randn(B, H, W, Cout, generator=g))
+    wd = torch.empty(Cout * Cin * 9, dtype=BF, device=DEV)
+    lib('conv3x3_bf16_pack_weights_dgrad', w, wd, Cout, Cin)
+    dx = torch.full((B, H, W, Cin), float('nan'), dtype=BF, device=DEV)
+    lib('conv3x3_bf16_nhwc', dz, wd, None, dx, B, H, W, Cout, Cin, 0, 0)
+    ref = F.conv_transpose2d(dz.double().permute(0, 3, 1, 2), w.to(BF).double(), padding=1).permute(0, 2, 3, 1)
+    _close_bf16(dx, ref, 'tiled dgrad', extra=2.0 ** -10)
+
+
+@pytest.mark.parametrize('P,Cout,Cin', [(3136, 64, 64), (1000, 64, 256), (4097, 256, 64), (6272, 128, 512), (2000, 1024, 256), (392, 2048, 512)])
+def test_wgrad_1x1(hip_lib, P, Cout, Cin):
+    lib = hip_lib
+    g = torch.Generator().manual_seed(P + Cout)
+    dz, x = _bf(torch.randn(P, Cout, generator=g)), _bf(torch.randn(P, Cin, generator=g))
+    need = lib.query('wgrad_bf16_workspace_bytes', P, Cout, Cin, 1)
+    ws = torch.empty(need // 4 + 1, device=DEV)
+    dW = torch.full((Cout, Cin), float('nan'), device=DEV)
+    lib('wgrad_bf16', dz, Cout, x, Cin, P, Cout, Cin, 1, 0, 0, dW, 0, ws, need)
+    ref = dz.double().t() @ x.double()
+    assert rel_err(dW, ref) < 2e-5
+    lib('wgrad_bf16', dz, Cout, x, Cin, P, Cout, Cin, 1, 0, 0, dW, 1, ws, need)            # accumulate
+    assert rel_err(dW, 2 * ref) < 2e-5
+
+
+@pytest.mark.parametrize('B,H,W,Cout,Cin', [(2, 56, 56, 64, 64), (3, 28, 28, 128, 128), (5, 14, 14, 256, 256), (7, 7, 7, 512, 512), (3, 8, 12, 64, 128), (33, 2, 2, 128, 64), (5, 4, 4, 64, 64)])
+def test_wgrad_3x3(hip_lib, B, H, W, Cout, Cin):
+    lib = hip_lib
+    g = torch.Generator().manual_seed(H + Cout)
+    P = B * H * W
+    dz, x = _bf(torch.randn(B, H, W, Cout, generator=g)), _bf(torch.randn(B, H, W, Cin, generator=g))
+    need = lib.query('wgrad_bf16_workspace_bytes', P, Cout, Cin, 9)
+    ws = torch.empty(need // 4 + 1, device=DEV)
+    dW = torch.full((Cout, Cin, 3, 3), float('nan'), device=DEV)
+    lib('wgrad_bf16', dz, Cout, x, Cin, P, Cout, Cin, 9, H, W, dW, 0, ws, need)
+    xx = x.double().permute(0, 3, 1, 2).requires_grad_(False)
+    wref = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
+    F.conv2d(xx, wref, padding=1).backward(dz.double().permute(0, 3, 1, 2))
+    assert rel_err(dW, wref.grad) < 2e-5
+
+
+@pytest.mark.parametrize('P,C', [(3136, 64), (5000, 256), (777, 2048), (100352, 128)])
+@pytest.mark.parametrize('training', [True, False])
+def test_batchnorm_bf16_forward_backward(hip_lib, P, C, training):
+    """The BatchNorm chain (stats -> final -> apply; bwd sums -> final -> apply) with residual + ReLU against float64
+    nn.functional.batch_norm on the same bf16 input."""
+    from lct_vqa_amd import resnet_bf16 as R
+    g = torch.Generator().manual_seed(P + C)
+    z = _bf(torch.randn(P, C, generator=g) * 1.5 + 0.3)
+    res = _bf(torch.randn(P, C, generator=g))
+    bn = torch.nn.BatchNorm2d(C).to(DEV)
+    bn.weight.data.copy_(torch.rand(C, generator=g) + 0.5)
+    bn.bias.data.copy_(torch.randn(C, generator=g) * 0.2)
+    bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+    bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    bn.train(training)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    zr = z.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True)
+    wr, br = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    yr = F.relu(F.batch_norm(zr, rm, rv, wr, br, training, bn.momentum, bn.eps) + rr)
+    y, coef, tr = R.bn_forward(z, None, 0, bn, res, True)
+    _close_bf16(y, yr.detach(), 'bn fwd', extra=2.0 ** -9)
+    if training:
+        assert rel_err(bn.running_mean, rm) < 1e-5 and rel_err(bn.running_var, rv) < 1e-5
+        assert int(bn.num_batches_tracked) == 1
+    else:
+        assert torch.equal(bn.running_mean, rm0) and torch.equal(bn.running_var, rv0)
+    dy = _bf(torch.randn(P, C, generator=g))
+    yr.backward(dy.double())
+    gres = torch.empty_like(z)
+    dz, dg, db = R.bn_backward(dy, y, z, coef, bn.weight, tr, g_out=gres)
+    _close_bf16(gres, rr.grad, 'residual gradient')
+    assert rel_err(dg, wr.grad) < 1e-3 and rel_err(db, br.grad) < 1e-3
+    _close_bf16(dz, zr.grad, 'bn dz', extra=3e-3)
+
+
+def test_maxpool_idx_and_small_helpers(hip_lib):
+    lib = hip_lib
+    g = torch.Generator().manual_seed(5)
+    B, H, W, C = 3, 16, 24, 64
+    x = F.relu(torch.randn(B, H, W, C, generator=g)).to(BF).to(DEV)               # many ties at zero, like the stem's output
+    Ho, Wo = H // 2, W // 2
+    y = torch.empty((B, Ho, Wo, C), dtype=BF, device=DEV)
+    idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=DEV)
+    lib('maxpool3x3_s2_bf16_idx', x, y, idx, B, H, W, C)
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    assert torch.equal(y.double().permute(0, 3, 1, 2), yr.detach())
+    dy = _bf(torch.randn(B, Ho, Wo, C, generator=g))
+    yr.backward(dy.double().permute(0, 3, 1, 2))
+    dx = torch.empty_like(x)
+    lib('maxpool3x3_s2_bf16_bwd', dy, idx, dx, B, H, W, C)
+    _close_bf16(dx, xr.grad.permute(0, 2, 3, 1), 'maxpool bwd')
+    up = torch.empty((B, H, W, C), dtype=BF, device=DEV)
+    lib('upsample2_zero_bf16', dy, up, B, H, W, C)
+    ref = torch.zeros(B, H, W, C, dtype=BF, device=DEV)
+    ref[:, ::2, ::2] = dy
+    assert torch.equal(up, ref)
+    d = torch.randn(B, C, generator=g).to(DEV)
+    dxa = torch.empty((B, 6, C), dtype=BF, device=DEV)
+    lib('global_avgpool_bf16_bwd', d, dxa, B, 6, C)
+    _close_bf16(dxa, (d.double() / 6)[:, None, :].expand(B, 6, C), 'avgpool bwd')
+
+
+def _oracle_and_trunk(seed, layers):
+    from oracle import resnet_oracle as O
+    from lct_vqa_amd.resnet import ResNet152Trunk
+    torch.manual_seed(seed)
+    ref = O.ResNet(layers)
+    g = torch.Generator().manual_seed(seed + 1)
+    for name, mod in ref.named_modules():                                        # non-trivial affine maps; a small last gamma keeps depth stable
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.data.copy_((torch.rand(mod.num_features, generator=g) * 0.5 + 0.75) * (0.25 if name.endswith('bn3') else 1.0))
+            mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+    m = ResNet152Trunk(layers)
+    m.load_state_dict(ref.state_dict())
+    return ref, m.to(DEV)
+
+
+def _l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _cos(a, b):
+    a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+    return (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize('layers,B,S', [((1, 1, 1, 1), 4, 64), ((2, 2, 2, 2), 8, 224)])
+def test_trainable_trunk_bf16_batch_stat_bn_vs_oracles(hip_lib, layers, B, S):
+    """Whole trainable trunk, TRAIN mode (batch-statistics BatchNorm), bf16-native; 224^2 at B = 8 is a size where the batch
+    statistics of every stage are meaningful (7 x 7 x 8 = 392 samples per channel in the last stage).
+      * vs oracle/resnet_bf16_emu (the fp32 oracle's arithmetic with the bf16 storage roundings of this path: same ReLU / max-pool
+        decisions up to the few elements whose rounding an fp32-vs-fp64 accumulation difference flips): output 1e-2 of the largest
+        entry, EVERY parameter gradient 3e-2 relative L2 -- pins the kernels;
+      * vs oracle/resnet_oracle in fp32: output 3e-2, running statistics 3e-2, every parameter gradient cosine >= 0.85 -- what bf16
+        storage itself costs (the emulation run on the CPU differs from the fp32 oracle by the same 0.2-0.4 relative L2:
+        tests/test_oracle_golden.py::test_bf16_storage_emulation_against_resnet_oracle)."""
+    from lct_vqa_amd import ops
+    from oracle import resnet_bf16_emu as E
+    lib = hip_lib
+    ref, m = _oracle_and_trunk(3, layers)
+    ref.train(); m.train()
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    g = torch.Generator().manual_seed(11)
+    img = torch.randn(B, 3, S, S, generator=g)
+    dy = torch.randn(B, 2048, generator=g)
+    yr = ref(img)
+    yr.backward(dy)
+    tiled = lambda H, W, C: bool(lib.query('conv3x3_bf16_supported', B, H, W, C, C, 0))
+    ye, ge, _ = E.trunk_forward_backward(sd0, layers, img, dy, True, tiled)
+    prev = ops.set_compute_dtype('bf16')
+    try:
+        y = m(img.to(DEV))
+        assert y.dtype == torch.float32 and y.grad_fn is not None and 'GlobalAvgPoolFn' in type(y.grad_fn).__name__
+        y.backward(dy.to(DEV))
+    finally:
+        ops.set_compute_dtype(prev)
+    errs, coss = [], []
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, n
+        errs.append((_l2(p.grad, ge[n]), n))
+        coss.append((_cos(p.grad, q.grad), n))
+    errs.sort(reverse=True)
+    coss.sort()
+    summary = dict(out_vs_emu=rel_err(y, ye), out_vs_fp32=rel_err(y, yr), grad_l2_vs_emu=errs[:4], grad_cos_vs_fp32=coss[:4])
+    print(summary)
+    assert summary['out_vs_emu'] < 1e-2 and summary['out_vs_fp32'] < 3e-2, summary
+    assert errs[0][0] < 3e-2, summary
+    assert coss[0][0] > 0.85, summary
+    for (n, b), (_, c) in zip(m.named_buffers(), ref.named_buffers()):
+        if 'running' in n:
+            assert rel_err(b, c) < 3e-2, n
+        else:
+            assert int(b) == int(c), n
+
+
+def test_trainable_trunk_bf16_eval_mode_bn_and_determinism(hip_lib):
+    """eval-mode BatchNorm (running statistics) with trainable parameters against the emulation, and bit-identical repeats."""
+    from lct_vqa_amd import ops
+    from oracle import resnet_bf16_emu as E
+    lib = hip_lib
+    layers, B, S = (1, 1, 1, 1), 2, 64
+    ref, m = _oracle_and_trunk(5, layers)
+    ref.eval(); m.eval()
+    g = torch.Generator().manual_seed(2)
+    img = torch.randn(B, 3, S, S, generator=g)
+    dy = torch.ones(B, 2048)
+    tiled = lambda H, W, C: bool(lib.query('conv3x3_bf16_supported', B, H, W, C, C, 0))
+    ye, ge, _ = E.trunk_forward_backward({k: v.clone() for k, v in ref.state_dict().items()}, layers, img, dy, False, tiled)
+    prev = ops.set_compute_dtype('bf16')
+    try:
+        outs = []
+        for _ in range(2):
+            m.zero_grad()
+            y = m(img.to(DEV))
+            y.sum().backward()
+            outs.append((y.detach().clone(), m.layer2[0].conv2.weight.grad.clone(), m.conv1.weight.grad.clone()))
+    finally:
+        ops.set_compute_dtype(prev)
+    assert rel_err(outs[0][0], ye) < 5e-3
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    errs = sorted(((_l2(p.grad, ge[n]), n) for n, p in m.named_parameters()), reverse=True)
+    assert errs[0][0] < 2e-2, errs[:8]
+    for (n, b), (_, c) in zip(m.named_buffers(), ref.named_buffers()):
+        assert torch.equal(b.cpu(), c), n                                          # eval mode leaves the running statistics alone
+
+
+@pytest.mark.parametrize('inplanes,planes,stride,down,B,S', [(256, 64, 1, False, 3, 56), (64, 64, 1, True, 2, 56), (256, 128, 2, True, 3, 56),
+                                                            (1024, 512, 2, True, 4, 14), (2048, 512, 1, False, 5, 7), (512, 128, 1, False, 2, 28)])
+def test_one_bottleneck_vs_bf16_emulation(hip_lib, inplanes, planes, stride, down, B, S):
+    """ONE BottleneckFn (train-mode BatchNorm) against the emulation's block on the same bf16 input: output, input gradient, every
+    parameter gradient (relative L2 1e-2; bf16 tensors additionally elementwise up to their rounding for all but a few elements
+    whose rounding an fp32-vs-fp64 accumulation difference flipped)."""
+    from lct_vqa_amd import resnet_bf16 as R
+    from lct_vqa_amd.resnet import _Bottleneck
+    from oracle import resnet_bf16_emu as E
+    lib = hip_lib
+    torch.manual_seed(inplanes + planes + S)
+    dn = None
+    if down:
+        dn = torch.nn.Sequential(torch.nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), torch.nn.BatchNorm2d(planes * 4))
+    blk = _Bottleneck(inplanes, planes, stride, dn)
+    g = torch.Generator().manual_seed(S)
+    for mod in blk.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.data.copy_(torch.rand(mod.num_features, generator=g) * 0.5 + 0.75)
+            mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.2)
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    blk = blk.to(DEV).train()
+    x = _bf(torch.randn(B, S, S, inplanes, generator=g).clamp_min(-0.5))
+    dy = _bf(torch.randn(B, S // stride, S // stride, planes * 4, generator=g))
+    grads = {}
+    tiled = bool(lib.query('conv3x3_bf16_supported', B, S, S, planes, planes, 0))
+    oe, bw, _ = E.block(x.double().cpu(), sd, '', stride, down, True, tiled, grads, None)
+    dxe = bw(dy.double().cpu())
+    xh = x.clone().requires_grad_(True)
+    ps = [blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias, blk.conv3.weight, blk.bn3.weight, blk.bn3.bias]
+    if down:
+        ps += [blk.downsample[0].weight, blk.downsample[1].weight, blk.downsample[1].bias]
+    y = R.BottleneckFn.apply(xh, blk, *ps)
+    y.backward(dy)
+    assert _l2(y, oe) < 2e-3 and _l2(xh.grad, dxe) < 1e-2, (_l2(y, oe), _l2(xh.grad, dxe))
+    off = ((y.double().cpu() - oe).abs() > oe.abs() * 2.0 ** -7 + 1e-3 * oe.abs().max()).double().mean().item()
+    assert off < 1e-3, off
+    errs = sorted(((_l2(p.grad, grads[n]), n) for n, p in blk.named_parameters()), reverse=True)
+    assert errs[0][0] < 1e-2, errs

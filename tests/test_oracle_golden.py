@@ -111,3 +111,39 @@ def test_ef_full_b4_oracle_against_reference():
     assert torch.equal(qo.argmax(2), fx['qst_out_argmax'])
     assert (qo[:, :, ::97] - fx['qst_out_sample']).abs().max() < 1e-5 * fx['qst_out_absmax']
     assert torch.equal(gq, fx['gen_qst']) and rel_err(ga, fx['gen_ans']) < 1e-5
+
+
+def test_bf16_storage_emulation_against_resnet_oracle():
+    """oracle/resnet_bf16_emu (the checker of the bf16-native trainable trunk): with its roundings switched off it IS the ResNet oracle
+    (output and every parameter gradient to 1e-5), which pins its hand-written backward; with them on it shows what bf16 storage costs
+    against exact arithmetic at the same point -- the figure the GPU test's fp32 gate (cosine >= 0.85) is derived from."""
+    import torch
+    from oracle import resnet_oracle as O, resnet_bf16_emu as E
+    layers, B, S = (1, 1, 1, 1), 4, 64
+    torch.manual_seed(3)
+    ref = O.ResNet(layers).train()
+    g = torch.Generator().manual_seed(4)
+    for name, mod in ref.named_modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.data.copy_((torch.rand(mod.num_features, generator=g) * 0.5 + 0.75) * (0.25 if name.endswith('bn3') else 1.0))
+            mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    img, dy = torch.randn(B, 3, S, S, generator=g), torch.randn(B, 2048, generator=g)
+    yr = ref(img)
+    yr.backward(dy)
+
+    def compare():
+        feat, grads, _ = E.trunk_forward_backward(sd, layers, img, dy)
+        out = ((feat - yr.double()).abs().max() / yr.abs().max()).item()
+        l2 = [((grads[n] - p.grad.double()).norm() / p.grad.double().norm()).item() for n, p in ref.named_parameters()]
+        cos = [(grads[n].flatten() @ p.grad.double().flatten() / grads[n].norm() / p.grad.double().norm()).item() for n, p in ref.named_parameters()]
+        return out, max(l2), min(cos)
+    rounding = E.r
+    try:
+        E.r = lambda t: t.double()
+        out, l2, cos = compare()
+        assert out < 1e-5 and l2 < 1e-5, (out, l2)
+    finally:
+        E.r = rounding
+    out, l2, cos = compare()
+    assert out < 3e-2 and 0.02 < l2 < 0.5 and cos > 0.9, (out, l2, cos)
