@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+HBM_PEAK_GBS = 8000.0                  # same guide: HBM3E spec (6.29 TB/s measured copy)
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # same guide: dense bf16 MFMA (AMD's 5 PF figure includes 2:1 sparsity)
 DIMS = dict(embed_size=512, qst_vocab_size=17858, ans_vocab_size=3129, word_embed_size=300, num_layers=1, hidden_size=512)
@@ -71,6 +72,7 @@ def parse():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="arithmetic of the frozen VGG19 trunk: 'f32' = the reference's (the headline); 'bf16' = bf16 activations/weights with fp32 "
                          "accumulation (BASELINE.json's bf16 configurations), reported under its OWN metric name, never as the headline")
+    ap.add_argument('--no-grad-sink', action='store_true', help='A/B: let autograd accumulate every parameter gradient with an ATen add_ (ops.grad_sink off)')
     ap.add_argument('--train-encoder', action='store_true',
                     help="--workload resnet_gru: train the ResNet-152 trunk too (batch-statistics BatchNorm, full backward) instead of the frozen trunk")
     ap.add_argument('--conv-algo', default=None, choices=['winograd', 'winograd2', 'direct'],
@@ -201,6 +203,38 @@ def dp_record(world, local, reducers):
     return rec
 
 
+_FAMILIES = ('gemm1x1_bf16', 'wgrad_bf16', 'bn_apply_bf16', 'bn_bwd_sums_bf16', 'bn_bwd_apply_bf16', 'conv3x3_bf16', 'conv3x3_gemm_bf16',
+             'wino4', 'wino', 'bf16', 'gemm1x1', 'wgrad', 'dgrad', 'first', 'gemm')
+
+
+def family_rooflines(conv, steps, bf16, step_ms):
+    """Group the HIP-event records of ops._timed by kernel family and price each family against ITS OWN bound: MFMA when its
+    algorithmic intensity (flops / algorithmic bytes) lies above the ridge of the dtype's dense peak over the 8 TB/s HBM spec, else
+    HBM.  -> (dominant family's roofline dict, [all families, by time])."""
+    peak_tf = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+    ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
+    fam = {}
+    for r in conv:
+        key = next((f for f in _FAMILIES if r['name'].startswith(f)), r['name'].split('_')[0])
+        a = fam.setdefault(key, {'family': key, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'launches': 0})
+        a['ms'] += r['ms']; a['flops'] += r['flops']; a['bytes'] += r.get('bytes', 0.0) or 0.0; a['launches'] += 1
+    out = []
+    for a in fam.values():
+        if a['ms'] <= 0:
+            continue
+        ai = a['flops'] / a['bytes'] if a['bytes'] else float('inf')
+        bound = 'mfma' if ai > ridge else 'hbm'
+        ach = a['flops'] / (a['ms'] * 1e-3) / 1e12 if bound == 'mfma' else a['bytes'] / (a['ms'] * 1e-3) / 1e9
+        pk = peak_tf if bound == 'mfma' else HBM_PEAK_GBS
+        out.append({'kernel': a['family'], 'bound': bound, 'achieved': round(ach, 2), 'peak': pk, 'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
+                    'frac': round(ach / pk, 4), 'traffic': None, 'launches': a['launches'], 'avg_launch_ms': round(a['ms'] / a['launches'], 4),
+                    'ms_per_step': round(a['ms'] / steps, 3), 'share_of_step': round(a['ms'] / steps / step_ms, 4),
+                    'flops_per_launch': a['flops'] / a['launches'], 'algorithmic_bytes_per_launch': a['bytes'] / a['launches'],
+                    'algorithmic_intensity': round(ai, 1) if a['bytes'] else None})
+    out.sort(key=lambda d: -d['ms_per_step'])
+    return (out[0] if out else None), out
+
+
 def bench_darts_vqa(args, rank, world, dev, img, qst, lab):
     """BASELINE configs[4] (fp32 form, one GPU): the weight step of the darts_vqa driver with the PC-DARTS search encoder,
     K timed steps between the barriers; the architecture step (2-level, second order) is timed once beside it."""
@@ -325,6 +359,7 @@ def main():
     else:
         model = models.VqaModel(**DIMS).to(dev).train()
     opt = FusedAdam(model.trainable_parameters(), lr=config.LEARNING_RATE, flatten=True)
+    ops.grad_sink(not args.no_grad_sink)            # fused backward nodes accumulate into the arena's gradient views
     trainable = opt.flat['params']
     reducer = parallel.FlatGradReducer(trainable, opt.flat_grad, scale_fn=parallel.hip_scale) if world > 1 else None
 
@@ -610,6 +645,16 @@ def main():
             roofline['traffic_source'] = f'{shown} is of other kernel sources (stamp mismatch): not reported'
     except Exception:
         pass
+    if conv and (args.train_encoder or args.workload == 'resnet_gru'):
+        # these steps are not the W workload's 15 convolution launches: every timed kernel family is priced against its own bound and
+        # the line carries the one the step spends most of its time in
+        dom, fams = family_rooflines(conv, args.steps, args.dtype == 'bf16', ms)
+        if dom is not None:
+            roofline = dict(dom)
+            roofline['families'] = fams
+            roofline['timed_share_of_step'] = round(sum(f['ms_per_step'] for f in fams) / ms, 4)
+            roofline['note'] = ('HIP events on the launch stream around every launch of the family inside the timed region; algorithmic bytes = '
+                                'operands + results once; untimed: statistics finishes, pools, weight conversion, optimizer')
     if args.layer_report:
         per = {}
         for r in conv:
@@ -623,7 +668,10 @@ def main():
         'metric': ('image-question pairs/sec (train step) at 224x224, seq=14, 3129-way' if args.workload == 'w' else
                    ('image-question pairs/sec (ResNet-152+GRU train step, %s trunk) at 224x224, seq=14, 3129-way' % ('trainable' if args.train_encoder else 'frozen')) if args.workload == 'resnet_gru' else
                    'image-question pairs/sec (LCT stage1+stage2 step: EF + generate + W soft loss%s) at 224x224, seq=14, 3129-way' % (', examiner trunk TRAINED' if args.train_encoder else ''))
-                  + (' [bf16 compute dtype: bf16 frozen trunk and bf16 head GEMMs, fp32 accumulate, fp32 master weights: NOT the headline fp32 metric]' if args.dtype == 'bf16' else ''),
+                  + ((' [bf16 compute dtype: bf16-native TRAINABLE trunk (bf16 activations and activation gradients, fp32 master weights / statistics / '
+                      'weight gradients) and bf16 head GEMMs: NOT the headline fp32 metric]' if args.train_encoder and args.workload == 'resnet_gru' else
+                      ' [bf16 compute dtype: bf16 frozen trunk and bf16 head GEMMs, fp32 accumulate, fp32 master weights: NOT the headline fp32 metric]')
+                     if args.dtype == 'bf16' else ''),
         'value': round(value, 2),
         'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
@@ -632,8 +680,8 @@ def main():
                                if args.workload == 'w' else
                                (('ResNet-152 (TRAINABLE: batch-statistics BatchNorm, full backward)' if args.train_encoder else
                                  'ResNet-152 (frozen, BatchNorm on running statistics folded into the convolutions)')
-                                + ' + GRU + fusion head, fp32 train step (fwd+CE+bwd+clip+Adam), batch %d per GPU, 224x224x3, 14 tokens, 3129 answers, '
-                                  "QV=17858: BASELINE configs[2]'s model shape on one GPU; the reference has no ResNet / GRU" % B)
+                                + ' + GRU + fusion head, %s train step (fwd+CE+bwd+clip+Adam), batch %d per GPU, 224x224x3, 14 tokens, 3129 answers, '
+                                  "QV=17858: BASELINE configs[2]'s model shape on one GPU; the reference has no ResNet / GRU" % (args.dtype, B))
                                if args.workload == 'resnet_gru' else
                                ('basic_vqa LCT stage-1 + stage-2 step fp32 (experiment.py:216-268): examiner (models_lct, %s'
                                 ') fwd+loss+bwd+clip+Adam, examiner.generate (14 tokens), W soft-loss '

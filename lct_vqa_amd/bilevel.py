@@ -62,12 +62,14 @@ def grads(loss, tensors, expect_unused=None, weight_grads=True):
     Averaged over the ranks when ``data_parallel`` is on.  ``weight_grads=False``: ``tensors`` holds architecture parameters only, the
     PC-DARTS ops skip their convolution-weight gradients in this backward pass (darts_ops.weight_grads)."""
     tensors = list(tensors)
-    if weight_grads:
-        got = torch.autograd.grad(loss, tensors, allow_unused=True)
-    else:
-        from . import darts_ops
-        with darts_ops.weight_grads(False):
+    from . import ops
+    with ops.no_grad_sink():                                     # autograd.grad wants the gradients as return values
+        if weight_grads:
             got = torch.autograd.grad(loss, tensors, allow_unused=True)
+        else:
+            from . import darts_ops
+            with darts_ops.weight_grads(False):
+                got = torch.autograd.grad(loss, tensors, allow_unused=True)
     unused = sum(g is None for g in got)
     if expect_unused is not None and unused != expect_unused:
         raise AssertionError(f'{unused} tensors received no gradient, expected {expect_unused}')

@@ -44,8 +44,8 @@ struct CgArgs {
   float* stats;                               // [2 * ceil(M/256)][2][N] or null
 };
 
-template <int NT2>
-__global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const CgArgs a) {
+template <int NT2, int TAPS>
+__global__ __launch_bounds__(256, TAPS == 1 ? 3 : 2) void conv_gemm_bf16_kernel(const CgArgs a) {
   constexpr int BM = 256, BN = 64 * NT2, MT = 4;
   constexpr int APL = BM * 4, BPL = BN * 4;
   constexpr int ASZ = 4 * APL, BSZ = 4 * BPL;
@@ -61,27 +61,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const CgArgs a) 
   const long m0 = (long)m_tile * BM;
   const int n0 = n_tile * BN;
   const int spt = a.Cin >> 5;                                    // K steps per tap
-  const int S = a.taps * spt;
+  const int S = TAPS * spt;
   const int rl = lane >> 2, sq = (lane & 3) ^ ((rl >> 2) & 3);
-  int arow[4], ay[4], ax[4];
+  int arow[4], ay[TAPS == 9 ? 4 : 1], ax[TAPS == 9 ? 4 : 1];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const long row = m0 + 16 * (wave + 4 * r) + rl;
     arow[r] = row < a.M ? (int)row : -1;
-    ax[r] = ay[r] = 0;
-    if (a.taps == 9) { ax[r] = (int)(row % a.W); ay[r] = (int)((row / a.W) % a.H); }
+    if (TAPS == 9) { ax[r] = (int)(row % a.W); ay[r] = (int)((row / a.W) % a.H); }
   }
   long boff[NT2];
 #pragma unroll
   for (int r = 0; r < NT2; r++) boff[r] = (long)(n0 + 16 * (wave + 4 * r) + rl) * a.ldb + sq * 8;
   auto stage = [&](int tap, int ks, float* ad, float* bd) {
     int dy = 0, dx = 0;
-    if (a.taps == 9) { dy = tap / 3 - 1; dx = tap - 3 * (tap / 3) - 1; }
+    if (TAPS == 9) { dy = tap / 3 - 1; dx = tap - 3 * (tap / 3) - 1; }
     const int dro = dy * a.W + dx;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       bool ok = arow[r] >= 0;
-      if (a.taps == 9) ok = ok && (unsigned)(ay[r] + dy) < (unsigned)a.H && (unsigned)(ax[r] + dx) < (unsigned)a.W;
+      if (TAPS == 9) ok = ok && (unsigned)(ay[r] + dy) < (unsigned)a.H && (unsigned)(ax[r] + dx) < (unsigned)a.W;
       const float* src = ok ? (const float*)(a.A + (long)(arow[r] + dro) * a.lda + sq * 8 + ks * 32) : g_zero_page_tb;
       glds16(src, ad + (wave + 4 * r) * 256);
     }
@@ -680,17 +679,16 @@ int lctvqa_conv_gemm_bf16(const void* A, long lda, const void* B, long ldb, void
            (const unsigned short*)addend, ld_add, (const unsigned short*)mask, ld_mask, stats};
   const long mt = (M + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
-  if (N % 128 == 0) {
-    const size_t lds = (size_t)(2 * 4 * 256 * 4 + 2 * 4 * 128 * 4) * sizeof(float);
-    auto k = conv_gemm_bf16_kernel<2>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)(mt * (N / 128))), dim3(256), lds, st, a);
-  } else {
-    const size_t lds = (size_t)(2 * 4 * 256 * 4 + 2 * 4 * 64 * 4) * sizeof(float);
-    auto k = conv_gemm_bf16_kernel<1>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)(mt * (N / 64))), dim3(256), lds, st, a);
+#define CG_LAUNCH(NT2v, TAPSv)                                                                                     \
+  {                                                                                                               \
+    const size_t lds = (size_t)(2 * 4 * 256 * 4 + 2 * 4 * 64 * NT2v * 4) * sizeof(float);                          \
+    auto k = conv_gemm_bf16_kernel<NT2v, TAPSv>;                                                                    \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+    hipLaunchKernelGGL(k, dim3((unsigned)(mt * (N / (64 * NT2v)))), dim3(256), lds, st, a);                        \
   }
+  if (N % 128 == 0) { if (taps == 1) CG_LAUNCH(2, 1) else CG_LAUNCH(2, 9) }
+  else { if (taps == 1) CG_LAUNCH(1, 1) else CG_LAUNCH(1, 9) }
+#undef CG_LAUNCH
   return lct_check_launch("conv_gemm_bf16");
 }
 

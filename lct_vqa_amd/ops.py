@@ -748,6 +748,55 @@ def eval_multi_choice(logits, choices, unk_idx, counts=None):
     return pred, counts
 
 
+# ----------------------------------------------------------------------------- gradient sink
+# ``loss.backward()`` hands every parameter gradient to an AccumulateGrad node, which -- when ``p.grad`` already exists, as the
+# views of the optimizer's flat arena always do -- launches one ATen ``add_`` per parameter (478 per step for the trainable
+# ResNet-152, ~300 for a PC-DARTS examiner).  With the sink on, the fused backward nodes (resnet_bf16.BottleneckFn / StemFn,
+# darts_ops.MixedEdgeFn) let their weight-gradient kernels accumulate INTO ``p.grad`` (their reduce / finish kernels take an
+# accumulate flag), return None for that input and fire the parameter's post-accumulate-grad hooks themselves (the arena's
+# "reached" record, the data-parallel reducer's bucket counters).  OFF by default: it is only right under ``loss.backward()``;
+# ``torch.autograd.grad`` (the architects' bilevel.grads) must see the gradients as return values, so bilevel.grads suspends it.
+_grad_sink = {'on': False}
+_sink_tls = threading.local()
+
+
+def grad_sink(on=True):
+    """Let the fused backward nodes accumulate parameter gradients straight into existing ``p.grad`` tensors (see above).
+    Returns the previous setting."""
+    prev = _grad_sink['on']
+    _grad_sink['on'] = bool(on)
+    return prev
+
+
+@contextlib.contextmanager
+def no_grad_sink():
+    """Suspend the sink (callers of torch.autograd.grad)."""
+    depth = getattr(_sink_tls, 'off', 0)
+    _sink_tls.off = depth + 1
+    try:
+        yield
+    finally:
+        _sink_tls.off = depth
+
+
+def sink_target(p):
+    """``p.grad`` when a backward node may accumulate into it directly, else None (the node then returns the gradient)."""
+    if not _grad_sink['on'] or getattr(_sink_tls, 'off', 0) or p is None:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_cuda or g.shape != p.shape or not g.is_contiguous():
+        return None
+    return g
+
+
+def sink_done(p):
+    """The gradient of ``p`` has been accumulated into ``p.grad`` by a kernel: run what AccumulateGrad would have run after it."""
+    hooks = getattr(p, '_post_accumulate_grad_hooks', None)
+    if hooks:
+        for h in list(hooks.values()):
+            h(p)
+
+
 # ----------------------------------------------------------------------------- per-launch timing (bench.py roofline)
 _conv_timer = None
 

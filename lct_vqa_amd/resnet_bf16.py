@@ -77,9 +77,10 @@ def bn_forward(z, part, n, bn, res, relu):
     return y, coef, training
 
 
-def bn_backward(dy, ymask, z, coef, gamma, training, g_out=None):
+def bn_backward(dy, ymask, z, coef, gamma, training, g_out=None, sink=(None, None)):
     """-> dz (bf16), dgamma, dbeta (fp32).  g = dy * (ymask > 0); ``g_out`` (a bf16 buffer) receives g and is then what the apply
-    pass reads (the residual branch needs it as well)."""
+    pass reads (the residual branch needs it as well).  ``sink``: (gamma.grad, beta.grad) tensors to accumulate into (ops.grad_sink);
+    the returned gradient is None for each one given."""
     C = z.shape[-1]
     P = z.numel() // C
     dev = z.device
@@ -93,10 +94,13 @@ def bn_backward(dy, ymask, z, coef, gamma, training, g_out=None):
     if world > 1:
         glob, _, _ = _reduce_rows(part, n, C, dev, force=True)
         dist.all_reduce(glob, group=_sync_bn['group'])
-    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    acc = sink[0] is not None and sink[1] is not None
+    dgamma = sink[0] if acc else torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = sink[1] if acc else torch.empty(C, dtype=torch.float32, device=dev)
     bcoef = torch.empty((3, C), dtype=torch.float32, device=dev)
-    lib('bn_bf16_bwd_final', buf, f64, rows, glob, C, float(P * world), coef, gamma, int(training), dgamma, dbeta, 0, bcoef)
+    lib('bn_bf16_bwd_final', buf, f64, rows, glob, C, float(P * world), coef, gamma, int(training), dgamma, dbeta, int(acc), bcoef)
+    if acc:
+        dgamma = dbeta = None
     dz = torch.empty_like(z)
     src, msk = (g_out, None) if g_out is not None else (dy, ymask)
     ops._timed(f'bn_bwd_apply_bf16_{C}', 0.0, 2.0 * P * C * (3 + (msk is not None)),
@@ -129,16 +133,17 @@ def conv1x1(x2, wb, stats=True, addend=None, mask=None):
     return y, st, n
 
 
-def wgrad(dz2, x2, Cout, Cin, taps=1, H=0, W=0):
-    """dW fp32 = dz^T . x (taps 1: [Cout,Cin]; taps 9: OIHW) from bf16 rows."""
+def wgrad(dz2, x2, Cout, Cin, taps=1, H=0, W=0, sink=None):
+    """dW fp32 = dz^T . x (taps 1: [Cout,Cin]; taps 9: OIHW) from bf16 rows; ``sink``: a gradient tensor to accumulate into
+    (ops.grad_sink; None is returned then)."""
     P = dz2.shape[0]
     dev = dz2.device
     need = lib.query('wgrad_bf16_workspace_bytes', P, Cout, Cin, taps)
     ws = ops._workspace(need, dev)
-    dW = torch.empty((Cout, Cin, 3, 3) if taps == 9 else (Cout, Cin, 1, 1), dtype=torch.float32, device=dev)
+    dW = sink if sink is not None else torch.empty((Cout, Cin, 3, 3) if taps == 9 else (Cout, Cin, 1, 1), dtype=torch.float32, device=dev)
     ops._timed(f'wgrad_bf16_{taps}x_{Cin}->{Cout}', 2.0 * P * Cout * Cin * taps, 2.0 * P * (Cout + Cin),
-               lambda: lib('wgrad_bf16', dz2, Cout, x2, Cin, P, Cout, Cin, taps, H, W, dW, 0, ws, need))
-    return dW
+               lambda: lib('wgrad_bf16', dz2, Cout, x2, Cin, P, Cout, Cin, taps, H, W, dW, int(sink is not None), ws, need))
+    return None if sink is not None else dW
 
 
 class _Conv3x3:
@@ -285,6 +290,7 @@ class BottleneckFn(torch.autograd.Function):
         ctx.save_for_backward(x, z1, y1, c1, z2, y2, c2, z3, c3, out, g1, g2, g3, w1t, w3t,
                               *((src, zd, cd, params[10], wdt) if down else ()))
         ctx.c3x3 = c3x3
+        ctx.blk = blk
         ctx.cfg = (down, s, planes, (tr1, tr2, tr3, trd))
         return out
 
@@ -300,24 +306,30 @@ class BottleneckFn(torch.autograd.Function):
         C4 = 4 * planes
         dev = x.device
         dout = dout.contiguous().view(Po, C4)
+        blk = ctx.blk
+        prm = [blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias,
+               blk.conv3.weight, blk.bn3.weight, blk.bn3.bias]
+        if down:
+            prm += [blk.downsample[0].weight, blk.downsample[1].weight, blk.downsample[1].bias]
+        tg = [ops.sink_target(p) for p in prm]                          # p.grad to accumulate into, or None (ops.grad_sink)
         # bn3 (+ residual, ReLU): g = dout * (out > 0) is written once: it is the residual gradient too
         gres = _bf16((Po, C4), dev)
-        dz3, dg3, db3 = bn_backward(dout, out.view(Po, C4), z3, c3, g3, tr3, g_out=gres)
-        dw3 = wgrad(dz3, y2, C4, planes)
+        dz3, dg3, db3 = bn_backward(dout, out.view(Po, C4), z3, c3, g3, tr3, g_out=gres, sink=(tg[7], tg[8]))
+        dw3 = wgrad(dz3, y2, C4, planes, sink=tg[6])
         gy2, _, _ = conv1x1(dz3, w3t, stats=False, mask=y2)             # ReLU mask of y2 in the epilogue
-        dz2, dg2, db2 = bn_backward(gy2, None, z2, c2, g2, tr2)
+        dz2, dg2, db2 = bn_backward(gy2, None, z2, c2, g2, tr2, sink=(tg[4], tg[5]))
         dz2f = dz2.view(B, Ho, Wo, planes) if s == 1 else _upsample_zero(dz2.view(B, Ho, Wo, planes), H, W)
-        dw2 = wgrad(dz2f.view(P, planes), y1, planes, planes, 9, H, W)
+        dw2 = wgrad(dz2f.view(P, planes), y1, planes, planes, 9, H, W, sink=tg[3])
         dy1, masked = c3x3.dgrad(dz2f, y1.view(B, H, W, planes))
-        dz1, dg1, db1 = bn_backward(dy1.view(P, planes), None if masked else y1, z1, c1, g1, tr1)
-        dw1 = wgrad(dz1, x.view(P, Cin), planes, Cin)
+        dz1, dg1, db1 = bn_backward(dy1.view(P, planes), None if masked else y1, z1, c1, g1, tr1, sink=(tg[1], tg[2]))
+        dw1 = wgrad(dz1, x.view(P, Cin), planes, Cin, sink=tg[0])
         grads = [dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3]
         if not down:
             dx, _, _ = conv1x1(dz1, w1t, stats=False, addend=gres)     # residual gradient added in the epilogue
         else:
             src, zd, cd, gd, wdt = sv[15:20]
-            dzd, dgd, dbd = bn_backward(gres, None, zd, cd, gd, trd)
-            dwd = wgrad(dzd, src, C4, Cin)
+            dzd, dgd, dbd = bn_backward(gres, None, zd, cd, gd, trd, sink=(tg[10], tg[11]))
+            dwd = wgrad(dzd, src, C4, Cin, sink=tg[9])
             if s == 1:
                 dx, _, _ = conv1x1(dz1, w1t, stats=False)
                 lib('conv_gemm_bf16', dzd, C4, wdt, C4, dx, Cin, P, Cin, C4, 1, 0, 0, dx, Cin, None, 0, None)   # dx += dzd . Wd
@@ -326,7 +338,10 @@ class BottleneckFn(torch.autograd.Function):
                 up = _upsample_zero(dsrc.view(B, Ho, Wo, Cin), H, W)
                 dx, _, _ = conv1x1(dz1, w1t, stats=False, addend=up.view(P, Cin))
             grads += [dwd, dgd, dbd]
-        ctx.c3x3 = None
+        ctx.c3x3 = ctx.blk = None
+        for p, g in zip(prm, grads):
+            if g is None:                                               # accumulated in place: what AccumulateGrad would do next
+                ops.sink_done(p)
         return (dx.view(B, H, W, Cin), None) + tuple(grads)
 
 
