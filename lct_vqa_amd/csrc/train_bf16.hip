@@ -14,6 +14,7 @@
 //                    finish in fp64, apply fused with residual add + ReLU; backward sums (ReLU mask applied on the fly, masked
 //                    gradient written once for the residual branch), coefficient finish, apply.  HBM-bound: 2 B per element and pass.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short us8 __attribute__((ext_vector_type(8)));
@@ -44,9 +45,9 @@ struct CgArgs {
   float* stats;                               // [2 * ceil(M/256)][2][N] or null
 };
 
-template <int NT2, int TAPS>
-__global__ __launch_bounds__(256, TAPS == 1 ? 3 : 2) void conv_gemm_bf16_kernel(const CgArgs a) {
-  constexpr int BM = 256, BN = 64 * NT2, MT = 4;
+template <int NT2, int TAPS, int MT>
+__global__ __launch_bounds__(256, (TAPS == 1 && MT == 4) ? 3 : 2) void conv_gemm_bf16_kernel(const CgArgs a) {
+  constexpr int BM = 64 * MT, BN = 64 * NT2;
   constexpr int APL = BM * 4, BPL = BN * 4;
   constexpr int ASZ = 4 * APL, BSZ = 4 * BPL;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -63,9 +64,9 @@ __global__ __launch_bounds__(256, TAPS == 1 ? 3 : 2) void conv_gemm_bf16_kernel(
   const int spt = a.Cin >> 5;                                    // K steps per tap
   const int S = TAPS * spt;
   const int rl = lane >> 2, sq = (lane & 3) ^ ((rl >> 2) & 3);
-  int arow[4], ay[TAPS == 9 ? 4 : 1], ax[TAPS == 9 ? 4 : 1];
+  int arow[MT], ay[TAPS == 9 ? MT : 1], ax[TAPS == 9 ? MT : 1];
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
+  for (int r = 0; r < MT; r++) {
     const long row = m0 + 16 * (wave + 4 * r) + rl;
     arow[r] = row < a.M ? (int)row : -1;
     if (TAPS == 9) { ax[r] = (int)(row % a.W); ay[r] = (int)((row / a.W) % a.H); }
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256, TAPS == 1 ? 3 : 2) void conv_gemm_bf16_kernel(
     if (TAPS == 9) { dy = tap / 3 - 1; dx = tap - 3 * (tap / 3) - 1; }
     const int dro = dy * a.W + dx;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < MT; r++) {
       bool ok = arow[r] >= 0;
       if (TAPS == 9) ok = ok && (unsigned)(ay[r] + dy) < (unsigned)a.H && (unsigned)(ax[r] + dx) < (unsigned)a.W;
       const float* src = ok ? (const float*)(a.A + (long)(arow[r] + dro) * a.lda + sq * 8 + ks * 32) : g_zero_page_tb;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, TAPS == 1 ? 3 : 2) void conv_gemm_bf16_kernel(
       cs += __shfl_xor(cs, 32, 64);
       cq += __shfl_xor(cq, 32, 64);
       if (h == 0) {
-        float* sp = a.stats + ((long)(m_tile * 2 + wm) * 2) * a.N + n0 + (wn * NT2 + nn) * 32 + j;
+        float* sp = a.stats + ((long)(m_tile * 2 + wm) * 2) * a.N + n0 + (wn * NT2 + nn) * 32 + j;     // slab = 32 * MT rows
         sp[0] = cs;
         sp[a.N] = cq;
       }
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256, TAPS == 1 ? 3 : 2) void conv_gemm_bf16_kernel(
 #pragma unroll
     for (int c = 0; c < 32 / PPI; c++) {
       const int pr = tp + PPI * c;
-      const long row = m0 + wm * 128 + m * 32 + pr;
+      const long row = m0 + wm * (32 * MT) + m * 32 + pr;
       if (row < a.M) {
         us8 av = {0, 0, 0, 0, 0, 0, 0, 0}, mv = av;
         if (a.addend) av = *(const us8*)(a.addend + row * a.ld_add + col0);
@@ -328,17 +329,170 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_tn_kernel(const WgArgs a) {
   }
 }
 
+// ---- ring form (the default): ONE workgroup per CU keeps D stages of LDS-DMA in flight (counted vmcnt, bare barrier: the DMA of
+// stage s + D - 1 is issued while stage s is multiplied), so a CU always has ~100 KB of loads outstanding -- the two-stage form above
+// waits a full memory latency per 32-pixel step.  Work items (tile, pixel split) are dealt so that the tiles of one pixel range run on
+// ONE XCD (blocks b and b + 8 share an XCD; speed only): they re-read the same dz / x rows from that XCD's L2, HBM sees them once.
+// Every wave issues exactly NI DMA instructions per stage (a zero-page source where there is nothing to load) so that
+// s_waitcnt vmcnt(NI * (D - 2)) means "my share of stage s has landed" at every iteration, the tail included.
+template <int WM, int WN, int D>
+__global__ __launch_bounds__(256, 1) void wgrad_bf16_ring_kernel(const WgArgs a) {
+  static_assert(WM * WN == 4, "four waves");
+  constexpr int NA = 4 * WM, NB = 4 * WN;
+  constexpr int NI = (NA + NB) / 4;
+  constexpr int STAGE = (NA + NB) * 1024;
+  static_assert((NA + NB) % 4 == 0 && NI * (D - 1) <= 63, "vmcnt budget");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntiles = a.ntile_m * a.ntile_n;
+  // item -> (tile, split): XCD = blockIdx % 8 owns the splits = XCD (mod 8)
+  const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+  const int tile = qq % ntiles, split = (qq / ntiles) * 8 + xcd;
+  const int tile_m = tile % a.ntile_m, tile_n = tile / a.ntile_m;
+  const int cpb = a.Cin >> 6;
+  const int steps_total = (a.P + 31) >> 5;
+  const int s_begin = split * a.steps_per_split;
+  const int s_end = min(steps_total, s_begin + a.steps_per_split);
+  const int S = s_end - s_begin;
+  if (S <= 0) return;                                             // uniform: a split beyond the pixel range (splits rounded up to 8)
+  const int prl = lane >> 2, slot = lane & 3;
+  long p_cur[2];
+  int py[2], px[2];
+#pragma unroll
+  for (int rh = 0; rh < 2; rh++) {
+    p_cur[rh] = (long)s_begin * 32 + 16 * rh + prl;
+    px[rh] = py[rh] = 0;
+    if (a.taps == 9) { px[rh] = (int)(p_cur[rh] % a.W); py[rh] = (int)((p_cur[rh] / a.W) % a.H); }
+  }
+  const long p_end = min((long)a.P, (long)s_end * 32);
+  const int xinc = 32 % a.W, yinc = 32 / a.W;
+  const bool tiny = yinc + 1 > a.H;
+  auto stage = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int idx = wave + 4 * i;
+      const float* src = g_zero_page_tb;
+      if (idx < NA) {
+        const int mb = idx >> 2, rh = (idx >> 1) & 1, c32 = idx & 1;
+        if (p_cur[rh] < p_end) src = (const float*)(a.dZ + p_cur[rh] * a.ldz + ((tile_m * WM + mb) << 6) + 32 * c32 + 8 * slot);
+      } else {
+        const int ib = idx - NA;
+        const int nb = ib >> 2, rh = (ib >> 1) & 1, c32 = ib & 1;
+        const int cb = tile_n * WN + nb;
+        if (cb < a.ncb) {
+          const int tap = cb / cpb, ci0 = (cb - tap * cpb) << 6;
+          int dy = 0, dx = 0;
+          if (a.taps == 9) { dy = tap / 3 - 1; dx = tap - 3 * (tap / 3) - 1; }
+          bool ok = p_cur[rh] < p_end;
+          if (a.taps == 9) ok = ok && (unsigned)(py[rh] + dy) < (unsigned)a.H && (unsigned)(px[rh] + dx) < (unsigned)a.W;
+          if (ok) src = (const float*)(a.X + (p_cur[rh] + dy * a.W + dx) * a.ldx + ci0 + 32 * c32 + 8 * slot);
+        }
+      }
+      glds16_opaque(src, (float*)(buf + idx * 1024));
+    }
+#pragma unroll
+    for (int rh = 0; rh < 2; rh++) {
+      p_cur[rh] += 32;
+      if (a.taps == 9) {
+        if (tiny) {
+          px[rh] = (int)(p_cur[rh] % a.W);
+          py[rh] = (int)((p_cur[rh] / a.W) % a.H);
+        } else {
+          px[rh] += xinc; py[rh] += yinc;
+          if (px[rh] >= a.W) { px[rh] -= a.W; py[rh]++; }
+          if (py[rh] >= a.H) py[rh] -= a.H;
+        }
+      }
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
+  const int cbw = tile_n * WN + wn;
+  const bool active = cbw < a.ncb;
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int lane_off = (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * pp) * 2;
+  // prologue: stages 0 .. D-2 (rows beyond this split's range read the zero page: they add nothing)
+#pragma unroll
+  for (int d = 0; d < D - 1; d++) stage(smem_raw + d * STAGE);
+  for (int s = 0; s < S; s++) {
+    // my DMA of stage s has landed when at most the NI * (D - 2) younger ones are outstanding; the barrier extends that to every
+    // wave's share and tells that every wave is done reading stage s - 1, whose slot the next issue overwrites
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (D - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    stage(smem_raw + ((s + D - 1) % D) * STAGE);
+    if (active) {
+      const unsigned char* ab = smem_raw + (s % D) * STAGE;
+      const unsigned char* bb = ab + NA * 1024;
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++) {
+        bf16x8 af[2], bf[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++) af[mi] = tr_frag(ab + (((wm * 2 + kk) * 2 + mi) << 10), lane_off);
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) bf[ni] = tr_frag(bb + (((wn * 2 + kk) * 2 + ni) << 10), lane_off);
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+          for (int ni = 0; ni < 2; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the tail's zero-page DMAs must not outlive the workgroup's LDS
+  if (active) {
+    const int tap = cbw / cpb, ci0 = (cbw - tap * cpb) << 6;
+    const int co0 = (tile_m * WM + wm) << 6;
+    const int j = lane & 31, h = lane >> 5;
+    float* out = a.slabs + ((long)split * a.taps + tap) * a.Cout * a.Cin;
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+      for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int co = co0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * h;
+          out[(long)co * a.Cin + ci0 + 32 * ni + j] = acc[mi][ni][r];
+        }
+  }
+}
+
 // out[co][ci][tap] (OIHW when taps == 9, [co][ci] when taps == 1) (+)= sum over splits of slabs[split][tap][co][ci]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, int taps, int Cout, int Cin, float* __restrict__ out, int accumulate) {
-  const long per = (long)taps * Cout * Cin;
-  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < per; o += (long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < splits; k++) s += slabs[k * per + o];
-    const int ci = (int)(o % Cin);
-    const long t2 = o / Cin;
+  // thread = 4 consecutive (tap, co, ci) entries (Cin % 64 == 0: never across a row); the slab loop keeps 8 independent 16-byte
+  // loads in flight (one dependent load per split made the kernel latency-bound: 64 splits x ~1 us) and adds them in a fixed order
+  const long per = (long)taps * Cout * Cin, per4 = per >> 2;
+  const f32x4* s4 = (const f32x4*)slabs;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < per4; o += (long)gridDim.x * blockDim.x) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= splits; k += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = s4[(k + u) * per4 + o];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; k < splits; k++) s += s4[k * per4 + o];
+    const long e = o << 2;
+    const int ci = (int)(e % Cin);
+    const long t2 = e / Cin;
     const int co = (int)(t2 % Cout), tap = (int)(t2 / Cout);
-    const long d = ((long)co * Cin + ci) * taps + tap;
-    out[d] = accumulate ? out[d] + s : s;
+    if (taps == 1) {
+      f32x4* d = (f32x4*)(out + (long)co * Cin + ci);
+      *d = accumulate ? *d + s : s;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const long d = ((long)co * Cin + ci + u) * taps + tap;
+        out[d] = accumulate ? out[d] + s[u] : s[u];
+      }
+    }
   }
 }
 
@@ -662,10 +816,20 @@ extern "C" {
 int lctvqa_conv_gemm_bf16_supported(long M, int N, int Cin, int taps) {
   return (M >= 1 && M < (1L << 31) && N >= 64 && N % 64 == 0 && Cin >= 32 && Cin % 32 == 0 && (taps == 1 || taps == 9)) ? 1 : 0;
 }
-// floats of the statistics buffer: [2 * ceil(M / 256)][2][N]
-long lctvqa_conv_gemm_bf16_stats_elems(long M, int N) { return 2L * ((M + 255) / 256) * 2 * N; }
-int lctvqa_conv_gemm_bf16_stats_slabs(long M) { return (int)(2 * ((M + 255) / 256)); }
-// C[M][N] bf16 = sum_tap sum_ci A[row + tap][ci] * B[n][tap * Cin + ci]  (+ addend, * mask); taps = 9: rows are pixels of
+// rows per workgroup tile: 128 for the 1x1 products (95 VGPRs, 33 KB of LDS: four workgroups per CU cover each other's load
+// latency and store tails; these products are HBM-bound), 256 for the tap loop and the 64-column tiles
+static int cg_tile_rows(long M, int N, int taps) {
+  static const int forced = getenv("LCTVQA_CG_ROWS") ? atoi(getenv("LCTVQA_CG_ROWS")) : 0;
+  if (forced == 128 || forced == 256) return forced;
+  (void)M;
+  return (taps == 1 && N > 64) ? 128 : 256;     // measured per shape at B = 256 (tools/bench_conv_gemm_bf16.py): 128 rows = 4 workgroups per CU
+}
+// slabs (rows) of the statistics buffer [slabs][2][N] for this product
+int lctvqa_conv_gemm_bf16_stats_slabs(long M, int N, int taps) {
+  const int bm = cg_tile_rows(M, N, taps);
+  return (int)(2 * ((M + bm - 1) / bm));
+}
+// C[M][N] bf16 = sum_tap sum_ci A[row + tap][ci] * B[n][tap * Cin + ci]  (* mask, + addend); taps = 9: rows are pixels of
 // [.,H,W] images, taps outside the image contribute zero.  stats (or NULL): per-slab column (sum, sum sq) of the fp32 result.
 int lctvqa_conv_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, long M, int N, int Cin, int taps, int H, int W,
                           const void* addend, long ld_add, const void* mask, long ld_mask, float* stats, void* stream) {
@@ -677,22 +841,33 @@ int lctvqa_conv_gemm_bf16(const void* A, long lda, const void* B, long ldb, void
   LCT_REQUIRE(taps == 1 || (H >= 1 && W >= 1 && M % ((long)H * W) == 0), "conv_gemm_bf16: taps = 9 needs M = B*H*W");
   CgArgs a{(const unsigned short*)A, lda, (const unsigned short*)B, ldb, (unsigned short*)C, ldc, (int)M, N, Cin, taps, H, W,
            (const unsigned short*)addend, ld_add, (const unsigned short*)mask, ld_mask, stats};
-  const long mt = (M + 255) / 256;
+  const int bm = cg_tile_rows(M, N, taps);
+  const long mt = (M + bm - 1) / bm;
   hipStream_t st = (hipStream_t)stream;
-#define CG_LAUNCH(NT2v, TAPSv)                                                                                     \
+#define CG_LAUNCH(NT2v, TAPSv, MTv)                                                                                \
   {                                                                                                               \
-    const size_t lds = (size_t)(2 * 4 * 256 * 4 + 2 * 4 * 64 * NT2v * 4) * sizeof(float);                          \
-    auto k = conv_gemm_bf16_kernel<NT2v, TAPSv>;                                                                    \
+    size_t lds = (size_t)(2 * 64 * MTv * 16 + 2 * 64 * NT2v * 16) * sizeof(float);                                 \
+    const size_t epi = (size_t)4 * 32 * (32 * NT2v + 1) * sizeof(float);                                           \
+    if (lds < epi) lds = epi;                                                                                      \
+    auto k = conv_gemm_bf16_kernel<NT2v, TAPSv, MTv>;                                                               \
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
     hipLaunchKernelGGL(k, dim3((unsigned)(mt * (N / (64 * NT2v)))), dim3(256), lds, st, a);                        \
   }
-  if (N % 128 == 0) { if (taps == 1) CG_LAUNCH(2, 1) else CG_LAUNCH(2, 9) }
-  else { if (taps == 1) CG_LAUNCH(1, 1) else CG_LAUNCH(1, 9) }
+  if (bm == 128) { if (N % 128 == 0) CG_LAUNCH(2, 1, 2) else CG_LAUNCH(1, 1, 2) }
+  else if (N % 128 == 0) { if (taps == 1) CG_LAUNCH(2, 1, 4) else CG_LAUNCH(2, 9, 4) }
+  else { if (taps == 1) CG_LAUNCH(1, 1, 4) else CG_LAUNCH(1, 9, 4) }
 #undef CG_LAUNCH
   return lct_check_launch("conv_gemm_bf16");
 }
 
-// ---- wgrad_bf16_tn ----
+// ---- wgrad_bf16 ----
+// forms: 1 = ring, 8 stages, one workgroup per CU; 2 = two-stage, ~1024 workgroups; 3 = ring, 4 stages, two workgroups per CU;
+// 4 = two-stage, ~512 workgroups.  LCTVQA_WGRAD_MODE overrides the per-shape choice (A/B: tools/bench_wgrad_bf16.py).
+static int wgrad_mode(long P, int taps) {
+  static const int forced = getenv("LCTVQA_WGRAD_MODE") ? atoi(getenv("LCTVQA_WGRAD_MODE")) : 0;
+  if (forced) return forced;
+  return (taps == 1 && P >= 150000) ? 3 : 2;                     // measured per shape at B = 256: profiles/r04_wgrad_bf16_forms.txt
+}
 static void wgrad_plan(long P, int Cout, int Cin, int taps, int* wm, int* ntm, int* ntn, int* splits, int* sps) {
   *wm = Cout >= 128 ? 2 : 1;
   const int wn = 4 / *wm;
@@ -701,11 +876,21 @@ static void wgrad_plan(long P, int Cout, int Cin, int taps, int* wm, int* ntm, i
   *ntn = (ncb + wn - 1) / wn;
   const long tiles = (long)*ntm * *ntn;
   const int steps_total = (int)((P + 31) / 32);
-  long s = 1024 / tiles;
-  if (s > steps_total / 8) s = steps_total / 8;
-  if (s < 1) s = 1;
+  const int mode = wgrad_mode(P, taps);
+  if (mode == 2 || mode == 4) {
+    long s = (mode == 2 ? 1024 : 512) / tiles;
+    if (s > steps_total / 8) s = steps_total / 8;
+    if (s < 1) s = 1;
+    *sps = (int)((steps_total + s - 1) / s);
+    *splits = (steps_total + *sps - 1) / *sps;
+    return;
+  }
+  // ring forms: one (two) workgroups per CU, splits a multiple of 8 (one residue class per XCD), at least 16 steps per split
+  long s = ((mode == 1 ? 256 : 512) + tiles - 1) / tiles;
+  s = ((s + 7) / 8) * 8;
+  while (s > 8 && steps_total / s < 16) s -= 8;
   *sps = (int)((steps_total + s - 1) / s);
-  *splits = (steps_total + *sps - 1) / *sps;
+  *splits = (int)s;
 }
 long lctvqa_wgrad_bf16_workspace_bytes(long P, int Cout, int Cin, int taps) {
   int wm, ntm, ntn, splits, sps;
@@ -728,20 +913,37 @@ int lctvqa_wgrad_bf16(const void* dz, long ldz, const void* x, long ldx, long P,
            taps * (Cin / 64), ntm, ntn};
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((long)ntm * ntn * splits);
-  if (wm == 2) {
-    const size_t lds = 2 * (size_t)(8 + 8) * 1024;
-    auto k = wgrad_bf16_tn_kernel<2, 2>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
-  } else {
-    const size_t lds = 2 * (size_t)(4 + 16) * 1024;
-    auto k = wgrad_bf16_tn_kernel<1, 4>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
+  int live = splits;                                              // slabs that are written (splits beyond the pixel range are not)
+  const int mode = wgrad_mode(P, taps);
+#define WG_RING(WMv, WNv, Dv)                                                                                    \
+  {                                                                                                              \
+    const size_t lds = (size_t)Dv * (4 * WMv + 4 * WNv) * 1024;                                                   \
+    auto k = wgrad_bf16_ring_kernel<WMv, WNv, Dv>;                                                                \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);                                                     \
   }
-  int rc = lct_check_launch("wgrad_bf16_tn");
+  if (mode == 2 || mode == 4) {
+    if (wm == 2) {
+      const size_t lds = 2 * (size_t)(8 + 8) * 1024;
+      auto k = wgrad_bf16_tn_kernel<2, 2>;
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
+    } else {
+      const size_t lds = 2 * (size_t)(4 + 16) * 1024;
+      auto k = wgrad_bf16_tn_kernel<1, 4>;
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
+    }
+  } else {
+    const int steps_total = (int)((P + 31) / 32);
+    live = (steps_total + sps - 1) / sps;
+    if (mode == 1) { if (wm == 2) WG_RING(2, 2, 8) else WG_RING(1, 4, 6) }
+    else { if (wm == 2) WG_RING(2, 2, 4) else WG_RING(1, 4, 3) }
+  }
+#undef WG_RING
+  int rc = lct_check_launch("wgrad_bf16");
   if (rc) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gs_blocks_tb((long)taps * Cout * Cin, 4096)), dim3(256), 0, st, workspace, splits, taps, Cout, Cin, dW,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gs_blocks_tb((long)taps * Cout * Cin, 4096)), dim3(256), 0, st, workspace, live, taps, Cout, Cin, dW,
                      accumulate);
   return lct_check_launch("wgrad_reduce");
 }
