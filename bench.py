@@ -239,7 +239,7 @@ def bench_darts_vqa(args, rank, world, dev, img, qst, lab):
     """BASELINE configs[4] (fp32 form, one GPU): the weight step of the darts_vqa driver with the PC-DARTS search encoder,
     K timed steps between the barriers; the architecture step (2-level, second order) is timed once beside it."""
     import types
-    from lct_vqa_amd import parallel
+    from lct_vqa_amd import ops, parallel
     from lct_vqa_amd.darts_vqa import config as dconfig, factory
     from lct_vqa_amd.basic_vqa import config as bconfig
     from lct_vqa_amd.optim import FusedAdam
@@ -251,6 +251,7 @@ def bench_darts_vqa(args, rank, world, dev, img, qst, lab):
     torch.manual_seed(10)
     model = factory.get_vqa_model(a, ds).to(dev).train()
     opt = FusedAdam(model.parameters(), lr=a.learn_rate, flatten=True)
+    ops.grad_sink(not args.no_grad_sink)            # the fused edges add their weight gradients into the arena views themselves
     arch = factory.get_architect(a, model)
     red = parallel.FlatGradReducer(opt.flat['params'], opt.flat_grad, scale_fn=parallel.hip_scale) if world > 1 else None
     B = args.batch

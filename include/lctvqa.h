@@ -290,6 +290,17 @@ int lctvqa_bn_wide_fwd(const float* x, const float* gamma, const float* beta, fl
 int lctvqa_bn_wide_bwd(const float* dy, const float* y_out, const float* x, const float* mean, const float* invstd, const float* gamma,
                        float* dx, float* dres, float* dgamma, float* dbeta, float* sums, double* part, long P, int C, int training,
                        void* stream);
+/* SyncBN forms of the two calls above (data-parallel training of a BatchNorm trunk: SURVEY.md section 8e): bn_wide_sums leaves the
+ * per-channel fp64 sums [C][2] of THIS rank ((sum x, sum x^2), or with bwd (sum g, sum g xhat)) for the caller's all-reduce; the
+ * _from_sums calls finish from sums over `count` elements per channel (all ranks').  part: lctvqa_bn_wide_blocks(P) * C * 2 doubles. */
+int lctvqa_bn_wide_sums(const float* x, const float* dy, const float* y_out, const float* mean, const float* invstd, long P, int C, int bwd,
+                        double* part, double* sums64, void* stream);
+int lctvqa_bn_wide_fwd_from_sums(const float* x, const double* sums64, double count, const float* gamma, const float* beta, float* run_mean,
+                                 float* run_var, long* tracked, const float* residual, int relu, float* y, float* mean, float* invstd, long P,
+                                 int C, float momentum, float eps, void* stream);
+int lctvqa_bn_wide_bwd_from_sums(const float* dy, const float* y_out, const float* x, const float* mean, const float* invstd, const float* gamma,
+                                 const double* sums_local, const double* sums_global, double count, float* dx, float* dres, float* dgamma,
+                                 float* dbeta, float* sums, long P, int C, void* stream);
 int lctvqa_global_avgpool_nhwc_bwd(const float* dy, float* dx, int B, int HW, int C, void* stream);
 /* weight gradient of the 7x7 / stride-2 stem: per-workgroup partials [blocks][147 (c,ky,kx)][64 cout] */
 int lctvqa_conv7x7_s2_stem_wgrad_blocks(int B, int H);

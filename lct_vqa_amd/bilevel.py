@@ -46,8 +46,22 @@ def _average_over_ranks(tensors):
     world = dist.get_world_size(_dp['group']) if (_dp['on'] is not False and dist.is_available() and dist.is_initialized()) else 1
     if world == 1:
         return tensors
-    flat = torch.cat([t.reshape(-1) for t in tensors])
+    # Two guard words ride along in the same all-reduce: the call counter and the element count.  Ranks that make different
+    # numbers of grads() calls, or calls of different sizes, see sums that are not world x their own value and raise instead of
+    # pairing unrelated collectives (a rank that makes NO matching call still blocks in the collective: every rank must run the
+    # architect step -- INTEGRATION.md, "Data parallel").
+    _dp['calls'] = _dp.get('calls', 0) + 1
+    n = sum(t.numel() for t in tensors)
+    ref = tensors[0]
+    guard = torch.tensor([float(_dp['calls'] % 4096), float(n % 16777216)], dtype=ref.dtype, device=ref.device)
+    flat = torch.cat([guard] + [t.reshape(-1) for t in tensors])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_dp['group'])
+    got = flat[:2].tolist()
+    if got[0] != world * float(_dp['calls'] % 4096) or got[1] != world * float(n % 16777216):
+        raise RuntimeError(f'bilevel.grads under data parallelism: the ranks are not making the same sequence of calls (call #{_dp["calls"]}, '
+                           f'{n} elements here; the group summed to {got}).  Every rank must run the same architect step, or switch the '
+                           'averaging off with bilevel.data_parallel(False).')
+    flat = flat[2:]
     flat.mul_(1.0 / world)
     out, o = [], 0
     for t in tensors:

@@ -187,12 +187,14 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // one wave per channel: forward -> mean, invstd (+ running update); backward -> sums[c] = sum g, sums[C + c] = sum g * xhat
 __global__ __launch_bounds__(64) void bn_wide_finish_kernel(const double* __restrict__ part, int nblk, int C, long P, float eps, float momentum,
                                                             int bwd, float* __restrict__ out0, float* __restrict__ out1,
-                                                            float* __restrict__ run_mean, float* __restrict__ run_var, long* __restrict__ tracked) {
+                                                            float* __restrict__ run_mean, float* __restrict__ run_var, long* __restrict__ tracked,
+                                                            double* __restrict__ sums64) {
   const int c = blockIdx.x;
   double a = 0.0, b = 0.0;
   for (int k = threadIdx.x; k < nblk; k += 64) { a += part[((long)k * C + c) * 2]; b += part[((long)k * C + c) * 2 + 1]; }
   a = wave_sum_f64(a); b = wave_sum_f64(b);
   if (threadIdx.x != 0) return;
+  if (sums64) { sums64[2 * c] = a; sums64[2 * c + 1] = b; return; }          // SyncBN: the per-channel sums, for the all-reduce
   if (bwd) { out0[c] = (float)a; out1[c] = (float)b; return; }
   const double m = a / (double)P;
   double var = b / (double)P - m * m;
@@ -234,9 +236,9 @@ __global__ void bn_wide_apply_kernel(const float* __restrict__ x, const float* _
 __global__ void bn_wide_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
                                          const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                          const float* __restrict__ sums, int training, float* __restrict__ dx, float* __restrict__ dres, long P,
-                                         int C) {
+                                         int C, double count) {
   const int NQ = C / 4;
-  const float invP = 1.f / (float)P;
+  const float invP = (float)(1.0 / count);
   for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < P * NQ; o += (long)gridDim.x * blockDim.x) {
     const int q = (int)(o % NQ);
     f32x4 g = ((const f32x4*)dy)[o];
@@ -394,7 +396,8 @@ int lctvqa_bn_wide_fwd(const float* x, const float* gamma, const float* beta, fl
     hipLaunchKernelGGL(bn_wide_partial_kernel<false>, dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, P, C, per, part);
     if ((rc = lct_check_launch("bn_wide_partial"))) return rc;
-    hipLaunchKernelGGL(bn_wide_finish_kernel, dim3(C), dim3(64), 0, st, part, nb, C, P, eps, momentum, 0, mean, invstd, run_mean, run_var, tracked);
+    hipLaunchKernelGGL(bn_wide_finish_kernel, dim3(C), dim3(64), 0, st, part, nb, C, P, eps, momentum, 0, mean, invstd, run_mean, run_var, tracked,
+                       (double*)nullptr);
   } else {
     LCT_REQUIRE(run_mean && run_var, "bn_wide_fwd eval: running statistics required");
     hipLaunchKernelGGL(bn_wide_eval_stats_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, run_mean, run_var, eps, C, mean, invstd);
@@ -418,13 +421,63 @@ int lctvqa_bn_wide_bwd(const float* dy, const float* y_out, const float* x, cons
   hipLaunchKernelGGL(bn_wide_partial_kernel<true>, dim3(nb), dim3(256), 0, st, x, dy, y_out, mean, invstd, P, C, per, part);
   if ((rc = lct_check_launch("bn_wide_bwd_partial"))) return rc;
   hipLaunchKernelGGL(bn_wide_finish_kernel, dim3(C), dim3(64), 0, st, part, nb, C, P, 0.f, 0.f, 1, sums, sums + C, (float*)nullptr,
-                     (float*)nullptr, (long*)nullptr);
+                     (float*)nullptr, (long*)nullptr, (double*)nullptr);
   if ((rc = lct_check_launch("bn_wide_bwd_finish"))) return rc;
   (void)hipMemcpyAsync(dbeta, sums, C * sizeof(float), hipMemcpyDeviceToDevice, st);
   (void)hipMemcpyAsync(dgamma, sums + C, C * sizeof(float), hipMemcpyDeviceToDevice, st);
   long nbk = (P * (C / 4) + 255) / 256;
   if (nbk > 8192) nbk = 8192;
-  hipLaunchKernelGGL(bn_wide_bwd_apply_kernel, dim3((int)nbk), dim3(256), 0, st, dy, y_out, x, mean, invstd, gamma, sums, training, dx, dres, P, C);
+  hipLaunchKernelGGL(bn_wide_bwd_apply_kernel, dim3((int)nbk), dim3(256), 0, st, dy, y_out, x, mean, invstd, gamma, sums, training, dx, dres, P, C,
+                     (double)P);
+  return lct_check_launch("bn_wide_bwd_apply");
+}
+// ---- SyncBN forms (data-parallel training, SURVEY.md section 8e BN caveat): the same kernels cut at the point where the per-channel
+// sums exist, so that the caller can all-reduce them.  sums64 [C][2] fp64: (sum x, sum x^2) or (sum g, sum g xhat) of THIS rank.
+int lctvqa_bn_wide_sums(const float* x, const float* dy, const float* y_out, const float* mean, const float* invstd, long P, int C, int bwd,
+                        double* part, double* sums64, void* stream) {
+  LCT_REQUIRE(C % 4 == 0 && P >= 1 && sums64, "bn_wide_sums: need C%%4==0");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = lctvqa_bn_wide_blocks(P);
+  const long per = (P + nb - 1) / nb;
+  if (bwd) hipLaunchKernelGGL(bn_wide_partial_kernel<true>, dim3(nb), dim3(256), 0, st, x, dy, y_out, mean, invstd, P, C, per, part);
+  else hipLaunchKernelGGL(bn_wide_partial_kernel<false>, dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
+                          (const float*)nullptr, (const float*)nullptr, P, C, per, part);
+  int rc = lct_check_launch("bn_wide_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_wide_finish_kernel, dim3(C), dim3(64), 0, st, part, nb, C, P, 0.f, 0.f, bwd, (float*)nullptr, (float*)nullptr,
+                     (float*)nullptr, (float*)nullptr, (long*)nullptr, sums64);
+  return lct_check_launch("bn_wide_sums");
+}
+// forward from all-reduced sums over `count` elements per channel: statistics (+ running estimates), then y = relu?(bn(x) (+ residual))
+int lctvqa_bn_wide_fwd_from_sums(const float* x, const double* sums64, double count, const float* gamma, const float* beta, float* run_mean,
+                                 float* run_var, long* tracked, const float* residual, int relu, float* y, float* mean, float* invstd, long P,
+                                 int C, float momentum, float eps, void* stream) {
+  LCT_REQUIRE(C % 4 == 0 && P >= 1 && count >= 1.0, "bn_wide_fwd_from_sums: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_wide_finish_kernel, dim3(C), dim3(64), 0, st, sums64, 1, C, (long)count, eps, momentum, 0, mean, invstd, run_mean, run_var,
+                     tracked, (double*)nullptr);
+  int rc = lct_check_launch("bn_wide_finish");
+  if (rc) return rc;
+  long nbk = (P * (C / 4) + 255) / 256;
+  if (nbk > 8192) nbk = 8192;
+  hipLaunchKernelGGL(bn_wide_apply_kernel, dim3((int)nbk), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, relu, y, P, C);
+  return lct_check_launch("bn_wide_apply");
+}
+// backward from sums: dgamma / dbeta from THIS rank's sums (the data-parallel reducer averages them), dx from the all-reduced ones
+int lctvqa_bn_wide_bwd_from_sums(const float* dy, const float* y_out, const float* x, const float* mean, const float* invstd, const float* gamma,
+                                 const double* sums_local, const double* sums_global, double count, float* dx, float* dres, float* dgamma,
+                                 float* dbeta, float* sums, long P, int C, void* stream) {
+  LCT_REQUIRE(C % 4 == 0 && P >= 1 && count >= 1.0, "bn_wide_bwd_from_sums: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_wide_finish_kernel, dim3(C), dim3(64), 0, st, sums_local, 1, C, P, 0.f, 0.f, 1, dbeta, dgamma, (float*)nullptr,
+                     (float*)nullptr, (long*)nullptr, (double*)nullptr);
+  hipLaunchKernelGGL(bn_wide_finish_kernel, dim3(C), dim3(64), 0, st, sums_global, 1, C, P, 0.f, 0.f, 1, sums, sums + C, (float*)nullptr,
+                     (float*)nullptr, (long*)nullptr, (double*)nullptr);
+  int rc = lct_check_launch("bn_wide_bwd_finish");
+  if (rc) return rc;
+  long nbk = (P * (C / 4) + 255) / 256;
+  if (nbk > 8192) nbk = 8192;
+  hipLaunchKernelGGL(bn_wide_bwd_apply_kernel, dim3((int)nbk), dim3(256), 0, st, dy, y_out, x, mean, invstd, gamma, sums, 1, dx, dres, P, C, count);
   return lct_check_launch("bn_wide_bwd_apply");
 }
 int lctvqa_global_avgpool_nhwc_bwd(const float* dy, float* dx, int B, int HW, int C, void* stream) {

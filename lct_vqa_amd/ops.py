@@ -654,7 +654,9 @@ class LinearXentFn(torch.autograd.Function):
         xa = _bf16_rows(x, M, Kp)
         wb = _bf16_rows(W, Np, Kp)
         part = torch.empty(lib.query('linear_xent_bf16_part_elems', M, Np), dtype=torch.float32, device=dev)
-        picked = torch.empty(M, dtype=torch.float32, device=dev)
+        # the kernel writes picked[m] only where a column block contains labels[m]: a label outside [0, N) must not read
+        # uninitialised memory -- it makes the loss NaN (torch's cross_entropy raises for it; no host sync here to do the same)
+        picked = torch.full((M,), float('nan'), dtype=torch.float32, device=dev)
         lse = torch.empty(M, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         lib('linear_xent_bf16_fwd', xa, Kp, wb, Kp, b, labels, M, N, Np, Kp, part, picked, lse, loss)

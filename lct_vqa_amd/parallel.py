@@ -87,6 +87,10 @@ class FlatGradReducer:
     def _on_grad(self, p):
         b = self.buckets[self.param_bucket[p]]
         b[2] -= 1
+        if b[2] < 0:
+            raise RuntimeError('FlatGradReducer: a gradient hook fired twice for one parameter before finish() (two backward() calls, or a '
+                               "parameter used by two graphs): the bucket's all-reduce is already in flight on the first pass's values.  "
+                               'Call finish() after every backward(), or accumulate locally and reduce once.')
         if b[2] == 0:
             self.stats['launched_by_hooks'] += 1
             self._launch(b)
@@ -196,6 +200,35 @@ def broadcast_buffers(model, src=0, process_group=None):
         return
     for b in model.buffers():
         dist.broadcast(b, src=src, group=process_group)
+
+
+_sync_bn = {'on': False, 'group': None}
+
+
+def set_sync_bn(on=True, process_group=None):
+    """SyncBN for data-parallel training of the BatchNorm trunks (BN caveat; the reference's BatchNorms are
+    pcdarts/operations.py:29,43,58,62,98 -- one process, so "the batch" is everything it is given).  ON: the trainable ResNet trunk
+    (resnet_ops.BnActFn in fp32, resnet_bf16 in bf16) all-reduces the per-channel fp64 sums -- (sum x, sum x^2) in the forward,
+    (sum g, sum g xhat) in the backward -- between its statistics kernels and their finish, so DP-N on batches of B/N equals ONE
+    process on the batch B (running statistics included, identical on every rank); dgamma / dbeta stay per-rank sums, the
+    gradient reducer averages them like every other parameter gradient.  OFF (default): per-rank statistics = N reference
+    processes with averaged gradients.  The fused PC-DARTS edges take their statistics inside the edge kernels and are not
+    covered (per-rank statistics; parallel.broadcast_buffers aligns the running estimates).  Returns the previous setting."""
+    prev = _sync_bn['on']
+    _sync_bn['on'], _sync_bn['group'] = bool(on), process_group
+    return prev
+
+
+def sync_bn_world():
+    """Ranks whose BatchNorm statistics are pooled (1 = SyncBN off or no process group)."""
+    if _sync_bn['on'] and dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(_sync_bn['group'])
+    return 1
+
+
+def sync_bn_all_reduce(t):
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_sync_bn['group'])
+    return t
 
 
 def make_flat_grad(params):

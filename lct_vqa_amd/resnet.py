@@ -239,7 +239,10 @@ class ResNet152Trunk(nn.Module):
                 if resnet_bf16.supported(self, image):                    # bf16 activations end to end (resnet_bf16.py)
                     return resnet_bf16.forward_trainable(self, image)
             return self._forward_trainable(image)
-        self._cache_ok = bool(self.cache_folded_weights)
+        # a trunk WITHOUT a trainable parameter is written by nobody between two forwards (the optimizer arena, multi_copy refills
+        # and the running-statistics kernels only touch trainable trunks; load_state_dict / copy_ move the version counters the
+        # cache key checks): fold once.  A trainable trunk evaluated under no_grad re-folds every call (see __init__).
+        self._cache_ok = bool(self.cache_folded_weights) or not trainable
         if not self._cache_ok and self._folded:
             self._folded.clear()
         if ops.get_compute_dtype() == 'bf16' and image.shape[1] == 3:

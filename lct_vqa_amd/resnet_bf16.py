@@ -9,29 +9,20 @@ where the gradient is produced (the GEMM epilogue) or consumed (the BatchNorm ba
 (conv_gemm_bf16 with BatchNorm statistics in its epilogue, wgrad_bf16 on transposed LDS reads, bn_bf16_*), csrc/conv3x3_bf16.hip
 (3x3 forward and, on flipped weights, data gradient), csrc/gemm_bf16.hip (stem on the matrix cores, pools)."""
 import torch
-import torch.distributed as dist
 
 from . import ops
 from ._lib import lib
 from .darts_ops import _scratch
 
-_sync_bn = {'on': False, 'group': None}
+from . import parallel
 
 
 def set_sync_bn(on=True, process_group=None):
-    """SyncBN for data-parallel training of this trunk (BN caveat): the per-channel (sum, sum of squares) of
-    the forward and (sum g, sum g z) of the backward are all-reduced over ``process_group`` inside the statistics finish, so DP-N
-    on batch B/N each equals one process at batch B.  Off by default (= N reference processes with averaged gradients).
-    Returns the previous setting."""
-    prev = _sync_bn['on']
-    _sync_bn['on'], _sync_bn['group'] = bool(on), process_group
-    return prev
+    """parallel.set_sync_bn (kept here for callers that only know this module)."""
+    return parallel.set_sync_bn(on, process_group)
 
 
-def _world():
-    if _sync_bn['on'] and dist.is_available() and dist.is_initialized():
-        return dist.get_world_size(_sync_bn['group'])
-    return 1
+_world = parallel.sync_bn_world
 
 
 def _bf16(shape, dev):
@@ -67,7 +58,7 @@ def bn_forward(z, part, n, bn, res, relu):
         world = _world()
         buf, f64, rows = _reduce_rows(part, n, C, dev, force=world > 1)
         if world > 1:
-            dist.all_reduce(buf, group=_sync_bn['group'])
+            parallel.sync_bn_all_reduce(buf)
         lib('bn_bf16_fwd_final', buf, f64, rows, C, float(P * world), float(bn.eps), float(bn.momentum), bn.weight, bn.bias, rm, rv, nbt, 1, coef)
     else:
         lib('bn_bf16_fwd_final', None, 0, 0, C, 1.0, float(bn.eps), 0.0, bn.weight, bn.bias, rm, rv, None, 0, coef)
@@ -93,7 +84,7 @@ def bn_backward(dy, ymask, z, coef, gamma, training, g_out=None, sink=(None, Non
     glob = None
     if world > 1:
         glob, _, _ = _reduce_rows(part, n, C, dev, force=True)
-        dist.all_reduce(glob, group=_sync_bn['group'])
+        parallel.sync_bn_all_reduce(glob)
     acc = sink[0] is not None and sink[1] is not None
     dgamma = sink[0] if acc else torch.empty(C, dtype=torch.float32, device=dev)
     dbeta = sink[1] if acc else torch.empty(C, dtype=torch.float32, device=dev)

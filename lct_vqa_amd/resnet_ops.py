@@ -4,7 +4,7 @@ BatchNorm fused with the ReLU / residual add that follows it (any channel count)
 1x1 convolutions are ``ops.linear`` on the rows, MaxPool(3,2,1) is ``darts_ops.Pool3x3Fn``, stride 2 is ``Subsample2Fn``."""
 import torch
 
-from . import ops
+from . import ops, parallel
 from ._lib import lib
 from .ops import _chk
 from .darts_ops import _scratch
@@ -27,17 +27,25 @@ class BnActFn(torch.autograd.Function):
         part = _scratch(lib.query('bn_wide_blocks', P) * C * 2, torch.float64, dev)
         res = _chk(residual) if residual is not None else None
         tr = bn.track_running_stats
-        lib('bn_wide_fwd', x, gamma, beta, bn.running_mean if tr else None, bn.running_var if tr else None,
-            bn.num_batches_tracked if tr else None, res, int(relu), y, stats[0], stats[1], part, P, C, int(training),
-            float(bn.momentum), float(bn.eps))
+        world = parallel.sync_bn_world() if training else 1
+        if world > 1:                                               # SyncBN: pool the per-channel sums of all ranks (parallel.set_sync_bn)
+            sums = torch.empty((C, 2), dtype=torch.float64, device=dev)
+            lib('bn_wide_sums', x, None, None, None, None, P, C, 0, part, sums)
+            parallel.sync_bn_all_reduce(sums)
+            lib('bn_wide_fwd_from_sums', x, sums, float(P * world), gamma, beta, bn.running_mean if tr else None, bn.running_var if tr else None,
+                bn.num_batches_tracked if tr else None, res, int(relu), y, stats[0], stats[1], P, C, float(bn.momentum), float(bn.eps))
+        else:
+            lib('bn_wide_fwd', x, gamma, beta, bn.running_mean if tr else None, bn.running_var if tr else None,
+                bn.num_batches_tracked if tr else None, res, int(relu), y, stats[0], stats[1], part, P, C, int(training),
+                float(bn.momentum), float(bn.eps))
         ctx.save_for_backward(x, y if relu else None, stats, gamma)
-        ctx.cfg = (int(training), residual is not None)
+        ctx.cfg = (int(training), residual is not None, world)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, stats, gamma = ctx.saved_tensors
-        training, has_res = ctx.cfg
+        training, has_res, world = ctx.cfg
         dy = _chk(dy)
         C = x.shape[-1]
         P = x.numel() // C
@@ -48,7 +56,13 @@ class BnActFn(torch.autograd.Function):
         db = torch.empty(C, dtype=torch.float32, device=dev)
         sums = _scratch(2 * C, torch.float32, dev)
         part = _scratch(lib.query('bn_wide_blocks', P) * C * 2, torch.float64, dev)
-        lib('bn_wide_bwd', dy, y, x, stats[0], stats[1], gamma, dx, dres, dg, db, sums, part, P, C, training)
+        if world > 1:
+            loc = torch.empty((C, 2), dtype=torch.float64, device=dev)
+            lib('bn_wide_sums', x, dy, y, stats[0], stats[1], P, C, 1, part, loc)
+            glob = parallel.sync_bn_all_reduce(loc.clone())
+            lib('bn_wide_bwd_from_sums', dy, y, x, stats[0], stats[1], gamma, loc, glob, float(P * world), dx, dres, dg, db, sums, P, C)
+        else:
+            lib('bn_wide_bwd', dy, y, x, stats[0], stats[1], gamma, dx, dres, dg, db, sums, part, P, C, training)
         return dx, dg, db, dres, None, None
 
 

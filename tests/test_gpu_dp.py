@@ -14,8 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _env(**extra):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', **extra)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
     env.pop('WORLD_SIZE', None)
+    env.update(extra)
     return env
 
 
@@ -90,3 +91,82 @@ def test_rccl_failure_is_loud(hip_lib):
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert 'only 1 GPUs are visible' in r.stderr or 'did not come up' in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_sync_bn_dp2_equals_the_single_process_batch(hip_lib, tmp_path, dtype):
+    """SyncBN (parallel.set_sync_bn; SURVEY.md section 8e BN caveat, reference BatchNorms pcdarts/operations.py:29,43,58,62,98): two ranks
+    on half batches with the per-channel sums all-reduced inside the statistics finish == ONE process on the full batch -- trunk
+    output, running statistics on both ranks, rank-averaged gradients (fp32 path: output and running statistics 1e-5, gradients 2e-5; bf16-native path: outputs up to a bf16
+    rounding, gradient cosine 0.99: its activations are bf16 and a pooled sum rounds differently from a single pass).  Both
+    ranks share the one GPU (gloo; RCCL refuses two ranks on a device)."""
+    script = tmp_path / 'syncbn.py'
+    script.write_text(textwrap.dedent('''
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        rank = int(os.environ['RANK'])
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=2)
+        from lct_vqa_amd import parallel, ops
+        from lct_vqa_amd.resnet import ResNet152Trunk
+        from lct_vqa_amd._lib import lib
+        lib.load()
+        dtype = %r
+        ops.set_compute_dtype(dtype)
+        B, S = 8, 64
+        g = torch.Generator().manual_seed(5)
+        img = torch.randn(B, 3, S, S, generator=g).cuda()
+        w = torch.randn(B, 2048, generator=g).cuda()
+        def run(m, x, wt, denom):
+            m.train()
+            y = m(x)
+            ((y * wt).sum() / denom).backward()
+            return y.detach()
+        torch.manual_seed(1)
+        ref = ResNet152Trunk((1, 1, 1, 1)).cuda()
+        for mod in ref.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.data.uniform_(0.75, 1.25); mod.bias.data.normal_(0, 0.1)
+        sd = {k: v.clone() for k, v in ref.state_dict().items()}
+        parallel.set_sync_bn(False)
+        y_full = run(ref, img, w, B)                                  # one process, whole batch
+        m = ResNet152Trunk((1, 1, 1, 1)).cuda()
+        m.load_state_dict(sd)
+        parallel.set_sync_bn(True)
+        lo, hi = rank * B // 2, (rank + 1) * B // 2
+        y = run(m, img[lo:hi], w[lo:hi], B // 2)
+        torch.cuda.synchronize()
+        def rel(a, b): return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+        def cos(a, b): return (a.double().flatten() @ b.double().flatten() / (a.double().norm() * b.double().norm()).clamp_min(1e-30)).item()
+        tol = 1e-5 if dtype == 'f32' else 1e-2
+        assert rel(y, y_full[lo:hi]) < tol, ('output', rel(y, y_full[lo:hi]))
+        for (n, b), (_, c) in zip(m.named_buffers(), ref.named_buffers()):
+            if 'running' in n:
+                assert rel(b, c) < (1e-5 if dtype == 'f32' else 1e-3), (n, rel(b, c))
+            else:
+                assert int(b) == int(c), n
+        worst = 0.0
+        for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+            gavg = p.grad.clone()
+            dist.all_reduce(gavg)
+            gavg /= 2
+            if dtype == 'f32':
+                assert rel(gavg, q.grad) < 2e-5, (n, rel(gavg, q.grad))
+            else:
+                assert cos(gavg, q.grad) > 0.99, (n, cos(gavg, q.grad))
+        # without SyncBN the same halves do NOT reproduce the full batch (the test would be vacuous otherwise)
+        m2 = ResNet152Trunk((1, 1, 1, 1)).cuda()
+        m2.load_state_dict(sd)
+        parallel.set_sync_bn(False)
+        y2 = run(m2, img[lo:hi], w[lo:hi], B // 2)
+        assert rel(y2, y_full[lo:hi]) > 10 * tol
+        dist.barrier()
+        dist.destroy_process_group()
+        print('SYNCBN_OK', rank)
+    ''' % (ROOT, dtype)))
+    port = '29547' if dtype == 'f32' else '29548'
+    procs = [subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=_env(RANK=str(r), WORLD_SIZE='2', MASTER_PORT=port)) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and 'SYNCBN_OK' in so, (so[-2000:], se[-4000:])
