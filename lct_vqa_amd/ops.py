@@ -758,8 +758,7 @@ def eval_multi_choice(logits, choices, unk_idx, counts=None):
 # accumulate flag), return None for that input and fire the parameter's post-accumulate-grad hooks themselves (the arena's
 # "reached" record, the data-parallel reducer's bucket counters).  OFF by default: it is only right under ``loss.backward()``;
 # ``torch.autograd.grad`` (the architects' bilevel.grads) must see the gradients as return values, so bilevel.grads suspends it.
-_grad_sink = {'on': False}
-_sink_tls = threading.local()
+_grad_sink = {'on': False, 'suspended': 0}
 
 
 def grad_sink(on=True):
@@ -772,18 +771,19 @@ def grad_sink(on=True):
 
 @contextlib.contextmanager
 def no_grad_sink():
-    """Suspend the sink (callers of torch.autograd.grad)."""
-    depth = getattr(_sink_tls, 'off', 0)
-    _sink_tls.off = depth + 1
+    """Suspend the sink (callers of torch.autograd.grad).  A process-wide counter, not a thread-local: the autograd engine runs the
+    backward nodes of a ROCm graph on its own worker thread, which must see the suspension of the thread that called it (one driver
+    thread per process: SURVEY.md section 8b, Threading)."""
+    _grad_sink['suspended'] += 1
     try:
         yield
     finally:
-        _sink_tls.off = depth
+        _grad_sink['suspended'] -= 1
 
 
 def sink_target(p):
     """``p.grad`` when a backward node may accumulate into it directly, else None (the node then returns the gradient)."""
-    if not _grad_sink['on'] or getattr(_sink_tls, 'off', 0) or p is None:
+    if not _grad_sink['on'] or _grad_sink['suspended'] or p is None:
         return None
     g = p.grad
     if g is None or g.dtype != torch.float32 or not g.is_cuda or g.shape != p.shape or not g.is_contiguous():

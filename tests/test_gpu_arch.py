@@ -167,6 +167,59 @@ def _arch_vqa_steps(m, fx, Architect, img, qst, lab, vimg, vqst, vlab):
         _check_arch_update(before, m.arch_parameters(), fx['arch'], fx[f'arch_after_{qst_only}'])
 
 
+def test_darts_vqa_architect_step_under_bf16(hip_lib):
+    """darts_vqa Architect.step (reference darts_vqa/pcdarts/architect_vqa.py:40-120) under ops.set_compute_dtype('bf16') -- BASELINE
+    configs[4] is a bf16 configuration -- against the reference's fp32 fixture.  Under this dtype the head GEMMs (image fc, LSTM input
+    projections, token head, fusion fc1 / fc2) multiply bf16 copies of their operands; the MixedOp edges, BatchNorm and the recurrence
+    stay fp32.  Stated tolerances (fp32 gates in brackets): direct term 5e-2 (1e-3) and alpha.grad 1e-1 (1e-3) of their largest entry;
+    the finite-difference term is a difference of two gradients 2R apart and inherits the bf16 rounding of BOTH divided by 2R, so it is
+    held to its sign pattern on the entries that matter (|entry| > 0.3 of the largest) and to 0.5 of the largest entry; alpha after the
+    Adam step: every entry whose reference gradient exceeds 0.2 of the largest moves the same way, within 0.1 lr."""
+    from lct_vqa_amd.darts_vqa import config, vqa_model
+    from lct_vqa_amd.basic_vqa import config as bconfig
+    config.DEVICE = bconfig.DEVICE = torch.device(DEV)
+    from lct_vqa_amd.darts_vqa.pcdarts.architect_vqa import Architect
+    from lct_vqa_amd import ops
+    fx = load('arch_vqa.pt')
+    torch.manual_seed(fx['seed'])
+    m = no_dropout(vqa_model.VqaModel(img_encoder_type='darts', **fx['dims']).to(DEV).train())
+    img, qst, lab = dev(fx['train'])
+    vimg, vqst, vlab = dev(fx['valid'])
+    prev = ops.set_compute_dtype('bf16')
+    try:
+        with ops.dropout_disabled():
+            for qst_only in (0, 1):
+                m.load_state_dict({**m.state_dict(), **{k: v.to(DEV) for k, v in fx[f'state_before_step_{qst_only}'].items()}})
+                for a, r in zip(m.arch_parameters(), fx['arch']):
+                    a.data.copy_(r)
+                    a.grad = None
+                args = types.SimpleNamespace(arch_learn_rate=6e-4, arch_wt_decay=1e-3, qst_only=bool(qst_only))
+                arch = Architect(m, args)
+                arch.trace = {}
+                arch.optimizer.zero_grad()
+                arch.compute_grads(img, qst, lab, vimg, vqst, vlab, 1e-3)
+                ref = fx[f'trace_{qst_only}']
+                close_arch(arch.trace['dalpha_direct'], ref['dalpha_direct'], 5e-2)
+                close_arch([a.grad for a in m.arch_parameters()], fx[f'arch_grads_{qst_only}'], 1e-1)
+                for a, r in zip(arch.trace['implicit'], ref['implicit']):
+                    big = r.abs() > 0.3 * r.abs().max()
+                    assert torch.equal(torch.sign(a.cpu()[big]), torch.sign(r[big]))
+                    assert (a.cpu() - r).abs().max().item() <= 0.5 * r.abs().max().item(), ((a.cpu() - r).abs().max().item(), r.abs().max().item())
+                before = [a.detach().clone() for a in m.arch_parameters()]
+                arch.optimizer.step()
+                moved = 0
+                for b, a, rb, ra, rg in zip(before, m.arch_parameters(), fx['arch'], fx[f'arch_after_{qst_only}'], fx[f'arch_grads_{qst_only}']):
+                    d, rd = (a.detach().cpu() - b.detach().cpu()), (ra - rb)
+                    eff = rg + 1e-3 * rb                            # Adam's first step is lr * sign(g + weight_decay * alpha):
+                    big = eff.abs() > 0.2 * eff.abs().max()        # only a clear effective gradient pins the sign
+                    assert torch.equal(torch.sign(d[big]), torch.sign(rd[big]))
+                    assert (d - rd)[big].abs().max().item() <= 0.1 * 6e-4
+                    moved += int(big.sum())
+                assert moved > 10
+    finally:
+        ops.set_compute_dtype(prev)
+
+
 def test_ef_darts_model_and_lct_architect(hip_lib):
     from lct_vqa_amd.basic_vqa import config, models, models_lct
     config.DEVICE = torch.device(DEV)

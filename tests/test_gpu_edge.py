@@ -151,7 +151,7 @@ def test_fused_edge_gradient_through_a_strided_slice_of_the_cell_output(hip_lib)
 def test_search_network_at_224_vs_oracle(hip_lib):
     """Network(16, 512, 4) (reference model_search.py:94-181) on a 224x224 batch of 2 against the CPU oracle (itself pinned to
     the reference's Network by tests/golden/darts_net.pt): eval output, train-mode output, alpha / beta gradients, the
-    gradients of a spread of weights from every cell, and every BatchNorm running statistic.  All 56 edges run the fused
+    gradient of EVERY parameter, and every BatchNorm running statistic.  All 56 edges run the fused
     kernels on maps of 224 / 112 / 56 pixels."""
     from lct_vqa_amd import darts_ops as D
     from lct_vqa_amd.basic_vqa import config
@@ -173,12 +173,8 @@ def test_search_network_at_224_vs_oracle(hip_lib):
     arch = [a.detach().cpu().clone() for a in net.arch_parameters()]
     img = torch.randn(2, 3, 224, 224, generator=g)
     wgt = torch.randn(2, 256 * 49, generator=g)
-    names = ['stem.0.weight', 'stem.1.weight', 'cells.0.preprocess1.op.1.weight', 'cells.0._ops.0._ops.4.op.1.weight',
-             'cells.0._ops.13._ops.7.op.2.weight', 'cells.1.preprocess0.op.1.weight', 'cells.1._ops.0._ops.3.conv_1.weight',
-             'cells.1._ops.1._ops.5.op.5.weight', 'cells.1._ops.9._ops.6.op.1.weight', 'cells.2.preprocess0.conv_2.weight',
-             'cells.2._ops.2._ops.4.op.6.weight', 'cells.2._ops.6._ops.5.op.2.weight', 'cells.3.preprocess0.conv_1.weight',
-             'cells.3._ops.5._ops.7.op.1.weight', 'cells.3._ops.13._ops.4.op.2.weight']
-    assert all(n in P for n in names)
+    names = [n for n, _ in net.named_parameters()]                 # EVERY parameter: 717 tensors, 158 496 entries
+    assert all(n in P for n in names) and len(names) > 700
     ref_ev = DO.network_forward(img, P, arch, False)
     Pg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in P.items()}
     ag = [a.clone().requires_grad_(True) for a in arch]
@@ -204,8 +200,19 @@ def test_search_network_at_224_vs_oracle(hip_lib):
     got = torch.autograd.grad((tr * wgt.to(DEV)).sum(), list(net.arch_parameters()) + [pd[n] for n in names])
     for a, r in zip(got[:4], ref_g[:4]):
         assert rel_err(a, r) < 1e-3
+    # every parameter gradient against the oracle's: within 1e-3 of the largest gradient entry of its own edge (MixedOp) -- the
+    # parameters of one edge share every pixel's ReLU / max-pool decisions --, of its own largest entry outside the edges
+    import re
+    group = lambda n_: (re.match(r'(cells\.\d+\._ops\.\d+)\.', n_) or re.match(r'(.*)', n_)).group(1)
+    scale = {}
+    for n, r in zip(names, ref_g[4:]):
+        scale[group(n)] = max(scale.get(group(n), 0.0), r.abs().max().item())
+    bad = []
     for n, a, r in zip(names, got[4:], ref_g[4:]):
-        assert rel_err(a, r) < 1e-3, n
+        err = (a.cpu() - r).abs().max().item()
+        if err > 1e-3 * scale[group(n)] + 1e-12:
+            bad.append((n, err, scale[group(n)]))
+    assert not bad, (len(bad), bad[:10])
     sd = net.state_dict()
     for k, v in ns.items():
         assert rel_err(sd[k], v) < 1e-4, k
