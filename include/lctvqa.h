@@ -418,6 +418,12 @@ int lctvqa_maxpool3x3_s2_bf16_bwd(const void* dy, const void* idx_u8, void* dx, 
 int lctvqa_upsample2_zero_bf16(const void* src, void* dst, int B, int H, int W, int C, void* stream);
 int lctvqa_global_avgpool_bf16_bwd(const float* dy, void* dx, int B, int HW, int C, void* stream);
 
+/* pieces of a trainable VGG19 trunk on bf16 activations (basic_vqa/models_lct.py:56-63): MaxPool2d(2,2); the backward of ReLU
+ * (-> MaxPool2d(2,2)) from the layer's post-ReLU output (first maximum of a window, like PyTorch); the backward of
+ * AdaptiveAvgPool2d((7,7)) + flatten (fp32 dy -> bf16 dx) */
+int lctvqa_maxpool2x2_bf16(const void* x, void* y, int B, int H, int W, int C, void* stream);
+int lctvqa_relu_pool_bwd_bf16(const void* d, const void* act, void* dz, int B, int H, int W, int C, int pool, void* stream);
+int lctvqa_adaptive_avgpool7_flatten_bwd_bf16(const float* dy, void* dx_nhwc_bf16, int B, int H, int W, int C, void* stream);
 /* ---- input pipeline, device side (data_loader_v2.py:53-55,82-86: ToTensor + Normalize done per sample on the host):
  *      uint8 HWC rows of the image store -> fp32 NCHW, y = (x/255 - mean[c]) / std[c] ---------------------------- */
 int lctvqa_image_u8_nhwc_to_f32_nchw(const uint8_t* x, float* y, int B, int H, int W, float m0, float m1, float m2,

@@ -795,6 +795,99 @@ __global__ void global_avgpool_bf16_bwd_kernel(const float* __restrict__ dy, uns
   }
 }
 
+// ---- trainable VGG trunk (reference basic_vqa/models_lct.py:56-63, pretrained=False) on bf16 activations ----
+// MaxPool2d(2, 2) on bf16 NHWC (floor: an odd last row / column is dropped)
+__global__ void maxpool2x2_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int B, int H, int W, int C8) {
+  const int Ho = H / 2, Wo = W / 2;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < (long)B * Ho * Wo * C8; o += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(o % C8);
+    long qq = o / C8;
+    const int ox = (int)(qq % Wo); qq /= Wo;
+    const int oy = (int)(qq % Ho);
+    const long n = qq / Ho;
+    const long base = ((n * H + 2 * oy) * W + 2 * ox) * C8 + c;
+    const us8 a = ((const us8*)x)[base], b = ((const us8*)x)[base + C8], cc = ((const us8*)x)[base + (long)W * C8], d = ((const us8*)x)[base + (long)W * C8 + C8];
+    us8 r;
+#pragma unroll
+    for (int e = 0; e < 8; e++) r[e] = f2bf(fmaxf(fmaxf(bf2f(a[e]), bf2f(b[e])), fmaxf(bf2f(cc[e]), bf2f(d[e]))));
+    ((us8*)y)[o] = r;
+  }
+}
+// Backward of (ReLU -> [MaxPool2d(2,2)]) in one pass: act = the conv layer's post-ReLU output [B,H,W,C].
+//   pool = 0: dz = d * (act > 0), d [B,H,W,C];   pool = 1: d [B,H/2,W/2,C] goes to the FIRST maximum of its 2x2 window (PyTorch's
+//   tie rule) where that maximum is positive; an odd last row / column gets zeros.  thread = (2x2 window | pixel, 8 channels).
+__global__ void relu_pool_bwd_bf16_kernel(const unsigned short* __restrict__ d, const unsigned short* __restrict__ act, unsigned short* __restrict__ dz,
+                                          int B, int H, int W, int C8, int pool) {
+  if (!pool) {
+    for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < (long)B * H * W * C8; o += (long)gridDim.x * blockDim.x) {
+      const us8 g = ((const us8*)d)[o], a = ((const us8*)act)[o];
+      us8 r;
+#pragma unroll
+      for (int e = 0; e < 8; e++) r[e] = bf2f(a[e]) > 0.f ? g[e] : (unsigned short)0;
+      ((us8*)dz)[o] = r;
+    }
+    return;
+  }
+  const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, Ho = H / 2, Wo = W / 2;     // windows incl. the dropped odd edge
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < (long)B * Hc * Wc * C8; o += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(o % C8);
+    long qq = o / C8;
+    const int ox = (int)(qq % Wc); qq /= Wc;
+    const int oy = (int)(qq % Hc);
+    const long n = qq / Hc;
+    const bool live = oy < Ho && ox < Wo;
+    us8 g = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (live) g = ((const us8*)d)[((n * Ho + oy) * Wo + ox) * C8 + c];
+    us8 a[4];
+    long pos[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int iy = 2 * oy + (k >> 1), ix = 2 * ox + (k & 1);
+      ok[k] = iy < H && ix < W;
+      pos[k] = ((n * H + iy) * W + ix) * C8 + c;
+      a[k] = ok[k] ? ((const us8*)act)[pos[k]] : us8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    us8 r[4];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      int best = 0;
+      float bv = bf2f(a[0][e]);
+#pragma unroll
+      for (int k = 1; k < 4; k++) {
+        const float v = bf2f(a[k][e]);
+        if (v > bv) { bv = v; best = k; }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) r[k][e] = (live && k == best && bv > 0.f) ? g[e] : (unsigned short)0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (ok[k]) ((us8*)dz)[pos[k]] = r[k];
+  }
+}
+// backward of AdaptiveAvgPool2d((7,7)) + flatten (torchvision's (c, y, x) feature order): fp32 dy [B][C*49] -> bf16 dx [B,H,W,C]
+__global__ void adaptive_avgpool7_flatten_bwd_bf16_kernel(const float* __restrict__ dy, unsigned short* __restrict__ dx, int B, int H, int W, int C) {
+  const long total = (long)B * H * W * C;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(o % C);
+    const long pix = o / C;
+    const int ix = (int)(pix % W), iy = (int)((pix / W) % H);
+    const long n = pix / ((long)W * H);
+    float a = 0.f;
+    for (int oy = 0; oy < 7; oy++) {
+      const int ys = (oy * H) / 7, ye = ((oy + 1) * H + 6) / 7;
+      if (iy < ys || iy >= ye) continue;
+      for (int ox = 0; ox < 7; ox++) {
+        const int xs = (ox * W) / 7, xe = ((ox + 1) * W + 6) / 7;
+        if (ix < xs || ix >= xe) continue;
+        a += dy[(n * C + c) * 49 + oy * 7 + ox] / (float)((ye - ys) * (xe - xs));
+      }
+    }
+    dx[o] = f2bf(a);
+  }
+}
+
 int gs_blocks_tb(long n, int cap = 16384) {
   long nb = (n + 255) / 256;
   if (nb > cap) nb = cap;
@@ -1057,6 +1150,27 @@ int lctvqa_global_avgpool_bf16_bwd(const float* dy, void* dx, int B, int HW, int
   hipLaunchKernelGGL(global_avgpool_bf16_bwd_kernel, dim3(gs_blocks_tb((long)B * HW * (C / 8))), dim3(256), 0, (hipStream_t)stream, dy,
                      (unsigned short*)dx, B, HW, C / 8);
   return lct_check_launch("global_avgpool_bf16_bwd");
+}
+
+int lctvqa_maxpool2x2_bf16(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+  LCT_REQUIRE(C % 8 == 0 && H >= 2 && W >= 2 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, "maxpool2x2_bf16: need C %% 8 == 0, aligned tensors");
+  hipLaunchKernelGGL(maxpool2x2_bf16_kernel, dim3(gs_blocks_tb((long)B * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)x, (unsigned short*)y, B, H, W, C / 8);
+  return lct_check_launch("maxpool2x2_bf16");
+}
+// dz [B,H,W,C] = backward of ReLU (-> MaxPool2d(2,2) when pool) given the layer's post-ReLU output `act` [B,H,W,C] and the gradient
+// d of what followed ([B,H,W,C], or [B,H/2,W/2,C] when pool)
+int lctvqa_relu_pool_bwd_bf16(const void* d, const void* act, void* dz, int B, int H, int W, int C, int pool, void* stream) {
+  LCT_REQUIRE(C % 8 == 0 && (((uintptr_t)d | (uintptr_t)act | (uintptr_t)dz) & 15) == 0, "relu_pool_bwd_bf16: need C %% 8 == 0, aligned tensors");
+  const long n = pool ? (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8) : (long)B * H * W * (C / 8);
+  hipLaunchKernelGGL(relu_pool_bwd_bf16_kernel, dim3(gs_blocks_tb(n)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)d,
+                     (const unsigned short*)act, (unsigned short*)dz, B, H, W, C / 8, pool);
+  return lct_check_launch("relu_pool_bwd_bf16");
+}
+int lctvqa_adaptive_avgpool7_flatten_bwd_bf16(const float* dy, void* dx_nhwc_bf16, int B, int H, int W, int C, void* stream) {
+  hipLaunchKernelGGL(adaptive_avgpool7_flatten_bwd_bf16_kernel, dim3(gs_blocks_tb((long)B * H * W * C, 8192)), dim3(256), 0, (hipStream_t)stream, dy,
+                     (unsigned short*)dx_nhwc_bf16, B, H, W, C);
+  return lct_check_launch("adaptive_avgpool7_flatten_bwd_bf16");
 }
 
 }  // extern "C"

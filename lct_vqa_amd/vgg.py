@@ -92,7 +92,20 @@ class VGG(nn.Module):
         # trainable trunk (reference models_lct.py:62-63): autograd through the HIP backward kernels
         plan = ['M' if isinstance(c, str) else 'C' for c in convs]
         params = [t for c in convs if not isinstance(c, str) for t in c]
-        h = ops.VggFeaturesFn.apply(x, plan, *params)
+        h = None
+        if ops.get_compute_dtype() == 'bf16' and x.dim() == 4 and x.shape[1] == 3:
+            # bf16 activations end to end (vgg_bf16.py) where the bf16 kernels tile every layer in both directions
+            from . import vgg_bf16
+            shapes, H, W = [], x.shape[2], x.shape[3]
+            for i, c in enumerate(convs):
+                if isinstance(c, str):
+                    H, W = H // 2, W // 2
+                else:
+                    shapes.append((c[0].shape[0], c[0].shape[1], H, W, i + 1 < len(convs) and isinstance(convs[i + 1], str)))
+            if vgg_bf16.plan_supported(shapes, x.shape[0]):
+                h = vgg_bf16.VggFeaturesBf16Fn.apply(x, plan, params, *params)
+        if h is None:
+            h = ops.VggFeaturesFn.apply(x, plan, *params)
         for (w, b, act, p) in fcs:
             train = p > 0
             m = ops.dropout_mask((h.shape[0], w.shape[0]), h.device, p) if train else None
