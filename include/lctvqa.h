@@ -157,6 +157,12 @@ int lctvqa_lstm_seq_fwd(const float* xp, const float* w_hh, const float* b_hh, f
                         float* wpack, int T, int B, int H, void* stream);
 int lctvqa_lstm_seq_bwd(float* dgates, const float* w_hh, const float* dout, const float* gates, const float* c_all,
                         float* dc_buf, float* wpack, int T, int B, int H, void* stream);
+/* the same two calls with the recurrent products h . W_hh^T and dg . W_hh on the bf16 matrix cores (operands rounded to bf16 per step,
+ * fp32 accumulation, fp32 gates and cell state): the bf16 compute dtype of BASELINE.json configs[2-4]; the greedy decode stays fp32 */
+int lctvqa_lstm_seq_fwd_bf16(const float* xp, const float* w_hh, const float* b_hh, float* h_all, float* c_all, float* gates,
+                        float* wpack, int T, int B, int H, void* stream);
+int lctvqa_lstm_seq_bwd_bf16(float* dgates, const float* w_hh, const float* dout, const float* gates, const float* c_all,
+                        float* dc_buf, float* wpack, int T, int B, int H, void* stream);
 /* greedy question generation (models_lct.py:124-157, darts_vqa/vqa_model.py:190-222) as one call: x_0 = tanh(emb[start]),
  * x_t = emb[pred_{t-1}]; (h,c) = LSTM step; pred_t = argmax(fc(tanh(h))).  h, c [B][H] in/out; tokens [B][L] int64 out;
  * scratch: lctvqa_lstm_decode_scratch_elems(B,H,We,QV) floats */

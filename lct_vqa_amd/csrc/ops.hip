@@ -824,7 +824,41 @@ __global__ void lstm_pack_whh_bwd_kernel(const float* __restrict__ w_hh, float* 
 // one time step on the packed weights.  Workgroup = 32 batch rows x 16 hidden units x 4 gates (two 32x32 accumulator
 // tiles per wave), the 4 waves split K = H into quarters of NG 16-deep groups; ALL of a wave's operand loads are issued
 // before its first MFMA (NG * 6 float4 registers), partial tiles meet in LDS, the cell update is the epilogue.
-template <int NG>
+// bf16 form of the packs (ops.set_compute_dtype('bf16'): the recurrent products on v_mfma_f32_32x32x16_bf16, fp32 accumulation,
+// fp32 state and gates): forward [H/16 unit tiles][H/16 k groups][2 tiles][64 lanes][8 bf16], lane (j, hh): k = grp*16 + 8hh + e;
+// backward [H/32 unit tiles][4H/64 super-groups][4 k16 groups][64 lanes][8 bf16], value[e] = W_hh[sg*64 + q*16 + 8hh + e][u0 + j]
+typedef __bf16 lstm_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ lstm_bf16x8 lstm_cvt8(const f32x4 a, const f32x4 b) {
+  return lstm_bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+}
+__global__ void lstm_pack_whh_fwd_bf16_kernel(const float* __restrict__ w_hh, lstm_bf16x8* __restrict__ p, int H) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int ng = H / 16;
+  if (idx >= (long)H * H / 2) return;                   // 4H*H values, 8 per lane
+  const int lane = idx & 63, tile = (idx >> 6) & 1;
+  const long rest = idx >> 7;
+  const int grp = rest % ng, ut = rest / ng;
+  const int j = lane & 31, hh = lane >> 5;
+  const int gate = tile * 2 + (j >> 4), unit = ut * 16 + (j & 15);
+  const float* src = w_hh + ((long)gate * H + unit) * H + grp * 16 + 8 * hh;
+  p[idx] = lstm_cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
+}
+__global__ void lstm_pack_whh_bwd_bf16_kernel(const float* __restrict__ w_hh, lstm_bf16x8* __restrict__ p, int H) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)H * H / 2) return;
+  const int nsg = 4 * H / 64;
+  const int lane = idx & 63, q = (idx >> 6) & 3;
+  const long rest = idx >> 8;
+  const int sg = rest % nsg, ut = rest / nsg;
+  const int j = lane & 31, hh = lane >> 5;
+  const int kc = sg * 64 + q * 16 + 8 * hh;
+  lstm_bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; e++) v[e] = (__bf16)w_hh[(long)(kc + e) * H + ut * 32 + j];
+  p[idx] = v;
+}
+
+template <int NG, bool BF16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void lstm_step2_kernel(const float* __restrict__ xp, const float* __restrict__ h_prev,
                                                          const float* __restrict__ c_prev, const float* __restrict__ wp,
                                                          const float* __restrict__ b_hh, float* __restrict__ gates,
@@ -843,10 +877,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int grp = wave * NG + n;
 #pragma unroll
     for (int kk = 0; kk < 2; kk++) {
-      A[n][kk] = *(const f32x4*)(h_prev + (long)arow * H + grp * 16 + (2 * kk + hh) * 4);
+      if (BF16) {                                       // A[n][0..1] = the lane's 8 consecutive h values, Bf[n][0][t] = 8 bf16 weights
+        A[n][kk] = *(const f32x4*)(h_prev + (long)arow * H + grp * 16 + 8 * hh + 4 * kk);
+        if (kk == 0) {
 #pragma unroll
-      for (int t = 0; t < 2; t++)
-        Bf[n][kk][t] = *(const f32x4*)(wp + (((((long)ut * NGRP + grp) * 2 + kk) * 2 + t) * 64 + lane) * 4);
+          for (int t = 0; t < 2; t++) Bf[n][0][t] = *(const f32x4*)(wp + ((((long)ut * NGRP + grp) * 2 + t) * 64 + lane) * 4);
+        }
+      } else {
+        A[n][kk] = *(const f32x4*)(h_prev + (long)arow * H + grp * 16 + (2 * kk + hh) * 4);
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+          Bf[n][kk][t] = *(const f32x4*)(wp + (((((long)ut * NGRP + grp) * 2 + kk) * 2 + t) * 64 + lane) * 4);
+      }
     }
   }
   // epilogue operands of this thread's two (row, unit) outputs, requested before the MFMAs
@@ -867,14 +909,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
   __builtin_amdgcn_sched_barrier(0);                    // keep every load above in front of the first MFMA
+  if (BF16) {
 #pragma unroll
-  for (int n = 0; n < NG; n++)
+    for (int n = 0; n < NG; n++) {
+      const lstm_bf16x8 a8 = lstm_cvt8(A[n][0], A[n][1]);
 #pragma unroll
-    for (int kk = 0; kk < 2; kk++)
+      for (int t = 0; t < 2; t++)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(lstm_bf16x8, Bf[n][0][t]), acc[t], 0, 0, 0);
+    }
+  } else {
 #pragma unroll
-      for (int e = 0; e < 4; e++)
+    for (int n = 0; n < NG; n++)
 #pragma unroll
-        for (int t = 0; t < 2; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[n][kk][e], Bf[n][kk][t][e], acc[t], 0, 0, 0);
+      for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+          for (int t = 0; t < 2; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[n][kk][e], Bf[n][kk][t][e], acc[t], 0, 0, 0);
+  }
 #pragma unroll
   for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -906,6 +958,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
 // BPTT step on the packed (transposed-fragment) weights: as lstm_step_bwd_fused_kernel, with 1-KB weight pieces and the
 // operands of two 64-deep super-groups in flight ahead of the MFMAs.
+template <bool BF16 = false>
 __global__ __launch_bounds__(256) void lstm_step2_bwd_kernel(const float* __restrict__ dg_t, const float* __restrict__ wp,
                                                              const float* __restrict__ dh_ext, const float* __restrict__ dc_next,
                                                              const float* __restrict__ gates_p, const float* __restrict__ c_pp,
@@ -923,20 +976,31 @@ __global__ __launch_bounds__(256) void lstm_step2_bwd_kernel(const float* __rest
   for (int r = 0; r < 16; r++) acc[r] = 0.f;
   const int arow = min(b0 + j, B - 1);
   const float* ap = dg_t + (long)arow * K;
-  const float* bp = wp + ((long)ut * nsg * 8 * 64 + lane) * 4;
+  const float* bp = wp + ((long)ut * nsg * (BF16 ? 4 : 8) * 64 + lane) * 4;
   f32x4 A0[8], A1[8], A2[8], B0[8], B1[8], B2[8];
   auto ld = [&](int sg, f32x4 (&A)[8], f32x4 (&Bf)[8]) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-      A[q] = *(const f32x4*)(ap + sg * 64 + (q >> 1) * 16 + (2 * (q & 1) + hh) * 4);
-      Bf[q] = *(const f32x4*)(bp + ((long)sg * 8 + q) * 256);
+      if (BF16) {                                       // A[2g], A[2g+1] = the lane's 8 consecutive dg values of k16 group g; Bf[g] = 8 bf16 weights
+        A[q] = *(const f32x4*)(ap + sg * 64 + (q >> 1) * 16 + 8 * hh + 4 * (q & 1));
+        if (q < 4) Bf[q] = *(const f32x4*)(bp + ((long)sg * 4 + q) * 256);
+      } else {
+        A[q] = *(const f32x4*)(ap + sg * 64 + (q >> 1) * 16 + (2 * (q & 1) + hh) * 4);
+        Bf[q] = *(const f32x4*)(bp + ((long)sg * 8 + q) * 256);
+      }
     }
   };
   auto mm = [&](const f32x4 (&A)[8], const f32x4 (&Bf)[8]) __attribute__((always_inline)) {
+    if (BF16) {
 #pragma unroll
-    for (int q = 0; q < 8; q++)
+      for (int g4 = 0; g4 < 4; g4++)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lstm_cvt8(A[2 * g4], A[2 * g4 + 1]), __builtin_bit_cast(lstm_bf16x8, Bf[g4]), acc, 0, 0, 0);
+    } else {
 #pragma unroll
-      for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[q][e], Bf[q][e], acc, 0, 0, 0);
+      for (int q = 0; q < 8; q++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[q][e], Bf[q][e], acc, 0, 0, 0);
+    }
   };
   int sg = wave;                                        // this wave's super-groups: wave, wave + 4, ...
   if (sg < nsg) ld(sg, A0, B0);
@@ -983,8 +1047,8 @@ extern "C" int lctvqa_lstm_seq_packed(int B, int H) { return (B >= 1 && (H == 64
 
 // h_all / c_all: [T+1][B][H] with slot 0 = the initial state (set by the caller); fills slots 1..T and gates [T][B][4H].
 // wpack: lctvqa_lstm_seq_scratch_elems(H) floats of scratch (untouched when the shape runs on the per-step kernels).
-extern "C" int lctvqa_lstm_seq_fwd(const float* xp, const float* w_hh, const float* b_hh, float* h_all, float* c_all, float* gates,
-                                   float* wpack, int T, int B, int H, void* stream) {
+static int lstm_seq_fwd_impl(const float* xp, const float* w_hh, const float* b_hh, float* h_all, float* c_all, float* gates,
+                             float* wpack, int T, int B, int H, int bf16, void* stream) {
   LCT_REQUIRE(T >= 1 && lctvqa_lstm_step_fused_supported(B, H), "lstm_seq_fwd: need T >= 1, H %% 32 == 0 (got T=%d H=%d)", T, H);
   LCT_REQUIRE((((uintptr_t)h_all | (uintptr_t)w_hh | (uintptr_t)wpack) & 15) == 0, "lstm_seq_fwd: h_all / w_hh / wpack must be 16-B aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -997,37 +1061,56 @@ extern "C" int lctvqa_lstm_seq_fwd(const float* xp, const float* w_hh, const flo
     }
     return 0;
   }
-  hipLaunchKernelGGL(lstm_pack_whh_fwd_kernel, dim3(cdiv((long)H * H, 256)), dim3(256), 0, st, w_hh, wpack, H);
+  if (bf16) hipLaunchKernelGGL(lstm_pack_whh_fwd_bf16_kernel, dim3(cdiv((long)H * H / 2, 256)), dim3(256), 0, st, w_hh, (lstm_bf16x8*)wpack, H);
+  else hipLaunchKernelGGL(lstm_pack_whh_fwd_kernel, dim3(cdiv((long)H * H, 256)), dim3(256), 0, st, w_hh, wpack, H);
   const dim3 grid(cdiv(B, 32) * (H / 16));
   for (int t = 0; t < T; t++) {
     const float *x = xp + t * 4 * BH, *hp = h_all + t * BH, *cp = c_all + t * BH;
     float *g = gates + t * 4 * BH, *co = c_all + (t + 1) * BH, *ho = h_all + (t + 1) * BH;
+#define LSTM_STEP(NGv)                                                                                                        \
+    if (bf16) hipLaunchKernelGGL((lstm_step2_kernel<NGv, true>), grid, dim3(256), 0, st, x, hp, cp, wpack, b_hh, g, co, ho, B); \
+    else hipLaunchKernelGGL((lstm_step2_kernel<NGv, false>), grid, dim3(256), 0, st, x, hp, cp, wpack, b_hh, g, co, ho, B);
     switch (H) {
-      case 64: hipLaunchKernelGGL(lstm_step2_kernel<1>, grid, dim3(256), 0, st, x, hp, cp, wpack, b_hh, g, co, ho, B); break;
-      case 128: hipLaunchKernelGGL(lstm_step2_kernel<2>, grid, dim3(256), 0, st, x, hp, cp, wpack, b_hh, g, co, ho, B); break;
-      case 256: hipLaunchKernelGGL(lstm_step2_kernel<4>, grid, dim3(256), 0, st, x, hp, cp, wpack, b_hh, g, co, ho, B); break;
-      default: hipLaunchKernelGGL(lstm_step2_kernel<8>, grid, dim3(256), 0, st, x, hp, cp, wpack, b_hh, g, co, ho, B); break;
+      case 64: LSTM_STEP(1) break;
+      case 128: LSTM_STEP(2) break;
+      case 256: LSTM_STEP(4) break;
+      default: LSTM_STEP(8) break;
     }
+#undef LSTM_STEP
   }
   return lct_check_launch("lstm_seq_fwd");
+}
+extern "C" int lctvqa_lstm_seq_fwd(const float* xp, const float* w_hh, const float* b_hh, float* h_all, float* c_all, float* gates,
+                                   float* wpack, int T, int B, int H, void* stream) {
+  return lstm_seq_fwd_impl(xp, w_hh, b_hh, h_all, c_all, gates, wpack, T, B, H, 0, stream);
+}
+// the same recurrence with the products h . W_hh^T on the bf16 matrix cores (h and W_hh rounded to bf16 per step, fp32 accumulation,
+// fp32 gates / cell state): the bf16 compute dtype of BASELINE.json's configurations 2-4; shapes outside the packed form run fp32
+extern "C" int lctvqa_lstm_seq_fwd_bf16(const float* xp, const float* w_hh, const float* b_hh, float* h_all, float* c_all, float* gates,
+                                        float* wpack, int T, int B, int H, void* stream) {
+  return lstm_seq_fwd_impl(xp, w_hh, b_hh, h_all, c_all, gates, wpack, T, B, H, 1, stream);
 }
 
 // Steps t = T-2 .. 0 of BPTT (step T-1 is the plain cell backward, lctvqa_lstm_cell_bwd, done by the caller into
 // dgates[T-1] and dc_buf[0]).  dout: dL/dh_t from the sequence output [T][B][H] or NULL.  dc_buf: [2][B][H]; step i reads
 // half i&1 and writes the other, so dL/dc_0's factor ends in half (T-1)&1.
-extern "C" int lctvqa_lstm_seq_bwd(float* dgates, const float* w_hh, const float* dout, const float* gates, const float* c_all,
-                                   float* dc_buf, float* wpack, int T, int B, int H, void* stream) {
+static int lstm_seq_bwd_impl(float* dgates, const float* w_hh, const float* dout, const float* gates, const float* c_all,
+                             float* dc_buf, float* wpack, int T, int B, int H, int bf16, void* stream) {
   LCT_REQUIRE(T >= 1 && lctvqa_lstm_step_fused_supported(B, H), "lstm_seq_bwd: need T >= 1, H %% 32 == 0 (got T=%d H=%d)", T, H);
   LCT_REQUIRE((((uintptr_t)dgates | (uintptr_t)wpack) & 15) == 0, "lstm_seq_bwd: dgates / wpack must be 16-B aligned");
   hipStream_t st = (hipStream_t)stream;
   const long BH = (long)B * H;
   const bool packed = lctvqa_lstm_seq_packed(B, H) && T > 1;
-  if (packed) hipLaunchKernelGGL(lstm_pack_whh_bwd_kernel, dim3(cdiv((long)H * H, 256)), dim3(256), 0, st, w_hh, wpack, H);
+  if (packed && bf16) hipLaunchKernelGGL(lstm_pack_whh_bwd_bf16_kernel, dim3(cdiv((long)H * H / 2, 256)), dim3(256), 0, st, w_hh, (lstm_bf16x8*)wpack, H);
+  else if (packed) hipLaunchKernelGGL(lstm_pack_whh_bwd_kernel, dim3(cdiv((long)H * H, 256)), dim3(256), 0, st, w_hh, wpack, H);
   for (int t = T - 2, i = 0; t >= 0; t--, i++) {
     const float* dext = dout ? dout + t * BH : nullptr;
     float *dcin = dc_buf + (i & 1) * BH, *dcout = dc_buf + ((i + 1) & 1) * BH;
-    if (packed) {
-      hipLaunchKernelGGL(lstm_step2_bwd_kernel, dim3(cdiv(B, 32) * (H / 32)), dim3(256), 0, st, dgates + (t + 1) * 4 * BH, wpack, dext,
+    if (packed && bf16) {
+      hipLaunchKernelGGL(lstm_step2_bwd_kernel<true>, dim3(cdiv(B, 32) * (H / 32)), dim3(256), 0, st, dgates + (t + 1) * 4 * BH, wpack, dext,
+                         dcin, gates + t * 4 * BH, c_all + t * BH, c_all + (t + 1) * BH, dgates + t * 4 * BH, dcout, B, H);
+    } else if (packed) {
+      hipLaunchKernelGGL(lstm_step2_bwd_kernel<false>, dim3(cdiv(B, 32) * (H / 32)), dim3(256), 0, st, dgates + (t + 1) * 4 * BH, wpack, dext,
                          dcin, gates + t * 4 * BH, c_all + t * BH, c_all + (t + 1) * BH, dgates + t * 4 * BH, dcout, B, H);
     } else {
       int rc = lctvqa_lstm_step_bwd_fused(dgates + (t + 1) * 4 * BH, w_hh, dext, dcin, gates + t * 4 * BH, c_all + t * BH,
@@ -1036,6 +1119,14 @@ extern "C" int lctvqa_lstm_seq_bwd(float* dgates, const float* w_hh, const float
     }
   }
   return lct_check_launch("lstm_seq_bwd");
+}
+extern "C" int lctvqa_lstm_seq_bwd(float* dgates, const float* w_hh, const float* dout, const float* gates, const float* c_all,
+                                   float* dc_buf, float* wpack, int T, int B, int H, void* stream) {
+  return lstm_seq_bwd_impl(dgates, w_hh, dout, gates, c_all, dc_buf, wpack, T, B, H, 0, stream);
+}
+extern "C" int lctvqa_lstm_seq_bwd_bf16(float* dgates, const float* w_hh, const float* dout, const float* gates, const float* c_all,
+                                        float* dc_buf, float* wpack, int T, int B, int H, void* stream) {
+  return lstm_seq_bwd_impl(dgates, w_hh, dout, gates, c_all, dc_buf, wpack, T, B, H, 1, stream);
 }
 
 // ------------------------------------------------------------------------------------------

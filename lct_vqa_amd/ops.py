@@ -311,7 +311,7 @@ class LSTMFn(torch.autograd.Function):
             c_all[0].copy_(c0.reshape(B, H))
         if lib.query('lstm_step_fused_supported', B, H):
             # the whole recurrence in one C call: W_hh packed once, one fused launch per time step
-            lib('lstm_seq_fwd', xp, w_hh, b_hh, h_all, c_all, gates, _lstm_scratch(B, H, dev), T, B, H)
+            lib('lstm_seq_fwd_bf16' if _compute_dtype == 'bf16' else 'lstm_seq_fwd', xp, w_hh, b_hh, h_all, c_all, gates, _lstm_scratch(B, H, dev), T, B, H)
         else:
             hp = torch.empty((B, 4 * H), dtype=torch.float32, device=dev)
             for t in range(T):
@@ -319,6 +319,7 @@ class LSTMFn(torch.autograd.Function):
                 lib('lstm_cell_fwd', xp[t], hp, c_all[t], gates[t], c_all[t + 1], h_all[t + 1], B, H)
         ctx.save_for_backward(x, w_ih, w_hh, gates, h_all, c_all)
         ctx.has_init = h0 is not None
+        ctx.bf16 = _compute_dtype == 'bf16'                       # the backward pass multiplies in the dtype the forward pass used
         return h_all[1:], h_all[T].clone(), c_all[T].clone()
 
     @staticmethod
@@ -337,7 +338,7 @@ class LSTMFn(torch.autograd.Function):
             dc_buf = torch.empty((2, B, H), dtype=torch.float32, device=dev)
             lib('lstm_cell_bwd', dh_rec, dout[T - 1] if dout is not None else None, dc, gates[T - 1],
                 c_all[T - 1], c_all[T], dgates[T - 1], dc_buf[0], B, H)
-            lib('lstm_seq_bwd', dgates, w_hh, dout, gates, c_all, dc_buf, _lstm_scratch(B, H, dev), T, B, H)
+            lib('lstm_seq_bwd_bf16' if ctx.bf16 else 'lstm_seq_bwd', dgates, w_hh, dout, gates, c_all, dc_buf, _lstm_scratch(B, H, dev), T, B, H)
             dc = dc_buf[(T - 1) & 1]
             if ctx.has_init:
                 dh_rec = linear_bwd_input(dgates[0], w_hh)

@@ -251,12 +251,10 @@ def test_darts_vqa_weight_step_bf16_vs_fp32(hip_lib, bf16_mode):
 
 def test_trainable_resnet_gru_bf16_vs_fp32(hip_lib, bf16_mode):
     """BASELINE configs[2] with the encoder TRAINED ('encoder trainable') under the bf16 dtype: the ResNet-152's 1x1
-    convolutions (forward, dX, dW: 40 % of the fp32 step) and the heads run on the bf16 GEMM, the 3x3 convolutions and the BatchNorms
-    stay fp32.  Forward + backward of the trainable path against the same in fp32, with the BatchNorms on (randomised) running
-    statistics: logits 5e-2, gradients of the heads within 1.5e-1, of trunk parameters from every stage within 3e-1 of their largest entry.  (With batch statistics
-    over a batch of 4 and 2x2 maps at the top -- the only sizes a unit test can afford -- the comparison is meaningless: the
-    statistics of 16 values amplify operand rounding until the stem's gradient differs by its own size, while the full-size bench
-    step agrees to 3e-5 in the loss: 7.49118 vs 7.49141.)"""
+    whole trunk runs bf16-native (resnet_bf16.py), the heads on the bf16 GEMM.  Forward + backward of the full-depth model against the
+    same in fp32, with the BatchNorms on (randomised) running statistics: logits 5e-2, gradients of the heads within 1.5e-1 of their
+    largest entry, of trunk parameters from every stage cosine >= 0.8.  (Batch-statistics BatchNorm at a size where it means something --
+    224^2, B = 8 -- is tests/test_gpu_train_bf16.py::test_trainable_trunk_bf16_batch_stat_bn_vs_oracles.)"""
     ops = bf16_mode
     from test_gpu_resnet import _randomise_bn
     from lct_vqa_amd.basic_vqa import models_ext, config
@@ -286,6 +284,12 @@ def test_trainable_resnet_gru_bf16_vs_fp32(hip_lib, bf16_mode):
     assert rel_err(y16, y32) < 5e-2 and abs(l16 - l32) < 1e-2 * abs(l32)
     for n, a, r in zip(names, g16, g32):
         assert torch.isfinite(a).all(), n
-        # the error grows with the number of bf16 products behind a gradient: heads 1.5e-1; inside the trunk (up to 150 layers of
-        # bf16-operand backward products and their ReLU masks; measured up to 1.7e-1) 3e-1
-        assert rel_err(a, r) < (3e-1 if '.model.' in n else 1.5e-1), (n, rel_err(a, r))
+        # heads: 1.5e-1 of the largest entry.  Inside the trunk the bf16-native path (round 4: bf16 activations end to end,
+        # resnet_bf16.py) is held to the gradient's direction, cosine >= 0.8 through up to 150 layers: bf16 storage flips the ReLU of
+        # pre-activations within one rounding of zero and each flip moves single entries by their own size (the tight pins of this
+        # path are tests/test_gpu_train_bf16.py: block level 1e-2 against the bf16-storage emulation of the fp32 oracle)
+        if '.model.' in n:
+            cos = (a.double().flatten() @ r.double().flatten() / (a.double().norm() * r.double().norm())).item()
+            assert cos > 0.8, (n, cos)
+        else:
+            assert rel_err(a, r) < 1.5e-1, (n, rel_err(a, r))

@@ -445,3 +445,38 @@ def test_shallow_vgg_stack_bf16_vs_fp32_path(hip_lib):
     assert rel_err(yb, y32) < 1e-2, rel_err(yb, y32)
     coss = [_cos(a, b) for a, b in zip(gb, g32)]
     assert min(coss) > 0.99, coss                                  # measured 0.9941 (first layer's weight) .. 0.9999
+
+
+@pytest.mark.parametrize('T,B,I,H', [(14, 256, 300, 512), (5, 33, 20, 64), (3, 70, 32, 256)])
+def test_lstm_bf16_recurrent_products_vs_fp32(hip_lib, T, B, I, H):
+    """nn.LSTM (reference basic_vqa/models.py:61, models_lct.py:107-108) under ops.set_compute_dtype('bf16'): the recurrent products
+    h . W_hh^T (forward) and dg . W_hh (BPTT) on the bf16 matrix cores with fp32 accumulation, fp32 gates and cell state
+    (lctvqa_lstm_seq_{fwd,bwd}_bf16), beside the bf16 input projection, against the fp32 path (itself pinned to torch.nn.LSTM and
+    the reference's goldens): outputs and final state 2e-2 of the largest entry, every gradient cosine >= 0.999 and 3e-2 relative L2."""
+    from lct_vqa_amd import ops
+    g = torch.Generator().manual_seed(T + H)
+    k = 1.0 / H ** 0.5
+    mk = lambda *s: ((torch.rand(*s, generator=g) * 2 - 1) * k).to(DEV).requires_grad_(True)
+    w_ih, w_hh, b_ih, b_hh = mk(4 * H, I), mk(4 * H, H), mk(4 * H), mk(4 * H)
+    x = torch.tanh(torch.randn(T, B, I, generator=g)).to(DEV).requires_grad_(True)
+    h0 = (torch.randn(B, H, generator=g) * 0.3).to(DEV).requires_grad_(True)
+    c0 = (torch.randn(B, H, generator=g) * 0.3).to(DEV).requires_grad_(True)
+    wo, wh, wc = (torch.randn(T, B, H, generator=g).to(DEV), torch.randn(B, H, generator=g).to(DEV), torch.randn(B, H, generator=g).to(DEV))
+    leaves = [x, w_ih, w_hh, b_ih, b_hh, h0, c0]
+
+    def run():
+        out, hT, cT = ops.lstm(x, w_ih, w_hh, b_ih, b_hh, h0, c0)
+        gr = torch.autograd.grad((out * wo).sum() + (hT * wh).sum() + (cT * wc).sum(), leaves)
+        return (out.detach(), hT.detach(), cT.detach()), gr
+    o32, g32 = run()
+    prev = ops.set_compute_dtype('bf16')
+    try:
+        ob, gb = run()
+        ob2, gb2 = run()
+    finally:
+        ops.set_compute_dtype(prev)
+    assert all(torch.equal(a, b) for a, b in zip(ob + tuple(gb), ob2 + tuple(gb2)))          # deterministic
+    for a, b in zip(ob, o32):
+        assert rel_err(a, b) < 2e-2, rel_err(a, b)
+    for n, a, b in zip(['x', 'w_ih', 'w_hh', 'b_ih', 'b_hh', 'h0', 'c0'], gb, g32):
+        assert _cos(a, b) > 0.999 and _l2(a, b) < 3e-2, (n, _cos(a, b), _l2(a, b))
