@@ -393,7 +393,7 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
  * (bf16 mask or NULL: the ReLU backward), out += addend (bf16 or NULL, may alias C).  stats (or NULL): per-slab column sums
  * (sum, sum of squares) of the fp32 result, [stats_slabs][2][N]: the BatchNorm statistics of the layer's output. */
 int lctvqa_conv_gemm_bf16_supported(long M, int N, int Cin, int taps);
-int lctvqa_conv_gemm_bf16_stats_slabs(long M, int N, int taps);
+int lctvqa_conv_gemm_bf16_stats_slabs(long M, int N, int Cin, int taps);
 int lctvqa_conv_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, long M, int N, int Cin, int taps, int H, int W,
                           const void* addend, long ld_add, const void* mask, long ld_mask, float* stats, void* stream);
 /* weight gradient dW (+)= sum_p dz[p][co] * x[p + tap][ci] (bf16 operands [P][ld], both pixel-strided: hardware transpose reads);

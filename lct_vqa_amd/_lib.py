@@ -95,10 +95,23 @@ class _Lib:
         conv = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
         if len(conv) == self._wants_stream[name] - 1:
             conv.append(_current_raw_stream())
+        if _TRACE:                                                  # LCTVQA_TRACE_CALLS=<file>: fault hunting -- name + arguments of every call,
+            _trace_call(name, args)                                 # the device drained after it: the last line names the kernel that faulted
         rc = fn(*conv)
+        if _TRACE:
+            torch.cuda.synchronize()
         if rc != 0 and fn.restype is ctypes.c_int:
             raise RuntimeError(f'lctvqa_{name} failed (rc={rc}): {self.last_error()}')
         return rc
+
+
+_TRACE = os.environ.get('LCTVQA_TRACE_CALLS')
+
+
+def _trace_call(name, args):
+    desc = [f'{tuple(a.shape)}:{str(a.dtype)[6:]}@{a.data_ptr():x}+{a.numel() * a.element_size()}' if isinstance(a, torch.Tensor) else repr(a) for a in args]
+    with open(_TRACE, 'a') as f:
+        f.write(name + ' ' + ' '.join(desc) + '\n')
 
 
 try:

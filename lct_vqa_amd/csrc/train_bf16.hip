@@ -178,6 +178,133 @@ __global__ __launch_bounds__(256, (TAPS == 1 && MT == 4) ? 3 : 2) void conv_gemm
   }
 }
 
+// ---- wide form of the 1x1 product for N % 256 == 0, K >= 256: 256 x 256 tile on EIGHT waves (2 x 4, wave tile 128 x 64 as above),
+// one workgroup per CU, D stages of LDS-DMA in flight with counted vmcnt (the form of wgrad_bf16_ring_kernel).  With 128 x 128 tiles
+// every operand byte of these products is staged 3-4 times through L2 (staged bytes = flops * 2 B / tile edge) and the K loop runs at one
+// memory latency per 32-deep step; here it is staged half as often and three stages are always in flight.  The n tiles of one m tile
+// are dealt to ONE XCD (blocks b and b + 8 share an XCD: speed only) so that they read the same A rows from that XCD's L2.
+template <int D>
+__global__ __launch_bounds__(512, 1) void conv_gemm_bf16_wide_kernel(const CgArgs a) {
+  constexpr int NI = 4;                                           // DMA instructions per wave and stage: 2 of A, 2 of B
+  constexpr int ASZ = 256 * 16, STG = 2 * ASZ;                    // floats: A tile [256 rows][64 B], then the B tile
+  static_assert(NI * (D - 1) <= 63, "vmcnt budget");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int j = lane & 31, h = lane >> 5;
+  const int NTL = a.N >> 8;
+  const int MTL = (a.M + 255) >> 8;
+  const int grp = blockIdx.x / (8 * NTL), rem = blockIdx.x % (8 * NTL);
+  const int m_tile = grp * 8 + (rem & 7), n_tile = rem >> 3;
+  if (m_tile >= MTL) return;                                      // uniform: the grid is rounded up to whole groups of 8 m tiles
+  const long m0 = (long)m_tile * 256;
+  const int n0 = n_tile * 256;
+  const int S = a.Cin >> 5;
+  const int rl = lane >> 2, sq = (lane & 3) ^ ((rl >> 2) & 3);
+  long aoff[2], boff[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const long row = m0 + 16 * (wave + 8 * r) + rl;
+    aoff[r] = row < a.M ? row * a.lda + sq * 8 : -1;
+    boff[r] = (long)(n0 + 16 * (wave + 8 * r) + rl) * a.ldb + sq * 8;
+  }
+  auto stage = [&](int s, float* buf) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const float* src = (aoff[r] >= 0 && s < S) ? (const float*)(a.A + aoff[r] + (long)s * 32) : g_zero_page_tb;
+      glds16_opaque(src, buf + (wave + 8 * r) * 256);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const float* src = s < S ? (const float*)(a.B + boff[r] + (long)s * 32) : g_zero_page_tb;
+      glds16_opaque(src, buf + ASZ + (wave + 8 * r) * 256);
+    }
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int nn = 0; nn < 2; nn++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][nn][r] = 0.f;
+  const int swz = (j >> 2) & 3;
+  const int fo[2] = {((0 + h) ^ swz) << 2, ((2 + h) ^ swz) << 2};
+  const int abase = (wm * 128 + j) * 16;
+  const int bbase = ASZ + (wn * 64 + j) * 16;
+#pragma unroll
+  for (int d = 0; d < D - 1; d++) stage(d, smem + d * STG);
+  for (int s = 0; s < S; s++) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (D - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    stage(s + D - 1, smem + ((s + D - 1) % D) * STG);
+    const float* ab = smem + (s % D) * STG + abase;
+    const float* bb = smem + (s % D) * STG + bbase;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      bf16x8 bf[2];
+#pragma unroll
+      for (int nn = 0; nn < 2; nn++) bf[nn] = __builtin_bit_cast(bf16x8, *(const f32x4*)(bb + nn * 512 + fo[kk]));
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const bf16x8 af = __builtin_bit_cast(bf16x8, *(const f32x4*)(ab + m * 512 + fo[kk]));
+#pragma unroll
+        for (int nn = 0; nn < 2; nn++) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nn], acc[m][nn], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the tail's zero-page DMAs
+  if (a.stats) {
+#pragma unroll
+    for (int nn = 0; nn < 2; nn++) {
+      float cs = 0.f, cq = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const float v = acc[m][nn][r]; cs += v; cq = fmaf(v, v, cq); }
+      cs += __shfl_xor(cs, 32, 64);
+      cq += __shfl_xor(cq, 32, 64);
+      if (h == 0) {
+        float* sp = a.stats + ((long)(m_tile * 2 + wm) * 2) * a.N + n0 + wn * 64 + nn * 32 + j;     // slab = 128 rows
+        sp[0] = cs;
+        sp[a.N] = cq;
+      }
+    }
+  }
+  constexpr int TS = 65;
+  float* T = smem + wave * 32 * TS;
+  const int tq = lane & 7, tp = lane >> 3;                        // 8 lanes x 16 B per row of 64 columns, 8 rows per store instruction
+  const int col0 = n0 + wn * 64 + 8 * tq;
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    __syncthreads();
+#pragma unroll
+    for (int nn = 0; nn < 2; nn++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) T[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + nn * 32 + j] = acc[m][nn][r];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int pr = tp + 8 * c;
+      const long row = m0 + wm * 128 + m * 32 + pr;
+      if (row < a.M) {
+        us8 av = {0, 0, 0, 0, 0, 0, 0, 0}, mv = av;
+        if (a.addend) av = *(const us8*)(a.addend + row * a.ld_add + col0);
+        if (a.mask) mv = *(const us8*)(a.mask + row * a.ld_mask + col0);
+        us8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          float v = T[pr * TS + 8 * tq + e];
+          if (a.mask) v = bf2f(mv[e]) > 0.f ? v : 0.f;
+          if (a.addend) v += bf2f(av[e]);
+          ov[e] = f2bf(v);
+        }
+        *(us8*)(a.C + row * a.ldc + col0) = ov;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // TN product (weight gradient).  Workgroup = 4 waves as WM x WN, wave tile 64 (co) x 64 (one column block: a tap and 64 input
 // channels); K step = 32 pixels.  LDS image of a step: 1-KB sub-tiles [16 pixels][32 channels] (one LDS-DMA instruction each: lane
@@ -911,6 +1038,14 @@ int lctvqa_conv_gemm_bf16_supported(long M, int N, int Cin, int taps) {
 }
 // rows per workgroup tile: 128 for the 1x1 products (95 VGPRs, 33 KB of LDS: four workgroups per CU cover each other's load
 // latency and store tails; these products are HBM-bound), 256 for the tap loop and the 64-column tiles
+// 1 when the wide (256 x 256, eight waves, ring) form takes the product
+static int cg_wide(long M, int N, int Cin, int taps) {
+  static const int forced = getenv("LCTVQA_CG_WIDE") ? atoi(getenv("LCTVQA_CG_WIDE")) : -1;
+  const bool able = taps == 1 && N % 256 == 0 && Cin >= 128 && M >= 1024;
+  if (forced >= 0) return forced && able;
+  return able && Cin >= 1024 && N == 256 && M >= 32768;           // the one ResNet shape family it wins on (14x14 1024->256: 42 vs 52 us);
+                                                                  // profiles/r04_conv_gemm_bf16_forms.txt has the whole A/B
+}
 static int cg_tile_rows(long M, int N, int taps) {
   static const int forced = getenv("LCTVQA_CG_ROWS") ? atoi(getenv("LCTVQA_CG_ROWS")) : 0;
   if (forced == 128 || forced == 256) return forced;
@@ -918,8 +1053,8 @@ static int cg_tile_rows(long M, int N, int taps) {
   return (taps == 1 && N > 64) ? 128 : 256;     // measured per shape at B = 256 (tools/bench_conv_gemm_bf16.py): 128 rows = 4 workgroups per CU
 }
 // slabs (rows) of the statistics buffer [slabs][2][N] for this product
-int lctvqa_conv_gemm_bf16_stats_slabs(long M, int N, int taps) {
-  const int bm = cg_tile_rows(M, N, taps);
+int lctvqa_conv_gemm_bf16_stats_slabs(long M, int N, int Cin, int taps) {
+  const int bm = cg_wide(M, N, Cin, taps) ? 256 : cg_tile_rows(M, N, taps);
   return (int)(2 * ((M + bm - 1) / bm));
 }
 // C[M][N] bf16 = sum_tap sum_ci A[row + tap][ci] * B[n][tap * Cin + ci]  (* mask, + addend); taps = 9: rows are pixels of
@@ -934,9 +1069,26 @@ int lctvqa_conv_gemm_bf16(const void* A, long lda, const void* B, long ldb, void
   LCT_REQUIRE(taps == 1 || (H >= 1 && W >= 1 && M % ((long)H * W) == 0), "conv_gemm_bf16: taps = 9 needs M = B*H*W");
   CgArgs a{(const unsigned short*)A, lda, (const unsigned short*)B, ldb, (unsigned short*)C, ldc, (int)M, N, Cin, taps, H, W,
            (const unsigned short*)addend, ld_add, (const unsigned short*)mask, ld_mask, stats};
+  hipStream_t st = (hipStream_t)stream;
+  if (cg_wide(M, N, Cin, taps)) {
+    static const int depth = getenv("LCTVQA_CG_WIDE_D") ? atoi(getenv("LCTVQA_CG_WIDE_D")) : 3;
+    const long mtl = (M + 255) / 256, groups = (mtl + 7) / 8;
+    const dim3 grid((unsigned)(groups * 8 * (N / 256)));
+    if (depth == 4) {
+      const size_t lds = (size_t)4 * 2 * 256 * 16 * sizeof(float);            // 128 KB
+      auto k = conv_gemm_bf16_wide_kernel<4>;
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k, grid, dim3(512), lds, st, a);
+    } else {
+      const size_t lds = (size_t)3 * 2 * 256 * 16 * sizeof(float);            // 96 KB (the epilogue's 8 x 32 x 65 floats fit inside)
+      auto k = conv_gemm_bf16_wide_kernel<3>;
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k, grid, dim3(512), lds, st, a);
+    }
+    return lct_check_launch("conv_gemm_bf16_wide");
+  }
   const int bm = cg_tile_rows(M, N, taps);
   const long mt = (M + bm - 1) / bm;
-  hipStream_t st = (hipStream_t)stream;
 #define CG_LAUNCH(NT2v, TAPSv, MTv)                                                                                \
   {                                                                                                               \
     size_t lds = (size_t)(2 * 64 * MTv * 16 + 2 * 64 * NT2v * 16) * sizeof(float);                                 \

@@ -117,7 +117,7 @@ def conv1x1(x2, wb, stats=True, addend=None, mask=None):
     y = _bf16((P, N), dev)
     st, n = None, 0
     if stats:
-        n = lib.query('conv_gemm_bf16_stats_slabs', P, N, 1)
+        n = lib.query('conv_gemm_bf16_stats_slabs', P, N, K, 1)
         st = _scratch(n * 2 * N, torch.float32, dev)
     ops._timed(f'gemm1x1_bf16_{K}->{N}', 2.0 * P * K * N, 2.0 * P * (K + N + (N if addend is not None else 0) + (N if mask is not None else 0)),
                lambda: lib('conv_gemm_bf16', x2, K, wb, K, y, N, P, N, K, 1, 0, 0, addend, N, mask, N, st))
@@ -167,7 +167,7 @@ class _Conv3x3:
                        lambda: lib('conv3x3_bf16_nhwc', x, wp, None, y, B, H, W, Cin, Cout, 0, 0))
         else:
             if stats:
-                n = lib.query('conv_gemm_bf16_stats_slabs', P, Cout, 9)
+                n = lib.query('conv_gemm_bf16_stats_slabs', P, Cout, Cin, 9)
                 st = _scratch(n * 2 * Cout, torch.float32, dev)
             ops._timed(f'conv3x3_gemm_bf16_{H}x{W}_{Cin}->{Cout}', 2.0 * P * Cout * Cin * 9, 2.0 * P * (Cin + Cout),
                        lambda: lib('conv_gemm_bf16', x, Cin, wp, 9 * Cin, y, Cout, P, Cout, Cin, 9, H, W, None, 0, mask, Cout, st))

@@ -27,13 +27,14 @@ def _close_bf16(out, ref, what, extra=2e-5):
     assert not bad.any(), f'{what}: {int(bad.sum())} of {bad.numel()} off, worst {((o - r).abs() / tol).max().item():.2f} tol'
 
 
-@pytest.mark.parametrize('M,N,K', [(256, 64, 64), (1000, 128, 64), (777, 256, 512), (3136, 64, 256), (513, 2048, 512)])
+@pytest.mark.parametrize('M,N,K', [(256, 64, 64), (1000, 128, 64), (777, 256, 512), (3136, 64, 256), (513, 2048, 512),
+                                   (4097, 256, 1024), (1300, 1024, 256), (2048, 512, 512), (12544, 2048, 512)])      # the last four: the wide (256 x 256, 8-wave ring) form
 def test_conv_gemm_1x1_stats_addend_mask(hip_lib, M, N, K):
     lib = hip_lib
     g = torch.Generator().manual_seed(M + N + K)
     A, Bm = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * 0.1)
     ref = A.double() @ Bm.double().t()
-    slabs = lib.query('conv_gemm_bf16_stats_slabs', M, N, 1)
+    slabs = lib.query('conv_gemm_bf16_stats_slabs', M, N, K, 1)
     st = torch.full((slabs, 2, N), float('nan'), device=DEV)
     C = torch.full((M, N), float('nan'), dtype=BF, device=DEV)
     lib('conv_gemm_bf16', A, K, Bm, K, C, N, M, N, K, 1, 0, 0, None, 0, None, 0, st)
@@ -61,7 +62,7 @@ def test_conv_gemm_3x3_taps_both_directions(hip_lib, B, H, W, Cin, Cout):
     wp = torch.empty(Cout * Cin * 9, dtype=BF, device=DEV)
     lib('pack3x3_taps_bf16', w, wp, Cout, Cin, 0)
     z = torch.full((B, H, W, Cout), float('nan'), dtype=BF, device=DEV)
-    slabs = lib.query('conv_gemm_bf16_stats_slabs', P, Cout, 9)
+    slabs = lib.query('conv_gemm_bf16_stats_slabs', P, Cout, Cin, 9)
     st = torch.empty((slabs, 2, Cout), device=DEV)
     lib('conv_gemm_bf16', x, Cin, wp, 9 * Cin, z, Cout, P, Cout, Cin, 9, H, W, None, 0, None, 0, st)
     ref = F.conv2d(x.double().permute(0, 3, 1, 2), wq, padding=1).permute(0, 2, 3, 1)

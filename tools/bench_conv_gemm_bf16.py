@@ -16,7 +16,7 @@ for H, K, N in shapes:
     w = torch.randn(N, K, device=DEV).to(BF)
     y = torch.empty(P, N, dtype=BF, device=DEV)
     aux = torch.randn(P, N, device=DEV).to(BF)
-    slabs = lib.query('conv_gemm_bf16_stats_slabs', P, N, 1)
+    slabs = lib.query('conv_gemm_bf16_stats_slabs', P, N, K, 1)
     st = torch.empty(slabs * 2 * N, device=DEV)
     for tag, add, msk, stats in (('fwd+stats', None, None, st), ('dgrad+mask', None, aux, None), ('dgrad+addend', aux, None, None)):
         f = lambda: lib('conv_gemm_bf16', x, K, w, K, y, N, P, N, K, 1, 0, 0, add, N, msk, N, stats)
