@@ -57,8 +57,13 @@ __global__ __launch_bounds__(256, (TAPS == 1 && MT == 4) ? 3 : 2) void conv_gemm
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int j = lane & 31, h = lane >> 5;
+  // the n tiles of one m tile read the same A rows: they are dealt to ONE XCD (blocks b and b + 8 share an XCD; speed only), so
+  // that A leaves HBM once instead of once per XCD (PMC, round 4: 2-3x the algorithmic bytes fetched with n tiles on consecutive blocks)
   const int NTL = a.N / BN;
-  const int n_tile = blockIdx.x % NTL, m_tile = blockIdx.x / NTL;
+  const int MTL = (a.M + BM - 1) / BM;
+  const int grp8 = blockIdx.x / (8 * NTL), rem8 = blockIdx.x % (8 * NTL);
+  const int m_tile = grp8 * 8 + (rem8 & 7), n_tile = rem8 >> 3;
+  if (m_tile >= MTL) return;                                      // uniform: the grid is rounded up to whole groups of 8 m tiles
   const long m0 = (long)m_tile * BM;
   const int n0 = n_tile * BN;
   const int spt = a.Cin >> 5;                                    // K steps per tap
@@ -319,6 +324,7 @@ struct WgArgs {
   int steps_per_split;                        // 32-pixel steps per split
   int ncb;                                    // column blocks = taps * Cin / 64
   int ntile_m, ntile_n;
+  int xcd_map;                                // two-stage form: deal the tiles of one pixel range to one XCD (1x1 products)
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* sub, int lane_off) {
@@ -339,13 +345,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_tn_kernel(const WgArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int ntiles = a.ntile_m * a.ntile_n;
-  const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+  // the tiles of one pixel range read the same dz / x rows: XCD = blockIdx % 8 owns the splits = XCD (mod 8) (as in the ring form)
+  // (for the 1x1 products: PMC showed 2.6x the algorithmic bytes fetched otherwise; the nine taps of a 3x3 product stage every x row
+  // nine times, which one XCD's L2 cannot feed: there the tiles of a pixel range stay spread over all eight)
+  const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+  const int tile = a.xcd_map ? qq % ntiles : blockIdx.x % ntiles;
+  const int split = a.xcd_map ? (qq / ntiles) * 8 + xcd : blockIdx.x / ntiles;
   const int tile_m = tile % a.ntile_m, tile_n = tile / a.ntile_m;
   const int cpb = a.Cin >> 6;                                     // column blocks per tap
   const int steps_total = (a.P + 31) >> 5;
   const int s_begin = split * a.steps_per_split;
   const int s_end = min(steps_total, s_begin + a.steps_per_split);
   const int S = s_end - s_begin;
+  if (S <= 0) return;                                             // uniform: the grid rounds the splits up to a multiple of 8
   // this lane's two pixel rows of a step (rh = 0, 1) and their image coordinates
   const int prl = lane >> 2, slot = lane & 3;
   long p_cur[2];
@@ -1096,7 +1108,7 @@ int lctvqa_conv_gemm_bf16(const void* A, long lda, const void* B, long ldb, void
     if (lds < epi) lds = epi;                                                                                      \
     auto k = conv_gemm_bf16_kernel<NT2v, TAPSv, MTv>;                                                               \
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-    hipLaunchKernelGGL(k, dim3((unsigned)(mt * (N / (64 * NT2v)))), dim3(256), lds, st, a);                        \
+    hipLaunchKernelGGL(k, dim3((unsigned)(((mt + 7) / 8) * 8 * (N / (64 * NT2v)))), dim3(256), lds, st, a);        \
   }
   if (bm == 128) { if (N % 128 == 0) CG_LAUNCH(2, 1, 2) else CG_LAUNCH(1, 1, 2) }
   else if (N % 128 == 0) { if (taps == 1) CG_LAUNCH(2, 1, 4) else CG_LAUNCH(2, 9, 4) }
@@ -1125,6 +1137,7 @@ static void wgrad_plan(long P, int Cout, int Cin, int taps, int* wm, int* ntm, i
   if (mode == 2 || mode == 4) {
     long s = (mode == 2 ? 1024 : 512) / tiles;
     if (s > steps_total / 8) s = steps_total / 8;
+    if (s >= 8 && taps == 1) s = (s / 8) * 8;                     // whole groups of 8: every XCD owns the same number of splits
     if (s < 1) s = 1;
     *sps = (int)((steps_total + s - 1) / s);
     *splits = (steps_total + *sps - 1) / *sps;
@@ -1155,9 +1168,9 @@ int lctvqa_wgrad_bf16(const void* dz, long ldz, const void* x, long ldx, long P,
   wgrad_plan(P, Cout, Cin, taps, &wm, &ntm, &ntn, &splits, &sps);
   LCT_REQUIRE(workspace && workspace_bytes >= (long)splits * taps * Cout * Cin * (long)sizeof(float), "wgrad_bf16: workspace too small");
   WgArgs a{(const unsigned short*)dz, ldz, (const unsigned short*)x, ldx, workspace, (int)P, Cout, Cin, taps, H > 0 ? H : 1, W > 0 ? W : 1, sps,
-           taps * (Cin / 64), ntm, ntn};
+           taps * (Cin / 64), ntm, ntn, taps == 1 ? 1 : 0};
   hipStream_t st = (hipStream_t)stream;
-  const unsigned grid = (unsigned)((long)ntm * ntn * splits);
+  const unsigned grid = (unsigned)((long)ntm * ntn * (((splits + 7) / 8) * 8));       // both forms deal splits to XCDs in groups of 8
   int live = splits;                                              // slabs that are written (splits beyond the pixel range are not)
   const int mode = wgrad_mode(P, taps);
 #define WG_RING(WMv, WNv, Dv)                                                                                    \
