@@ -398,7 +398,7 @@ int lctvqa_conv_gemm_bf16(const void* A, long lda, const void* B, long ldb, void
                           const void* addend, long ld_add, const void* mask, long ld_mask, float* stats, void* stream);
 /* weight gradient dW (+)= sum_p dz[p][co] * x[p + tap][ci] (bf16 operands [P][ld], both pixel-strided: hardware transpose reads);
  * dW fp32 [Cout][Cin] (taps 1) or OIHW [Cout][Cin][3][3] (taps 9); split over the pixels into fp32 slabs in `workspace` */
-long lctvqa_wgrad_bf16_workspace_bytes(long P, int Cout, int Cin, int taps);
+long lctvqa_wgrad_bf16_workspace_bytes(long P, int Cout, int Cin, int taps, int H, int W);
 int lctvqa_wgrad_bf16(const void* dz, long ldz, const void* x, long ldx, long P, int Cout, int Cin, int taps, int H, int W, float* dW,
                       int accumulate, float* workspace, long workspace_bytes, void* stream);
 /* fp32 OIHW [Cout][Cin][3][3] -> bf16 [Cout][tap][Cin] (the B operand of conv_gemm_bf16 with taps 9); dgrad: [Cin][tap][Cout], taps flipped */

@@ -601,6 +601,110 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_ring_kernel(const WgArgs a)
   }
 }
 
+// ---- 3x3 weight gradient on 2-D pixel patches (round 4).  The tap-as-column-block form above stages every x row nine times (once per
+// tap) and a dz row once per (tap, ci block): 16 KB of LDS-DMA per 32 MFMAs, and LDS-DMA delivers only about the HBM rate per CU.  Here
+// a K step is a PATCH of PH x PWV output pixels (k = py * PWS + px; slots px >= PWV are zero rows of dz) and the x operand is the
+// patch's (PH+2) x (PWV+2) halo, staged ONCE (image borders read the zero page at staging time): the nine taps are nine constant row
+// offsets dy * (PWV+2) + dx into the same LDS image, taken by the per-lane row addresses of ds_read_b64_tr_b16.  Workgroup = 64 co x 64
+// ci x 9 taps (2 x 2 waves, nine 32x32 accumulators each); 12 KB staged per 72 MFMAs.
+struct Wg3Args {
+  const unsigned short* dZ; long ldz;
+  const unsigned short* X; long ldx;
+  float* slabs;                               // [splits][9][Cout][Cin]
+  int B, H, W, Cout, Cin;
+  int patches_per_split, npatch, pby, pbx;    // patches per image row band / per image: pby = H / PH, pbx = W / PWV
+};
+
+template <int PH, int PWS, int PWV>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const Wg3Args a) {
+  static_assert(PH * PWS == 32 && PWV <= PWS && (PH + 2) * (PWV + 2) <= 64 && PWS % 4 == 0, "patch shape");
+  constexpr int HW_ = PWV + 2;                                    // halo row length
+  constexpr int STAGE = 12 * 1024, XB = 4 * 1024;                 // bytes: dz sub-tiles (rh, c32), then x [2 ch halves][64 halo pixels][64 B]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntm = a.Cout >> 6, ntiles = ntm * (a.Cin >> 6);
+  const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;           // the tiles of one patch range on one XCD (speed only)
+  const int tile = qq % ntiles, split = (qq / ntiles) * 8 + xcd;
+  const int co0 = (tile % ntm) << 6, ci0 = (tile / ntm) << 6;
+  const int t_begin = split * a.patches_per_split;
+  const int t_end = min(a.npatch, t_begin + a.patches_per_split);
+  const int S = t_end - t_begin;
+  if (S <= 0) return;
+  const int prl = lane >> 2, slot = lane & 3;
+  const int ppi = a.pby * a.pbx;
+  auto stage = [&](int t, unsigned char* buf) {
+    const int n = t / ppi, rem = t - n * ppi;
+    const int y0 = (rem / a.pbx) * PH, x0 = (rem % a.pbx) * PWV;
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int i = wave + 4 * jj;                                // wave-uniform
+      const float* src = g_zero_page_tb;
+      if (i < 4) {
+        const int rh = i >> 1, c32 = i & 1;
+        const int k = 16 * rh + prl, py = k / PWS, px = k % PWS;
+        if (px < PWV) src = (const float*)(a.dZ + ((long)(n * a.H + y0 + py) * a.W + x0 + px) * a.ldz + co0 + 32 * c32 + 8 * slot);
+      } else {
+        const int ix = i - 4, c32 = ix >> 2, hr = 16 * (ix & 3) + prl;
+        const int hy = hr / HW_, hx = hr % HW_;
+        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+        if (hr < (PH + 2) * HW_ && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
+          src = (const float*)(a.X + ((long)(n * a.H + yy) * a.W + xx) * a.ldx + ci0 + 32 * c32 + 8 * slot);
+      }
+      glds16(src, (float*)(buf + i * 1024));
+    }
+  };
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int coloff = (16 * (g & 1) + 4 * pp) * 2;
+  const int a_off = (8 * (g >> 1) + q) * 64 + coloff;             // dz: row 8h + q of a 16-pixel sub-tile (+256: rows +4)
+  int b_off[2][2];                                                // x: halo pixel of k = 16 kk + 8h + q (+4), tap (0, 0)
+#pragma unroll
+  for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int k = 16 * kk + 8 * (g >> 1) + q + 4 * u;
+      const int py = k / PWS, px = min(k % PWS, PWV - 1);         // padded slots: any in-range halo pixel (their dz rows are zero)
+      b_off[kk][u] = XB + wn * 4096 + ((py + 1) * HW_ + px + 1) * 64 + coloff;
+    }
+  stage(t_begin, smem_raw);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int s = 0; s < S; s++) {
+    if (s + 1 < S) stage(t_begin + s + 1, smem_raw + ((s + 1) & 1) * STAGE);
+    const unsigned char* sb = smem_raw + (s & 1) * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      const bf16x8 af = tr_frag(sb + ((kk * 2 + wm) << 10), a_off);
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const int d = ((t / 3 - 1) * HW_ + (t % 3 - 1)) * 64;     // compile-time row shift of the tap
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sb + b_off[kk][0] + d));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sb + b_off[kk][1] + d));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, v), acc[t], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 9; t++) {
+    float* out = a.slabs + ((long)split * 9 + t) * a.Cout * a.Cin;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int co = co0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+      out[(long)co * a.Cin + ci0 + 32 * wn + j] = acc[t][r];
+    }
+  }
+}
+
 // out[co][ci][tap] (OIHW when taps == 9, [co][ci] when taps == 1) (+)= sum over splits of slabs[split][tap][co][ci]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, int taps, int Cout, int Cin, float* __restrict__ out, int accumulate) {
   // thread = 4 consecutive (tap, co, ci) entries (Cin % 64 == 0: never across a row); the slab loop keeps 8 independent 16-byte
@@ -1125,6 +1229,27 @@ static int wgrad_mode(long P, int taps) {
   if (forced) return forced;
   return (taps == 1 && P >= 150000) ? 3 : 2;                     // measured per shape at B = 256: profiles/r04_wgrad_bf16_forms.txt
 }
+// patch form of the 3x3 weight gradient: (PH, PWS, PWV) by map size, 0 when no patch shape tiles the map
+static int wg3_shape(int H, int W, int Cout, int Cin, int taps) {
+  static const int off = getenv("LCTVQA_WGRAD3_OFF") != nullptr;
+  if (off || taps != 9 || Cout % 64 || Cin % 64 || H < 1 || W < 1) return 0;
+  if (H % 4 == 0 && W % 8 == 0) return 1;                         // 4 x 8 patches
+  if (H % 4 == 0 && W % 7 == 0) return 2;                         // 4 x 7 of 8 slots (28 x 28)
+  if (H % 2 == 0 && W % 14 == 0) return 3;                        // 2 x 14 of 16 slots (14 x 14)
+  return 0;
+}
+static void wg3_plan(long P, int H, int W, int Cout, int Cin, int shape, int* npatch, int* pps, int* splits) {
+  const int ph = shape == 3 ? 2 : 4, pwv = shape == 1 ? 8 : (shape == 2 ? 7 : 14);
+  const long B = P / ((long)H * W);
+  *npatch = (int)(B * (H / ph) * (W / pwv));
+  const long tiles = (long)(Cout / 64) * (Cin / 64);
+  long s = 512 / tiles;                                           // about two workgroups per CU
+  if (s > *npatch / 8) s = *npatch / 8;
+  s = (s / 8) * 8;
+  if (s < 8) s = 8;
+  *pps = (int)((*npatch + s - 1) / s);
+  *splits = (int)s;
+}
 static void wgrad_plan(long P, int Cout, int Cin, int taps, int* wm, int* ntm, int* ntn, int* splits, int* sps) {
   *wm = Cout >= 128 ? 2 : 1;
   const int wn = 4 / *wm;
@@ -1150,9 +1275,15 @@ static void wgrad_plan(long P, int Cout, int Cin, int taps, int* wm, int* ntm, i
   *sps = (int)((steps_total + s - 1) / s);
   *splits = (int)s;
 }
-long lctvqa_wgrad_bf16_workspace_bytes(long P, int Cout, int Cin, int taps) {
+long lctvqa_wgrad_bf16_workspace_bytes(long P, int Cout, int Cin, int taps, int H, int W) {
   int wm, ntm, ntn, splits, sps;
-  wgrad_plan(P, Cout, Cin, taps, &wm, &ntm, &ntn, &splits, &sps);
+  const int shape = wg3_shape(H, W, Cout, Cin, taps);
+  if (shape) {
+    int npatch, pps;
+    wg3_plan(P, H, W, Cout, Cin, shape, &npatch, &pps, &splits);
+  } else {
+    wgrad_plan(P, Cout, Cin, taps, &wm, &ntm, &ntn, &splits, &sps);
+  }
   return (long)splits * taps * Cout * Cin * (long)sizeof(float);
 }
 // dW (+)= sum_p dz[p][co] * x[p + tap][ci]: dW fp32 [Cout][Cin] (taps = 1) or OIHW [Cout][Cin][3][3] (taps = 9; rows are pixels
@@ -1165,11 +1296,36 @@ int lctvqa_wgrad_bf16(const void* dz, long ldz, const void* x, long ldx, long P,
               "wgrad_bf16: operands must be 16-byte aligned bf16 rows");
   LCT_REQUIRE(taps == 1 || (H >= 1 && W >= 1 && P % ((long)H * W) == 0), "wgrad_bf16: taps = 9 needs P = B*H*W");
   int wm, ntm, ntn, splits, sps;
+  hipStream_t st = (hipStream_t)stream;
+  const int shape = wg3_shape(H, W, Cout, Cin, taps);
+  if (shape) {
+    int npatch, pps;
+    wg3_plan(P, H, W, Cout, Cin, shape, &npatch, &pps, &splits);
+    LCT_REQUIRE(workspace && workspace_bytes >= (long)splits * 9 * Cout * Cin * (long)sizeof(float), "wgrad_bf16: workspace too small");
+    const int ph = shape == 3 ? 2 : 4, pwv = shape == 1 ? 8 : (shape == 2 ? 7 : 14);
+    Wg3Args g{(const unsigned short*)dz, ldz, (const unsigned short*)x, ldx, workspace, (int)(P / ((long)H * W)), H, W, Cout, Cin, pps, npatch,
+              H / ph, W / pwv};
+    const unsigned grid3 = (unsigned)((long)(Cout / 64) * (Cin / 64) * splits);
+    const size_t lds3 = 2 * 12 * 1024;
+#define WG3(PHv, PWSv, PWVv)                                                                                   \
+    {                                                                                                          \
+      auto k = wgrad3x3_bf16_kernel<PHv, PWSv, PWVv>;                                                            \
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);         \
+      hipLaunchKernelGGL(k, dim3(grid3), dim3(256), lds3, st, g);                                               \
+    }
+    if (shape == 1) WG3(4, 8, 8) else if (shape == 2) WG3(4, 8, 7) else WG3(2, 16, 14)
+#undef WG3
+    int rc3 = lct_check_launch("wgrad3x3_bf16");
+    if (rc3) return rc3;
+    const int live3 = (npatch + pps - 1) / pps;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gs_blocks_tb((long)9 * Cout * Cin, 4096)), dim3(256), 0, st, workspace, live3, 9, Cout, Cin, dW,
+                       accumulate);
+    return lct_check_launch("wgrad_reduce");
+  }
   wgrad_plan(P, Cout, Cin, taps, &wm, &ntm, &ntn, &splits, &sps);
   LCT_REQUIRE(workspace && workspace_bytes >= (long)splits * taps * Cout * Cin * (long)sizeof(float), "wgrad_bf16: workspace too small");
   WgArgs a{(const unsigned short*)dz, ldz, (const unsigned short*)x, ldx, workspace, (int)P, Cout, Cin, taps, H > 0 ? H : 1, W > 0 ? W : 1, sps,
            taps * (Cin / 64), ntm, ntn, taps == 1 ? 1 : 0};
-  hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((long)ntm * ntn * (((splits + 7) / 8) * 8));       // both forms deal splits to XCDs in groups of 8
   int live = splits;                                              // slabs that are written (splits beyond the pixel range are not)
   const int mode = wgrad_mode(P, taps);

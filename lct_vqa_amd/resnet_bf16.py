@@ -129,7 +129,7 @@ def wgrad(dz2, x2, Cout, Cin, taps=1, H=0, W=0, sink=None):
     (ops.grad_sink; None is returned then)."""
     P = dz2.shape[0]
     dev = dz2.device
-    need = lib.query('wgrad_bf16_workspace_bytes', P, Cout, Cin, taps)
+    need = lib.query('wgrad_bf16_workspace_bytes', P, Cout, Cin, taps, H, W)
     ws = ops._workspace(need, dev)
     dW = sink if sink is not None else torch.empty((Cout, Cin, 3, 3) if taps == 9 else (Cout, Cin, 1, 1), dtype=torch.float32, device=dev)
     ops._timed(f'wgrad_bf16_{taps}x_{Cin}->{Cout}', 2.0 * P * Cout * Cin * taps, 2.0 * P * (Cout + Cin),

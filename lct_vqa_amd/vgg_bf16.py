@@ -124,7 +124,7 @@ class VggFeaturesBf16Fn(torch.autograd.Function):
                 x_in = acts[li - 1]
             give(2 * li + 1, _colsum_bf16(dz.view(P, Cout), Cout))
             tgt = ops.sink_target(prm[2 * li])
-            need = lib.query('wgrad_bf16_workspace_bytes', P, Cout, Cin, 9)
+            need = lib.query('wgrad_bf16_workspace_bytes', P, Cout, Cin, 9, H, W)
             ws = ops._workspace(need, dev)
             dw = tgt if tgt is not None else torch.empty_like(w)
             ops._timed(f'wgrad_bf16_9x_{Cin}->{Cout}', 2.0 * P * Cout * Cin * 9, 2.0 * P * (Cout + Cin),

@@ -103,7 +103,7 @@ def test_wgrad_1x1(hip_lib, P, Cout, Cin):
     lib = hip_lib
     g = torch.Generator().manual_seed(P + Cout)
     dz, x = _bf(torch.randn(P, Cout, generator=g)), _bf(torch.randn(P, Cin, generator=g))
-    need = lib.query('wgrad_bf16_workspace_bytes', P, Cout, Cin, 1)
+    need = lib.query('wgrad_bf16_workspace_bytes', P, Cout, Cin, 1, 0, 0)
     ws = torch.empty(need // 4 + 1, device=DEV)
     dW = torch.full((Cout, Cin), float('nan'), device=DEV)
     lib('wgrad_bf16', dz, Cout, x, Cin, P, Cout, Cin, 1, 0, 0, dW, 0, ws, need)
@@ -113,13 +113,14 @@ def test_wgrad_1x1(hip_lib, P, Cout, Cin):
     assert rel_err(dW, 2 * ref) < 2e-5
 
 
-@pytest.mark.parametrize('B,H,W,Cout,Cin', [(2, 56, 56, 64, 64), (3, 28, 28, 128, 128), (5, 14, 14, 256, 256), (7, 7, 7, 512, 512), (3, 8, 12, 64, 128), (33, 2, 2, 128, 64), (5, 4, 4, 64, 64)])
+@pytest.mark.parametrize('B,H,W,Cout,Cin', [(2, 56, 56, 64, 64), (3, 28, 28, 128, 128), (5, 14, 14, 256, 256), (7, 7, 7, 512, 512), (3, 8, 12, 64, 128), (33, 2, 2, 128, 64), (5, 4, 4, 64, 64),
+                                           (2, 8, 16, 128, 64), (3, 4, 14, 64, 64), (2, 6, 14, 64, 128), (1, 224, 224, 64, 64)])   # patch form: 4x8, 4x7, 2x14
 def test_wgrad_3x3(hip_lib, B, H, W, Cout, Cin):
     lib = hip_lib
     g = torch.Generator().manual_seed(H + Cout)
     P = B * H * W
     dz, x = _bf(torch.randn(B, H, W, Cout, generator=g)), _bf(torch.randn(B, H, W, Cin, generator=g))
-    need = lib.query('wgrad_bf16_workspace_bytes', P, Cout, Cin, 9)
+    need = lib.query('wgrad_bf16_workspace_bytes', P, Cout, Cin, 9, H, W)
     ws = torch.empty(need // 4 + 1, device=DEV)
     dW = torch.full((Cout, Cin, 3, 3), float('nan'), device=DEV)
     lib('wgrad_bf16', dz, Cout, x, Cin, P, Cout, Cin, 9, H, W, dW, 0, ws, need)

@@ -14,7 +14,7 @@ for H, Cout, Cin, taps in shapes:
     P = B * H * H
     dz = torch.randn(P, Cout, device=DEV).to(torch.bfloat16)
     x = torch.randn(P, Cin, device=DEV).to(torch.bfloat16)
-    need = lib.query('wgrad_bf16_workspace_bytes', P, Cout, Cin, taps)
+    need = lib.query('wgrad_bf16_workspace_bytes', P, Cout, Cin, taps, H, H)
     ws = torch.empty(need // 4 + 1, device=DEV)
     dW = torch.empty(Cout * Cin * taps, device=DEV)
     for _ in range(3):
