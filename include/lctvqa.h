@@ -427,6 +427,9 @@ int lctvqa_global_avgpool_bf16_bwd(const float* dy, void* dx, int B, int HW, int
 /* pieces of a trainable VGG19 trunk on bf16 activations (basic_vqa/models_lct.py:56-63): MaxPool2d(2,2); the backward of ReLU
  * (-> MaxPool2d(2,2)) from the layer's post-ReLU output (first maximum of a window, like PyTorch); the backward of
  * AdaptiveAvgPool2d((7,7)) + flatten (fp32 dy -> bf16 dx) */
+/* the 7x7 / stride-2 stem's input windows as bf16 rows [B*Ho*Wo][192] (k = (c, ky, kx) < 147, zero-padded): its weight gradient is
+ * then dz^T . cols on lctvqa_wgrad_bf16 */
+int lctvqa_stem_im2col_bf16(const float* x_nchw, void* cols, int B, int H, int W, void* stream);
 int lctvqa_maxpool2x2_bf16(const void* x, void* y, int B, int H, int W, int C, void* stream);
 int lctvqa_relu_pool_bwd_bf16(const void* d, const void* act, void* dz, int B, int H, int W, int C, int pool, void* stream);
 int lctvqa_adaptive_avgpool7_flatten_bwd_bf16(const float* dy, void* dx_nhwc_bf16, int B, int H, int W, int C, void* stream);

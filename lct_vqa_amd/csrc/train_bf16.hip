@@ -828,8 +828,17 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const Tin* __restrict__ 
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const int r0 = blockIdx.y * per, r1 = min(n, r0 + per);
   double acc = 0.0;
-  if (col < W2)
-    for (int r = r0 + rl; r < r1; r += 4) acc += (double)in[(long)r * W2 + col];
+  if (col < W2) {
+    int r = r0 + rl;
+    for (; r + 28 < r1; r += 32) {                                // eight independent loads in flight, added in a fixed order
+      Tin v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = in[(long)(r + 4 * u) * W2 + col];
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc += (double)v[u];
+    }
+    for (; r < r1; r += 4) acc += (double)in[(long)r * W2 + col];
+  }
   red[rl][threadIdx.x & 63] = acc;
   __syncthreads();
   if (rl == 0 && col < W2) out[(long)blockIdx.y * W2 + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
@@ -1128,6 +1137,33 @@ __global__ void adaptive_avgpool7_flatten_bwd_bf16_kernel(const float* __restric
       }
     }
     dx[o] = f2bf(a);
+  }
+}
+
+// Stem weight gradient as a product: cols[p][k] (bf16, k = (c, ky, kx) < 147, zero up to 192) = the 7x7 / stride-2 / padding-3 window
+// of output pixel p of the fp32 NCHW image; dW = dz^T . cols then runs on wgrad_bf16 (the VALU form, resnet.hip
+// conv7x7_s2_stem_wgrad_kernel, spends 2.6 ms per B = 256 step on 60 GFLOP).  thread = (output pixel, 8 consecutive k).
+__global__ void stem_im2col_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ cols, int B, int H, int W, int Ho, int Wo) {
+  const long total = (long)B * Ho * Wo * 24;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const int kg = (int)(o % 24);
+    long p = o / 24;
+    const int ox = (int)(p % Wo);
+    const int oy = (int)((p / Wo) % Ho);
+    const long n = p / ((long)Wo * Ho);
+    us8 v;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int k = kg * 8 + e;
+      float f = 0.f;
+      if (k < 147) {
+        const int c = k / 49, ky = (k % 49) / 7, kx = k % 7;
+        const int iy = 2 * oy - 3 + ky, ix = 2 * ox - 3 + kx;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) f = x[((n * 3 + c) * H + iy) * W + ix];
+      }
+      v[e] = f2bf(f);
+    }
+    *(us8*)(cols + p * 192 + kg * 8) = v;
   }
 }
 
@@ -1473,6 +1509,14 @@ int lctvqa_global_avgpool_bf16_bwd(const float* dy, void* dx, int B, int HW, int
   return lct_check_launch("global_avgpool_bf16_bwd");
 }
 
+// cols [B*Ho*Wo][192] bf16 = the stem convolution's input windows (k = (c, ky, kx), zero beyond 147), Ho = (H-1)/2+1
+int lctvqa_stem_im2col_bf16(const float* x_nchw, void* cols, int B, int H, int W, void* stream) {
+  LCT_REQUIRE(B > 0 && H >= 7 && W >= 7 && ((uintptr_t)cols & 15) == 0, "stem_im2col_bf16: bad shape / alignment");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(stem_im2col_bf16_kernel, dim3(gs_blocks_tb((long)B * Ho * Wo * 24)), dim3(256), 0, (hipStream_t)stream, x_nchw,
+                     (unsigned short*)cols, B, H, W, Ho, Wo);
+  return lct_check_launch("stem_im2col_bf16");
+}
 int lctvqa_maxpool2x2_bf16(const void* x, void* y, int B, int H, int W, int C, void* stream) {
   LCT_REQUIRE(C % 8 == 0 && H >= 2 && W >= 2 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, "maxpool2x2_bf16: need C %% 8 == 0, aligned tensors");
   hipLaunchKernelGGL(maxpool2x2_bf16_kernel, dim3(gs_blocks_tb((long)B * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0, (hipStream_t)stream,

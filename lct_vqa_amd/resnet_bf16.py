@@ -33,7 +33,7 @@ def _reduce_rows(part, n, C, dev, force=False):
     """fp32 partials [n][2][C] -> (buffer, is_f64, rows) the final kernels read: as they are when few, else fp64 chunk sums."""
     if n <= 32 and not force:
         return part, 0, n
-    chunks = 1 if force else min(32, -(-n // 128))
+    chunks = 1 if force else min(32, -(-n // 64))
     out = torch.empty((chunks, 2 * C), dtype=torch.float64, device=dev)
     lib('colreduce_f32', part, n, 2 * C, chunks, out)
     return out, 1, chunks
@@ -233,10 +233,11 @@ class StemFn(torch.autograd.Function):
         dy = _bf16((B, Ho, Wo, 64), dev)
         lib('maxpool3x3_s2_bf16_bwd', dout, idx, dy, B, Ho, Wo, 64)
         dz, dg, db = bn_backward(dy, y, z, coef, gamma, training)
-        nb = lib.query('conv7x7_s2_stem_wgrad_blocks', B, H)
-        part = torch.empty((nb, 147 * 64), dtype=torch.float32, device=dev)
-        lib('conv7x7_s2_stem_wgrad_bf16', image, dz, part, B, H, W)
-        dw = ops.colsum(part).reshape(147, 64).t().contiguous().reshape(64, 3, 7, 7)
+        # weight gradient as a product on the matrix cores: dW[co][k] = sum_p dz[p][co] * window(p)[k] (k = (c, ky, kx) padded to 192)
+        P0 = B * Ho * Wo
+        cols = _bf16((P0, 192), dev)
+        lib('stem_im2col_bf16', image, cols, B, H, W)
+        dw = wgrad(dz.view(P0, 64), cols, 64, 192).view(64, 192)[:, :147].reshape(64, 3, 7, 7).contiguous()
         return None, dw, dg, db, None
 
 

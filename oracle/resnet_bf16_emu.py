@@ -204,6 +204,6 @@ def trunk_forward_backward(sd, layers, image, dy, training=True, tiled=lambda H,
     dz0, dg, db = bn0.backward(dy0 * (y0 > 0), z0)
     grads['bn1.weight'], grads['bn1.bias'] = dg, db
     w = torch.zeros(64, 3, 7, 7, dtype=torch.float64, requires_grad=True)
-    F.conv2d(img, w, stride=2, padding=3).backward(_nchw(dz0))
+    F.conv2d(r(img), w, stride=2, padding=3).backward(_nchw(dz0))       # the stem's weight gradient multiplies bf16 input windows
     grads['conv1.weight'] = w.grad
     return feat, grads, stats
