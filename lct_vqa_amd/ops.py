@@ -765,8 +765,12 @@ _grad_sink = {'on': False, 'suspended': 0}
 def grad_sink(on=True):
     """Let the fused backward nodes accumulate parameter gradients straight into existing ``p.grad`` tensors (see above).
     Returns the previous setting."""
+    global _hooks_fire_on_none
     prev = _grad_sink['on']
     _grad_sink['on'] = bool(on)
+    if on and _hooks_fire_on_none is None:                      # probed here, outside any backward pass (see sink_done)
+        with torch.enable_grad():
+            _hooks_fire_on_none = _probe_hooks_fire_on_none()
     return prev
 
 
@@ -792,8 +796,38 @@ def sink_target(p):
     return g
 
 
+_hooks_fire_on_none = None
+
+
+def _probe_hooks_fire_on_none():
+    """Does this torch run a leaf's post-accumulate-grad hooks when the node feeding it returned None for it?  (torch 2.10 does:
+    AccumulateGrad is still scheduled and its hooks run; older releases returned before them.)  Probed once, on the CPU."""
+    class _P(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            return x * 2 + 0 * w.sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2, None
+    w = torch.nn.Parameter(torch.ones(2))
+    w.grad = torch.zeros(2)
+    x = torch.ones(2, requires_grad=True)
+    fired = []
+    h = w.register_post_accumulate_grad_hook(lambda q: fired.append(1))
+    _P.apply(x, w).sum().backward()
+    h.remove()
+    return bool(fired)
+
+
 def sink_done(p):
-    """The gradient of ``p`` has been accumulated into ``p.grad`` by a kernel: run what AccumulateGrad would have run after it."""
+    """The gradient of ``p`` has been accumulated into ``p.grad`` by a kernel and the node returns None for it: make sure the
+    parameter's post-accumulate-grad hooks (the arena's "reached" record, the data-parallel reducer's bucket counters) run exactly
+    once -- by autograd itself where it runs them for a None gradient, else here."""
+    if _hooks_fire_on_none is None:
+        raise RuntimeError('ops.sink_done before ops.grad_sink(True)')
+    if _hooks_fire_on_none:
+        return
     hooks = getattr(p, '_post_accumulate_grad_hooks', None)
     if hooks:
         for h in list(hooks.values()):

@@ -170,3 +170,21 @@ def test_sync_bn_dp2_equals_the_single_process_batch(hip_lib, tmp_path, dtype):
     outs = [p.communicate(timeout=600) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0 and 'SYNCBN_OK' in so, (so[-2000:], se[-4000:])
+
+
+def test_trainable_bf16_resnet_under_dp_with_the_gradient_sink(hip_lib):
+    """BASELINE configs[2] (ResNet-152 + GRU, bf16, encoder trainable, data parallel) rehearsed on two ranks sharing the one GPU: with
+    ops.grad_sink the bottleneck nodes accumulate their parameter gradients into the optimizer arena themselves and return None, and
+    the reducer's bucket counters must still see every parameter exactly once per backward pass (torch runs a leaf's
+    post-accumulate-grad hooks for a None gradient as well; ops.sink_done fires them itself only where it does not): every bucket is
+    launched by the hooks during backward, none by finish(), and no hook fires twice (FlatGradReducer raises on that)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', 'resnet_gru', '--train-encoder', '--dtype',
+                        'bf16', '--batch', '8', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'], capture_output=True, text=True,
+                       timeout=600, env=_env(LCTVQA_REHEARSE_ONE_GPU='1'), cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-4000:])
+    out = json.loads(lines[0])
+    dp = out['dp']
+    assert out['n_gpus'] == 2 and dp['world'] == 2 and dp['buckets'] >= 8
+    assert dp['launched_during_backward_per_step'] == float(dp['buckets']) and dp['launched_by_finish_per_step'] == 0.0
+    assert 5.0 < out['loss'] < 10.0
