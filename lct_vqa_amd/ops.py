@@ -756,8 +756,8 @@ def eval_multi_choice(logits, choices, unk_idx, counts=None):
 # views of the optimizer's flat arena always do -- launches one ATen ``add_`` per parameter (478 per step for the trainable
 # ResNet-152, ~300 for a PC-DARTS examiner).  With the sink on, the fused backward nodes (resnet_bf16.BottleneckFn / StemFn,
 # darts_ops.MixedEdgeFn) let their weight-gradient kernels accumulate INTO ``p.grad`` (their reduce / finish kernels take an
-# accumulate flag), return None for that input and fire the parameter's post-accumulate-grad hooks themselves (the arena's
-# "reached" record, the data-parallel reducer's bucket counters).  OFF by default: it is only right under ``loss.backward()``;
+# accumulate flag) and return None for that input; the parameter's post-accumulate-grad hooks (the arena's "reached" record, the
+# data-parallel reducer's bucket counters) still run exactly once (sink_done).  OFF by default: it is only right under ``loss.backward()``;
 # ``torch.autograd.grad`` (the architects' bilevel.grads) must see the gradients as return values, so bilevel.grads suspends it.
 _grad_sink = {'on': False, 'suspended': 0}
 
