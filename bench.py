@@ -615,8 +615,9 @@ def main():
                 'kernel': ('gemm_bf16_kernel (1x1 convolutions of the bottlenecks on v_mfma_f32_32x32x16_bf16, %d launches) + conv3x3_bf16_kernel (%d)' % (ngemm_bf, nbf)) if ngemm_bf else
                           ('gemm_f32_kernel (1x1 convolutions of the bottlenecks as fp32 MFMA GEMMs, %d launches) + conv3x3_wino4_kernel (%d)' % (ngemm, nw4)) if ngemm else
                           ('conv3x3_bf16_kernel (direct implicit GEMM on v_mfma_f32_32x32x16_bf16, fp32 accumulate, %d launches)' % nbf) if nbf else
-                          ('conv3x3_wino4_kernel (Winograd F(4x4,3x3), %d launches) + conv3x3_wino2/3_kernel (F(2x2,3x3), %d) + '
-                           'conv3x3_mfma_kernel (direct, %d): fp32 MFMA' % (nw4, nwino - nw4, nlaunch - nwino)) if nwino else
+                          ('conv3x3_wino4_kernel (Winograd F(4x4,3x3), %d launches, %d of them as input transform + 36 batched fp32 GEMMs + output '
+                           'transform) + conv3x3_wino2/3_kernel (F(2x2,3x3), %d) + conv3x3_mfma_kernel (direct, %d): fp32 MFMA'
+                           % (nw4, sum(1 for r in conv if r['name'].endswith('_split')), nwino - nw4, nlaunch - nwino)) if nwino else
                           'conv3x3_mfma_kernel (direct implicit GEMM, 15 VGG19 layers/step)',
                 'algorithm': 'direct' if nbf else algo, 'achieved': round(executed, 2),
                 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(executed / peak, 4),

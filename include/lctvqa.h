@@ -86,6 +86,12 @@ int lctvqa_conv3x3_wino4_wgrad_supported(int B, int H, int W, int Cin, int Cout)
 long lctvqa_conv3x3_wino4_wgrad_workspace_elems(int B, int H, int W, int Cin, int Cout);
 int lctvqa_conv3x3_wino4_wgrad(const float* x, const float* dz, float* dw_oihw, float* workspace, long workspace_elems, int B, int H,
                                int W, int Cin, int Cout, void* stream);
+/* F(4x4,3x3) forward as three kernels (input transform, 36 batched fp32 GEMMs, output transform + bias + ReLU + pool): the split form
+ * of conv3x3_wino4_nhwc, built as an A/B for the 28x28 512-channel layers (models.py:35-36) */
+long lctvqa_conv3x3_wino4_split_workspace_elems(int B, int H, int W, int Cin, int Cout);
+int lctvqa_conv3x3_wino4_split_pack_weights(const float* w_oihw, float* U, int Cout, int Cin, void* stream);
+int lctvqa_conv3x3_wino4_split_nhwc(const float* x, const float* U, const float* bias, float* y, float* workspace, long workspace_elems,
+                                    int B, int H, int W, int Cin, int Cout, int relu, int pool, void* stream);
 long lctvqa_conv3x3_first_wgrad_scratch_elems(int B, int H, int W, int Cout);
 int lctvqa_conv3x3_first_wgrad(const float* x_nchw, const float* dz_nhwc, float* dw, float* db, float* scratch, int B, int H,
                                int W, int Cout, void* stream);

@@ -182,9 +182,142 @@ __global__ __launch_bounds__(256) void wino4_wgrad_finish(const float* __restric
   }
 }
 
+// ---- split forward path (built as an A/B): F(4x4,3x3) as three kernels -- the input transform above
+// (V = B^T d B), 36 batched fp32 GEMMs M[xn][t][co] = sum_ci V[xn][t][ci] * U[xn][co][ci], and the output transform below
+// (Y = A^T M A + bias, ReLU, optional 2x2 max pool) -- instead of the fused conv3x3_wino4_kernel.  U[36][Cout][Cin] = G g G^T.
+__global__ void wino4_split_pack_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin) {
+  const long total = (long)Cout * Cin;
+  const long plane = total;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const float* g = w + o * 9;                                  // OIHW: [co][ci][3][3], o = co * Cin + ci
+    float t[6][3];                                               // G g
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float g0 = g[c], g1 = g[3 + c], g2 = g[6 + c];
+      t[0][c] = 0.25f * g0;
+      t[1][c] = (-1.f / 6) * (g0 + g1 + g2);
+      t[2][c] = (-1.f / 6) * (g0 - g1 + g2);
+      t[3][c] = (1.f / 24) * g0 + (1.f / 12) * g1 + (1.f / 6) * g2;
+      t[4][c] = (1.f / 24) * g0 - (1.f / 12) * g1 + (1.f / 6) * g2;
+      t[5][c] = g2;
+    }
+#pragma unroll
+    for (int xi = 0; xi < 6; xi++) {
+      const float a = t[xi][0], b = t[xi][1], c = t[xi][2];
+      float* u = U + (long)(xi * 6) * plane + o;
+      u[0] = 0.25f * a;
+      u[plane] = (-1.f / 6) * (a + b + c);
+      u[2 * plane] = (-1.f / 6) * (a - b + c);
+      u[3 * plane] = (1.f / 24) * a + (1.f / 12) * b + (1.f / 6) * c;
+      u[4 * plane] = (1.f / 24) * a - (1.f / 12) * b + (1.f / 6) * c;
+      u[5 * plane] = c;
+    }
+  }
+}
+// thread = (tile t, channel quad q): the 4x4 output tile of M[36][Tp][C] -> y NHWC (+ bias, ReLU, 2x2 max pool)
+__global__ __launch_bounds__(256) void wino4_split_out_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y,
+                                                              int H, int W, int C, int Hp4, int Wp4, int T, int Tp, int relu, int pool) {
+  const int CQ = C >> 2;
+  const long total = (long)T * CQ;
+  const long plane = (long)Tp * C;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(o % CQ);
+    const int t = (int)(o / CQ);
+    const float* src = M + (long)t * C + 4 * q;
+    f32x4 ta[4][6];                                              // (A^T m)[i][nu]
+#pragma unroll
+    for (int nu = 0; nu < 6; nu++) {
+      f32x4 m[6];
+#pragma unroll
+      for (int xi = 0; xi < 6; xi++) m[xi] = *(const f32x4*)(src + (long)(xi * 6 + nu) * plane);
+      const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+      ta[0][nu] = m[0] + s12 + s34;
+      ta[1][nu] = d12 + 2.f * d34;
+      ta[2][nu] = s12 + 4.f * s34;
+      ta[3][nu] = d12 + 8.f * d34 + m[5];
+    }
+    const f32x4 bv = bias ? *(const f32x4*)(bias + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 out[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const f32x4* e = ta[i];
+      const f32x4 s12 = e[1] + e[2], d12 = e[1] - e[2], s34 = e[3] + e[4], d34 = e[3] - e[4];
+      out[i][0] = e[0] + s12 + s34 + bv;
+      out[i][1] = d12 + 2.f * d34 + bv;
+      out[i][2] = s12 + 4.f * s34 + bv;
+      out[i][3] = d12 + 8.f * d34 + e[5] + bv;
+    }
+    if (relu) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int jx = 0; jx < 4; jx++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) out[i][jx][e] = fmaxf(out[i][jx][e], 0.f);
+    }
+    const int tpi = Hp4 * Wp4;
+    const int n = t / tpi, r = t % tpi;
+    const int y0 = (r / Wp4) * 4, x0 = (r % Wp4) * 4;
+    if (!pool) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int jx = 0; jx < 4; jx++)
+          if (y0 + i < H && x0 + jx < W) *(f32x4*)(y + (((long)n * H + y0 + i) * W + x0 + jx) * C + 4 * q) = out[i][jx];
+    } else {
+      const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int jx = 0; jx < 2; jx++) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            v[e] = fmaxf(fmaxf(out[2 * i][2 * jx][e], out[2 * i][2 * jx + 1][e]), fmaxf(out[2 * i + 1][2 * jx][e], out[2 * i + 1][2 * jx + 1][e]));
+          const int oy = (y0 >> 1) + i, ox = (x0 >> 1) + jx;
+          if (oy < Ho && ox < Wo) *(f32x4*)(y + (((long)n * Ho + oy) * Wo + ox) * C + 4 * q) = v;
+        }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+long lctvqa_conv3x3_wino4_split_workspace_elems(int B, int H, int W, int Cin, int Cout) {
+  const long T = (long)B * ((H + 3) / 4) * ((W + 3) / 4);
+  const long Tp = (T + 3) / 4 * 4;
+  return 36L * Tp * (Cin + Cout);
+}
+int lctvqa_conv3x3_wino4_split_pack_weights(const float* w_oihw, float* U, int Cout, int Cin, void* stream) {
+  long nb = ((long)Cout * Cin + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(wino4_split_pack_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, w_oihw, U, Cout, Cin);
+  return lct_check_launch("wino4_split_pack");
+}
+// y = relu?(conv3x3(x) + bias) (+ 2x2 max pool), NHWC fp32, F(4x4,3x3) as transform -> 36 batched GEMMs -> transform.
+// U: lctvqa_conv3x3_wino4_split_pack_weights; workspace: lctvqa_conv3x3_wino4_split_workspace_elems floats.
+int lctvqa_conv3x3_wino4_split_nhwc(const float* x, const float* U, const float* bias, float* y, float* workspace, long workspace_elems,
+                                    int B, int H, int W, int Cin, int Cout, int relu, int pool, void* stream) {
+  LCT_REQUIRE(B >= 1 && H >= 2 && W >= 2 && Cin % 4 == 0 && Cout % 4 == 0 && (!pool || (H % 2 == 0 && W % 2 == 0)), "conv3x3_wino4_split: bad shape");
+  LCT_REQUIRE(workspace && workspace_elems >= lctvqa_conv3x3_wino4_split_workspace_elems(B, H, W, Cin, Cout), "conv3x3_wino4_split: workspace too small");
+  LCT_REQUIRE((((uintptr_t)x | (uintptr_t)U | (uintptr_t)y | (uintptr_t)workspace) & 15) == 0, "conv3x3_wino4_split: tensors must be 16-B aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int Hp4 = (H + 3) / 4, Wp4 = (W + 3) / 4;
+  const long T = (long)B * Hp4 * Wp4, Tp = (T + 3) / 4 * 4;
+  float* V = workspace;
+  float* M = V + 36L * Tp * Cin;
+  auto blocks = [](long threads) { long b = (threads + 255) / 256; return (int)(b > 16384 ? 16384 : b); };
+  hipLaunchKernelGGL(wino4_wgrad_xform_x, dim3(blocks(Tp * (Cin / 4))), dim3(256), 0, st, x, V, H, W, Cin, Hp4, Wp4, (int)T, (int)Tp);
+  int rc = lct_check_launch("wino4_split_xform_x");
+  if (rc) return rc;
+  rc = lctvqa_gemm_f32_batched(V, Cin, 1, Tp * Cin, U, Cin, 1, (long)Cout * Cin, M, Cout, Tp * Cout, 36, (int)Tp, Cout, Cin, nullptr, 0, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(wino4_split_out_kernel, dim3(blocks(T * (Cout / 4))), dim3(256), 0, st, M, bias, y, H, W, Cout, Hp4, Wp4, (int)T, (int)Tp,
+                     relu, pool);
+  return lct_check_launch("wino4_split_out");
+}
 
 // 1 where the Winograd-domain weight gradient is the better choice (measured, B = 256: 2.0-2.8x at 256/512 channels, 1.65x at
 // 128->256, 1.35x at 14x14 256->256, a loss at 128->128): both channel counts at least 128 and one at least 256, the map wastes at

@@ -858,6 +858,14 @@ _conv_algo = os.environ.get('LCTVQA_CONV_ALGO', 'winograd')   # see set_conv_alg
 
 
 _CONV_ALGOS = ('winograd', 'winograd2', 'direct')
+_wino4_split = os.environ.get('LCTVQA_WINO4_SPLIT', '1') != '0'     # A/B switch of the split F(4x4,3x3) path (see _conv_block)
+
+
+def set_wino4_split(on=True):
+    """Use the split F(4x4,3x3) path (transform / batched GEMM / transform) where it is the faster form.  Returns the previous setting."""
+    global _wino4_split
+    prev, _wino4_split = _wino4_split, bool(on)
+    return prev
 
 
 def set_conv_algo(name):
@@ -994,6 +1002,20 @@ def _conv_block(cur, w, b, B, H, W, pool, cache=False, relu=1):
     dev = cur.device
     Cout, Cin = w.shape[0], w.shape[1]
     wv = _wino_variant(B, H, W, Cin, Cout, pool)
+    if wv == 'wino4' and _wino4_split and H * W <= 28 * 28 and Cin >= 512 and Cout >= 512 and B * H * W >= 4096:
+        # F(4x4,3x3) as input transform + 36 batched fp32 GEMMs + output transform (csrc/conv3x3_wino_wgrad.hip, round 4): faster than
+        # the fused kernel on the 28x28 and 14x14 512 -> 512 layers (profiles/r04_ab_wino_split.txt: 2.59 vs 2.85, 0.84 vs 0.93 ms alone on
+        # the chip at B = 256; inside the two-stream step 2.56 vs 2.87 with the pool, 0.76 vs 0.83), slower at 56x56 and, inside the
+        # step, on 28x28 256 -> 512; same arithmetic (exact fp32 MFMA products, the published transform matrices), 6e-6 apart
+        U = _packed_weights(w, 'wino4split', 36 * Cout * Cin, lambda dst: lib('conv3x3_wino4_split_pack_weights', w, dst, Cout, Cin), cache)
+        n = lib.query('conv3x3_wino4_split_workspace_elems', B, H, W, Cin, Cout)
+        ws = _workspace(4 * n, dev)
+        Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
+        _timed(f'wino4_{H}x{W}_{Cin}->{Cout}{"+pool" if pool else ""}_split', 2.0 * B * H * W * Cout * Cin * 9,
+               4.0 * B * (H * W * Cin + Ho * Wo * Cout),
+               lambda: lib('conv3x3_wino4_split_nhwc', cur, U, b, out, ws, ws.numel(), B, H, W, Cin, Cout, int(relu), pool))
+        return out
     if wv is not None:
         up = _packed_weights(w, wv, Cout * Cin * (36 if wv == 'wino4' else 16),
                              lambda dst: lib(f'conv3x3_{wv}_pack_weights', w, dst, Cout, Cin, 0), cache)
