@@ -109,9 +109,12 @@ def conv_source_stamp():
     """Hash of the trunk-convolution kernel sources: a committed PMC profile is only quoted for the kernels it measured."""
     import hashlib
     h = hashlib.sha256()
-    for f in ('conv3x3.hip', 'conv3x3_bf16.hip', 'conv3x3_wino.hip', 'conv3x3_wino4.hip', 'common.h'):
+    for f in ('conv3x3.hip', 'conv3x3_bf16.hip', 'conv3x3_wino.hip', 'conv3x3_wino4.hip', 'conv3x3_wino_wgrad.hip', 'gemm.hip', 'common.h'):
         with open(os.path.join(ROOT, 'lct_vqa_amd', 'csrc', f), 'rb') as fh:
             h.update(fh.read())
+    import inspect
+    from lct_vqa_amd import ops as _ops
+    h.update(inspect.getsource(_ops._conv_block).encode())      # which layers take the split Winograd path is decided there
     return h.hexdigest()[:16]
 
 
