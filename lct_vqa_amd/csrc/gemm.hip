@@ -242,7 +242,8 @@ __device__ __attribute__((aligned(64))) float g_zero_page_g[64];
 template <bool AKM, bool BKM, int NTW>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
                                                               long ldb, float* __restrict__ C, long ldc, int M, int N, int K,
-                                                              int kper, GemmEpi epi, int direct, long sA, long sB, long sC, int relu_ab) {
+                                                              int kper, GemmEpi epi, int direct, long sA, long sB, long sC, int relu_ab,
+                                                              int flat_nb) {
   constexpr int BM = 256, BN = 64 * NTW;
   constexpr int ASZ = BM * 16, BSZ = BN * 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -254,12 +255,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __res
   const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM;
   // workgroups are dealt to the 8 XCDs round-robin: with at least 8 row blocks the ntn workgroups that read one A row block are
   // given ids that share an XCD (its L2); fewer row blocks keep the plain order (the other mapping would leave XCDs idle)
-  int tn, tm;
-  if (ntm >= 8) { tn = (blockIdx.x >> 3) % ntn; tm = ((blockIdx.x >> 3) / ntn) * 8 + (blockIdx.x & 7); }
+  int tn, tm, nb = blockIdx.y;
+  if (flat_nb > 0) {
+    // batched: the row blocks of ALL batch members are dealt to the XCDs together (49 row blocks per member would give XCD 0 seven
+    // and the others six of every member: a 14 % longer tail on that XCD)
+    const int r = ((blockIdx.x >> 3) / ntn) * 8 + (blockIdx.x & 7);
+    if (r >= flat_nb * ntm) return;
+    tn = (blockIdx.x >> 3) % ntn; nb = r / ntm; tm = r - nb * ntm;
+  } else if (ntm >= 8) { tn = (blockIdx.x >> 3) % ntn; tm = ((blockIdx.x >> 3) / ntn) * 8 + (blockIdx.x & 7); }
   else { tn = blockIdx.x % ntn; tm = blockIdx.x / ntn; }
   if (tm >= ntm) return;
   const int m0 = tm * BM, n0 = tn * BN;
-  A += (long)blockIdx.y * sA; B += (long)blockIdx.y * sB; C += (long)blockIdx.y * sC;
+  A += (long)nb * sA; B += (long)nb * sB; C += (long)nb * sC;
   const int kbeg = blockIdx.z * kper;
   const int kend = min(K, kbeg + kper);
   const int nk = (kend - kbeg + 15) / 16;
@@ -498,7 +505,7 @@ long lctvqa_gemm_workspace_bytes(int M, int N, int K) {
 }
 
 typedef void (*gemm_dma_kern_t)(const float*, long, const float*, long, float*, long, int, int, int, int, GemmEpi, int, long, long,
-                                long, int);
+                                long, int, int);
 static gemm_dma_kern_t gemm_dma_table[2][2][2] = {
     {{gemm_f32_dma_kernel<false, false, 1>, gemm_f32_dma_kernel<false, false, 2>},
      {gemm_f32_dma_kernel<false, true, 1>, gemm_f32_dma_kernel<false, true, 2>}},
@@ -527,12 +534,15 @@ static int launch_gemm_dma(const float* A, long lda, int akm, const float* B, lo
   splits = cdiv(K, kper);
   gemm_dma_kern_t k = gemm_dma_table[akm][bkm][BN == 128];
   const size_t lds = (size_t)(2 * 256 * 16 + 2 * BN * 16) * sizeof(float);
-  dim3 grid(ntm >= 8 ? ((ntm + 7) / 8) * 8 * ntn : ntm * ntn, batch, splits);
+  // batched products whose row-block count is not a multiple of 8: one flat grid over (member, row block), dealt to the XCDs together
+  static const int flat_on = [] { const char* e = getenv("LCTVQA_GEMM_FLAT"); return e ? atoi(e) : 1; }();
+  const int flat_nb = (flat_on && batch > 1 && (long)batch * ntm >= 8 && (ntm % 8 != 0 || flat_on > 1)) ? batch : 0;
+  dim3 grid(flat_nb ? (((long)batch * ntm + 7) / 8) * 8 * ntn : ntm >= 8 ? ((ntm + 7) / 8) * 8 * ntn : ntm * ntn, flat_nb ? 1 : batch, splits);
   if (splits == 1) {
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K, kper, epi, 1, sA, sB, sC, relu_ab);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K, kper, epi, 1, sA, sB, sC, relu_ab, flat_nb);
     return lct_check_launch("gemm_f32_dma");
   }
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, workspace, (long)N, M, N, K, kper, epi, 0, 0L, 0L, 0L, relu_ab);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, workspace, (long)N, M, N, K, kper, epi, 0, 0L, 0L, 0L, relu_ab, 0);
   int rc = lct_check_launch("gemm_f32_dma(splitk)");
   if (rc) return rc;
   return lct_splitk_reduce(workspace, splits, C, ldc, M, N, epi, st);

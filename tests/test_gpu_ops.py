@@ -224,6 +224,21 @@ def test_gemm_batched_nt(hip_lib):
     assert rel_err(C, want) < 2e-5
 
 
+@pytest.mark.parametrize('nb,M,N,K', [(20, 2500, 384, 72), (36, 1100, 256, 64), (3, 45000, 130, 512)])
+def test_gemm_batched_nt_flat_grid(hip_lib, nb, M, N, K):
+    """Batched products whose row-block count is not a multiple of 8 run on one flat grid over (member, row block) so that the 8 XCDs get
+    equal shares (10 and 5 row blocks here; 176 keeps the per-member grid): ragged last row block, ragged last column block, K not a
+    multiple of the step."""
+    g = torch.Generator().manual_seed(nb + K)
+    A = torch.randn(nb, M, K, generator=g).to(DEV)
+    Bm = torch.randn(nb, N, K, generator=g).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    C = torch.full((nb, M, N), float('nan'), device=DEV)
+    hip_lib('gemm_f32_batched_nt', A, K, M * K, Bm, K, N * K, C, N, M * N, nb, M, N, K, bias, 1)
+    want = torch.relu(torch.bmm(A.double(), Bm.double().transpose(1, 2)) + bias.double())
+    assert rel_err(C, want) < 2e-5
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [(16, 14, 14, 256, 256), (6, 28, 28, 128, 256), (2, 56, 56, 256, 128), (17, 15, 13, 128, 256),
                                             (64, 8, 8, 512, 512)])
 def test_conv3x3_weight_grad_winograd(ops, hip_lib, B, H, W, Cin, Cout):
