@@ -390,6 +390,18 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
                           const float* pre, const float* mean, const float* invstd, const float* wsel, const float* beta, float* dx,
                           float* dwsel, float* dbeta, float* wgrad, float* scratch, int training, int accumulate_dx, const float* x1d,
                           int need_wgrad, void* stream);
+/* The same pair with the nine pre-BatchNorm tensors STORED as bf16 (pre = [9][P][Cq] bf16, P*Cq a multiple of 8; everything else as
+ * above, arithmetic and statistics fp32): a value is rounded to bf16 before it is stored and before it enters its BatchNorm's batch
+ * statistics, so forward normalisation, backward x-hat and the ReLU masks of the sep_conv second stages all see the stored numbers.
+ * Selected by darts_ops under the bf16 compute dtype (BASELINE.json configs[4] "bf16"); csrc/mixed_edge_bf16.hip. */
+int lctvqa_mixed_edge_fwd_bf16pre(const float* x, int B, int H, int W, int C, int stride, const void* const* w, void* const* bn,
+                                  unsigned short* pre, float* mean, float* invstd, double* part, const float* wsel, const float* beta,
+                                  float* out, long ldo, int accumulate, int training, float momentum, float eps, const float* x1d,
+                                  void* stream);
+int lctvqa_mixed_edge_bwd_bf16pre(const float* dout, long ldd, const float* x, int B, int H, int W, int C, int stride,
+                                  const void* const* w, const unsigned short* pre, const float* mean, const float* invstd,
+                                  const float* wsel, const float* beta, float* dx, float* dwsel, float* dbeta, float* wgrad,
+                                  float* scratch, int training, int accumulate_dx, const float* x1d, int need_wgrad, void* stream);
 
 /* ---- bf16-native TRAINABLE convolution trunk (BASELINE.json configs[2] "bf16 ... encoder trainable"; trainable-trunk semantics of
  *      basic_vqa/models_lct.py:56-63): bf16 NHWC activations and activation gradients, fp32 master weights / statistics / weight

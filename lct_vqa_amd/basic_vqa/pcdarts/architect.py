@@ -26,6 +26,7 @@ class Architect(object):
         self.compute_grads(img_train, qst_train, label_train, img_valid, qst_valid, label_valid, eta, unrolled)
         self.optimizer.step()
 
+    @bilevel.architecture_pass
     def compute_grads(self, img_train, qst_train, label_train, img_valid, qst_valid, label_valid, eta=None, unrolled=True):
         """Leave d L_val / d alpha (second order when ``unrolled``) in the ``.grad`` of the architecture parameters."""
         alphas = self.model.arch_parameters()

@@ -36,6 +36,7 @@ class ArchitectLct(object):
         self.compute_grads(img_train, qst_train, label_train, img_valid, qst_valid, label_valid, ef_lr, w_lr)
         self.optimizer.step()
 
+    @bilevel.architecture_pass
     def compute_grads(self, img_train, qst_train, label_train, img_valid, qst_valid, label_valid, ef_lr, w_lr):
         """Leave gamma * ef_lr * w_lr in the ``.grad`` of the examiner's architecture parameters (no optimizer step)."""
         gamma, val_loss = self._alpha_direction(img_train, qst_train, label_train, img_valid, qst_valid, label_valid, ef_lr, w_lr)

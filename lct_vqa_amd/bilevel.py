@@ -16,8 +16,34 @@ parameter-space updates are one multi-tensor launch each, in place on the live p
 exactly the in-place ``p.data`` writes the kernels are required to observe, which is why no kernel
 caches anything derived from a trainable parameter.
 """
+import contextlib
+import functools
+
 import torch
 import torch.distributed as dist
+
+
+@contextlib.contextmanager
+def exact_edge_storage():
+    """The fused MixedOp edges keep their pre-BatchNorm tensors in fp32 inside this block, whatever the compute dtype
+    (darts_ops.set_edge_pre_bf16).  The architecture steps difference two gradients taken 2R apart in parameter space (R = 0.01 / ||v||,
+    architect.py:89-109): a tensor stored with 8 bits of mantissa turns that difference into rounding noise."""
+    from . import darts_ops
+    prev = darts_ops.set_edge_pre_bf16(False)
+    try:
+        yield
+    finally:
+        darts_ops.set_edge_pre_bf16(prev)
+
+
+def architecture_pass(fn):
+    """Decorator of the architects' ``compute_grads``: everything they evaluate runs under ``exact_edge_storage``."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        with exact_edge_storage():
+            return fn(*args, **kwargs)
+    return wrapped
+
 
 _dp = {'group': None, 'on': None}      # on: None = automatic (on whenever a process group with more than one rank exists)
 

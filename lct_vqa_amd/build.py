@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT_DIR = os.path.join(HERE, '_C')
 LIB = os.path.join(OUT_DIR, 'liblctvqa_hip.so')
-SOURCES = ['api.hip', 'conv3x3.hip', 'conv3x3_bf16.hip', 'conv3x3_bwd.hip', 'conv3x3_wino.hip', 'conv3x3_wino4.hip', 'conv3x3_wino_wgrad.hip', 'darts.hip', 'gemm.hip', 'gemm_bf16.hip', 'mixed_edge.hip', 'ops.hip', 'resnet.hip', 'train_bf16.hip']
+SOURCES = ['api.hip', 'conv3x3.hip', 'conv3x3_bf16.hip', 'conv3x3_bwd.hip', 'conv3x3_wino.hip', 'conv3x3_wino4.hip', 'conv3x3_wino_wgrad.hip', 'darts.hip', 'gemm.hip', 'gemm_bf16.hip', 'mixed_edge.hip', 'mixed_edge_bf16.hip', 'ops.hip', 'resnet.hip', 'train_bf16.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', 
          '-Wno-unused-result', '-Wno-unused-value', '-Wno-inline-asm', '-I' + CSRC]
 

@@ -382,6 +382,100 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __res
   gemm_store_tiles<4, NTW>(acc, out, ldc, m0 + wm * 128, n0 + wn * 32 * NTW, m0 + BM, n0 + BN, M, N, epi, direct, j, h);
 }
 
+// The K-contiguous x K-contiguous case with BUFFER addressing of the LDS-DMA (K % 16 == 0): `buffer_load_dwordx4 ... offen lds` takes a
+// wave-uniform 128-bit descriptor (SGPRs), one 32-bit byte offset per lane that is the same for every K step, and the step's byte offset
+// as a scalar -- no per-step address arithmetic on the vector ALU and half the address registers of `global_load_lds` (64-bit per lane).
+// Rows past M / N are CLAMPED to the last row (their products land in output rows / columns that the epilogue does not store).
+typedef int gemm_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bufdma16(unsigned voff, gemm_i32x4 rsrc, unsigned soff, float* lds_wave_base) {
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) void*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(l) : "memory", "m0");
+}
+__device__ __forceinline__ gemm_i32x4 make_rsrc(const float* base) {
+  const unsigned long a = (unsigned long)(uintptr_t)base;
+  gemm_i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);     // stride 0: raw buffer
+  r[2] = 0x7ffffff0;                                                             // bytes addressable from base
+  r[3] = 0x00020000;
+  return r;
+}
+
+template <int NTW>
+__global__ __launch_bounds__(256, 2) void gemm_f32_nt_buf_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb,
+                                                                 float* __restrict__ C, long ldc, int M, int N, int K, GemmEpi epi, long sA,
+                                                                 long sB, long sC, int flat_nb) {
+  constexpr int BM = 256, BN = 64 * NTW;
+  constexpr int ASZ = BM * 16, BSZ = BN * 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* abuf = smem;                 // [2][ASZ]
+  float* bbuf = smem + 2 * ASZ;       // [2][BSZ]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
+  const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM;
+  int tn, tm, nb = blockIdx.y;
+  if (flat_nb > 0) {                                              // see gemm_f32_dma_kernel
+    const int r = ((blockIdx.x >> 3) / ntn) * 8 + (blockIdx.x & 7);
+    if (r >= flat_nb * ntm) return;
+    tn = (blockIdx.x >> 3) % ntn; nb = r / ntm; tm = r - nb * ntm;
+  } else if (ntm >= 8) { tn = (blockIdx.x >> 3) % ntn; tm = ((blockIdx.x >> 3) / ntn) * 8 + (blockIdx.x & 7); }
+  else { tn = blockIdx.x % ntn; tm = blockIdx.x / ntn; }
+  if (tm >= ntm) return;
+  const int m0 = tm * BM, n0 = tn * BN;
+  A += (long)nb * sA + (long)m0 * lda; B += (long)nb * sB + (long)n0 * ldb; C += (long)nb * sC;
+  const gemm_i32x4 ra = make_rsrc(A), rb = make_rsrc(B);
+  const int nk = K / 16;
+  const int rl = lane >> 2, sq = (lane & 3) ^ ((rl >> 2) & 3);
+  unsigned aoff[4], boff[NTW];
+#pragma unroll
+  for (int t = 0; t < 4; t++) aoff[t] = (unsigned)(((long)min(16 * (wave + 4 * t) + rl, M - 1 - m0) * lda + 4 * sq) * 4);
+#pragma unroll
+  for (int t = 0; t < NTW; t++) boff[t] = (unsigned)(((long)min(16 * (wave + 4 * t) + rl, N - 1 - n0) * ldb + 4 * sq) * 4);
+  auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)kt * 64u);
+    float* ad = abuf + buf * ASZ;
+    float* bd = bbuf + buf * BSZ;
+#pragma unroll
+    for (int t = 0; t < 4; t++) bufdma16(aoff[t], ra, so, ad + (wave + 4 * t) * 256);
+#pragma unroll
+    for (int t = 0; t < NTW; t++) bufdma16(boff[t], rb, so, bd + (wave + 4 * t) * 256);
+  };
+  const int swz = (j >> 2) & 3;
+  const int fo0 = j * 16 + (((0 + h) ^ swz) << 2), fo1 = j * 16 + (((2 + h) ^ swz) << 2);
+  f32x16 acc[4][NTW];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < NTW; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+  if (nk > 0) stage(0, 0);
+  for (int kt = 0; kt < nk; kt++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);               // (requesting the first fragments before these six pieces: measured 2 % slower)
+    const float* la = abuf + (kt & 1) * ASZ;
+    const float* lb = bbuf + (kt & 1) * BSZ;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      f32x4 af[4], bf[NTW];
+#pragma unroll
+      for (int a = 0; a < 4; a++) af[a] = *(const f32x4*)(la + (wm * 128 + a * 32) * 16 + (kk ? fo1 : fo0));
+#pragma unroll
+      for (int b = 0; b < NTW; b++) bf[b] = *(const f32x4*)(lb + (wn * 32 * NTW + b * 32) * 16 + (kk ? fo1 : fo0));
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < NTW; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][e], bf[b][e], acc[a][b], 0, 0, 0);
+    }
+  }
+  gemm_store_tiles<4, NTW>(acc, C, ldc, m0 + wm * 128, n0 + wn * 32 * NTW, m0 + BM, n0 + BN, M, N, epi, 1, j, h);
+}
+
 __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ ws, int splits, float* __restrict__ C, long ldc,
                                           int M, int N, GemmEpi epi) {
   long total = (long)M * N;
@@ -538,6 +632,12 @@ static int launch_gemm_dma(const float* A, long lda, int akm, const float* B, lo
   static const int flat_on = [] { const char* e = getenv("LCTVQA_GEMM_FLAT"); return e ? atoi(e) : 1; }();
   const int flat_nb = (flat_on && batch > 1 && (long)batch * ntm >= 8 && (ntm % 8 != 0 || flat_on > 1)) ? batch : 0;
   dim3 grid(flat_nb ? (((long)batch * ntm + 7) / 8) * 8 * ntn : ntm >= 8 ? ((ntm + 7) / 8) * 8 * ntn : ntm * ntn, flat_nb ? 1 : batch, splits);
+  static const int buf_on = [] { const char* e = getenv("LCTVQA_GEMM_BUF"); return e ? atoi(e) : 1; }();
+  if (buf_on && !akm && !bkm && BN == 128 && splits == 1 && relu_ab == 0 && K % 16 == 0 && (long)256 * lda * 4 < 0x7fffff00L &&
+      (long)128 * ldb * 4 < 0x7fffff00L) {
+    hipLaunchKernelGGL(gemm_f32_nt_buf_kernel<2>, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K, epi, sA, sB, sC, flat_nb);
+    return lct_check_launch("gemm_f32_nt_buf");
+  }
   if (splits == 1) {
     hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K, kper, epi, 1, sA, sB, sC, relu_ab, flat_nb);
     return lct_check_launch("gemm_f32_dma");

@@ -42,6 +42,42 @@ struct EdgeBN {         // per slot: running statistics + batch counter (null wh
   long* tracked[NSLOT];
 };
 
+// Storage type of the nine pre-BN tensors.  The file is compiled twice: as it is (fp32, the entry points lctvqa_mixed_edge_*) and from
+// mixed_edge_bf16.hip with EDGE_PRE_BF16 (bf16 storage, entry points lctvqa_mixed_edge_*_bf16pre; darts_ops selects them under the bf16
+// compute dtype).  In the bf16 build a value is ROUNDED (nearest even) before both its store and its BatchNorm statistics, so that the
+// statistics are those of the stored tensor and every later reader (normalisation, backward x-hat, ReLU masks of the second stages) sees
+// the same numbers; all arithmetic stays fp32.
+#ifdef EDGE_PRE_BF16
+typedef unsigned short pre_t;
+#define EDGE_SYM(name) name##_bf16pre
+__device__ __forceinline__ float rndp(float v) {
+  unsigned int u = __builtin_bit_cast(unsigned int, v);
+  u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+  return __builtin_bit_cast(float, u);
+}
+__device__ __forceinline__ f32x4 ldp4(const pre_t* p) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 r = *(const u32x2*)p;
+  return f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u), __builtin_bit_cast(float, r[1] << 16),
+               __builtin_bit_cast(float, r[1] & 0xffff0000u)};
+}
+__device__ __forceinline__ void stp4(pre_t* p, f32x4 v) {      // v holds bf16-representable values (every caller has applied rndp): the low halves are zero
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  // (element copies first: __builtin_bit_cast applied directly to an ext-vector ELEMENT expression reads element 0 with this compiler)
+  const float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+  const unsigned int a = __builtin_bit_cast(unsigned int, v0) >> 16, b = __builtin_bit_cast(unsigned int, v1) & 0xffff0000u;
+  const unsigned int c = __builtin_bit_cast(unsigned int, v2) >> 16, d = __builtin_bit_cast(unsigned int, v3) & 0xffff0000u;
+  *(u32x2*)p = u32x2{a | b, c | d};
+}
+#else
+typedef float pre_t;
+#define EDGE_SYM(name) name
+__device__ __forceinline__ float rndp(float v) { return v; }
+#endif
+__device__ __forceinline__ f32x4 ldp4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ void stp4(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ f32x4 rndp4(f32x4 v) { return f32x4{rndp(v[0]), rndp(v[1]), rndp(v[2]), rndp(v[3])}; }
+
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
   return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
 }
@@ -50,8 +86,8 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 // floats); ACT 0: as stored, 1: ReLU'd, 2: normalised + ReLU'd ((v - mean) * invstd, then max 0: the input of a sep_conv's
 // second stage).  The trip counts are compile-time, so the loads of up to 8 rounds are issued back to back before the first
 // LDS store (one memory round trip per batch instead of one per round).
-template <int NQ, int ACT, int TH_, int TW_, int TPB, int BATCH_ = 0>
-__device__ __forceinline__ void load_tile(f32x4* __restrict__ tile, const float* __restrict__ src, long ld, int n, int H, int W,
+template <int NQ, int ACT, int TH_, int TW_, int TPB, int BATCH_ = 0, typename ST = float>
+__device__ __forceinline__ void load_tile(f32x4* __restrict__ tile, const ST* __restrict__ src, long ld, int n, int H, int W,
                                           int y0, int x0, const float* __restrict__ mean, const float* __restrict__ invstd, int tid_ = -1) {
   constexpr int NPOS = TH_ * TW_, TOT = NPOS * NQ, ROUNDS = (TOT + TPB - 1) / TPB, BATCH = BATCH_ ? BATCH_ : (NQ >= 4 ? 4 : 8);
   const int tid = tid_ < 0 ? (int)threadIdx.x : tid_;            // a caller may pass a laundered copy (keeps the index math inside its tile loop)
@@ -67,7 +103,7 @@ __device__ __forceinline__ void load_tile(f32x4* __restrict__ tile, const float*
       const int y = y0 + ly, x = x0 + lx;
       ok[r] = (r0 + r < ROUNDS) && idx < TOT && y >= 0 && y < H && x >= 0 && x < W;
       v[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ok[r]) v[r] = *(const f32x4*)(src + (((long)n * H + y) * W + x) * ld + 4 * q);
+      if (ok[r]) v[r] = ldp4(src + (((long)n * H + y) * W + x) * ld + 4 * q);
     }
 #pragma unroll
     for (int r = 0; r < BATCH; r++) {
@@ -189,10 +225,19 @@ __device__ __forceinline__ void phase_stats(const float (*u)[CQ], bool live, flo
   }
 }
 
-template <int CQ>
-__device__ __forceinline__ void store_row(float* __restrict__ dst, const float* __restrict__ v) {
+template <int CQ, typename DT>
+__device__ __forceinline__ void store_row(DT* __restrict__ dst, const float* __restrict__ v) {
 #pragma unroll
-  for (int q = 0; q < CQ / 4; q++) *(f32x4*)(dst + 4 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+  for (int q = 0; q < CQ / 4; q++) stp4(dst + 4 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+}
+template <int NS, int CQ>
+__device__ __forceinline__ void round_rows(float (*u)[CQ]) {       // bf16 build: the values that are stored are the values that are counted
+#ifdef EDGE_PRE_BF16
+#pragma unroll
+  for (int k = 0; k < NS; k++)
+#pragma unroll
+    for (int c = 0; c < CQ; c++) u[k][c] = rndp(u[k][c]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -201,7 +246,7 @@ __device__ __forceinline__ void store_row(float* __restrict__ dst, const float* 
 // ------------------------------------------------------------------------------------------------------------------
 template <int CQ, int S, int TH, int TW>
 __global__ __launch_bounds__(TH * TW) void edge_fwd_a_kernel(const float* __restrict__ x /* x1 rows */, long ldx, int B, int H, int W, EdgeW wts,
-                                                             float* __restrict__ pre /* [9][P][CQ] */,
+                                                             pre_t* __restrict__ pre /* [9][P][CQ] */,
                                                              double* __restrict__ part /* [grid][7*CQ][2] */) {
   constexpr int TPB = TH * TW, NQ = CQ / 4, C = 4 * CQ;
   constexpr int IH = S * (TH - 1) + 9, IW = S * (TW - 1) + 9, NPOS = IH * IW;
@@ -288,6 +333,7 @@ __global__ __launch_bounds__(TH * TW) void edge_fwd_a_kernel(const float* __rest
 #pragma unroll
         for (int c = 0; c < CQ; c++) u[2][c] = 0.f;
       }
+      round_rows<3, CQ>(u);
       if (live) {
         store_row<CQ>(pre + (0 * P + qo) * CQ, u[0]);
         store_row<CQ>(pre + (1 * P + qo) * CQ, u[1]);
@@ -308,6 +354,7 @@ __global__ __launch_bounds__(TH * TW) void edge_fwd_a_kernel(const float* __rest
       dw_at<CQ, 5, 1, true, false>(tile, NPOS, IW, cy - 2, cx - 2, scalar_ptr(wts.dw[1]), d);
       pw_at<CQ, CQ>(scalar_ptr(wts.pw[1]), d, u[1]);
 #endif
+      round_rows<2, CQ>(u);
       if (live) { store_row<CQ>(pre + (3 * P + qo) * CQ, u[0]); store_row<CQ>(pre + (4 * P + qo) * CQ, u[1]); }
       phase_stats<CQ, 2, 7, TPB>(u, live, red, seg, acc, 3);
     }
@@ -324,6 +371,7 @@ __global__ __launch_bounds__(TH * TW) void edge_fwd_a_kernel(const float* __rest
       dw_at<CQ, 5, 2, true, false>(tile, NPOS, IW, cy - 4, cx - 4, scalar_ptr(wts.dw[3]), d);
       pw_at<CQ, CQ>(scalar_ptr(wts.pw[3]), d, u[1]);
 #endif
+      round_rows<2, CQ>(u);
       if (live) { store_row<CQ>(pre + (5 * P + qo) * CQ, u[0]); store_row<CQ>(pre + (6 * P + qo) * CQ, u[1]); }
       phase_stats<CQ, 2, 7, TPB>(u, live, red, seg, acc, 5);
     }
@@ -409,7 +457,7 @@ __device__ __forceinline__ void stats_from_lds(const float* __restrict__ Us, int
 
 template <int CQ, int S, int TH, int TW, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void edge_fwd_a2_kernel(const float* __restrict__ x /* x1 rows */, long ldx, int B, int H, int W, EdgeW wts,
-                                                                 const float* __restrict__ wq, float* __restrict__ pre /* [9][P][CQ] */,
+                                                                 const float* __restrict__ wq, pre_t* __restrict__ pre /* [9][P][CQ] */,
                                                                  double* __restrict__ part /* [grid][7*CQ][2] */) {
   constexpr int TPB = 64 * NW, NPX = TH * TW, NQ = CQ / 4;
   constexpr int IH = S * (TH - 1) + 9, IW = S * (TW - 1) + 9, NPOS = IH * IW;
@@ -508,8 +556,8 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_fwd_a2_kernel(const float* __
       const float inv = 1.f / (float)max(cnt, 1);
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        Us[p * CQ + qC + NQ * e] = live ? mx[e] : 0.f;
-        Us[NPX * CQ + p * CQ + qC + NQ * e] = live ? sm[e] * inv : 0.f;     // (the first version leaves sm * inv here too: zero padding sums to 0)
+        Us[p * CQ + qC + NQ * e] = live ? rndp(mx[e]) : 0.f;
+        Us[NPX * CQ + p * CQ + qC + NQ * e] = live ? rndp(sm[e] * inv) : 0.f;     // (the first version leaves sm * inv here too: zero padding sums to 0)
       }
       *(f32x4*)(Ds + (p * NQ + qC) * 4) = dw_quad<3, 1, true, NQ>(tp - IW - 1, IW, wq0, qC);
       *(f32x4*)(Ds + NPX * CQ + (p * NQ + qC) * 4) = dw_quad<5, 1, true, NQ>(tp - 2 * IW - 2, IW, wq1, qC);
@@ -539,10 +587,11 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_fwd_a2_kernel(const float* __
       for (int m = 0; m < 4; m++) u3 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[0][m], d3[m], u3, 0, 0, 0);
 #pragma unroll
       for (int m = 0; m < 4; m++) u4 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[1][m], d5[m], u4, 0, 0, 0);
+      u2 = rndp4(u2); u3 = rndp4(u3); u4 = rndp4(u4);
       if (live) {
-        if (S == 2) *(f32x4*)(pre + (2 * P + qo) * CQ + 4 * qB) = u2;
-        *(f32x4*)(pre + (3 * P + qo) * CQ + 4 * qB) = u3;
-        *(f32x4*)(pre + (4 * P + qo) * CQ + 4 * qB) = u4;
+        if (S == 2) stp4(pre + (2 * P + qo) * CQ + 4 * qB, u2);
+        stp4(pre + (3 * P + qo) * CQ + 4 * qB, u3);
+        stp4(pre + (4 * P + qo) * CQ + 4 * qB, u4);
       }
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       *(f32x4*)(Us + 2 * NPX * CQ + pc * CQ + 4 * qB) = live ? u2 : z;
@@ -556,8 +605,8 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_fwd_a2_kernel(const float* __
       const int oy = ty0 + pc / TW, ox = tx0 + pc % TW;
       if (oy < Ho && ox < Wo) {
         const long qo = ((long)n * Ho + oy) * Wo + ox;
-        *(f32x4*)(pre + (0 * P + qo) * CQ + 4 * q) = *(const f32x4*)(Us + pc * CQ + 4 * q);
-        *(f32x4*)(pre + (1 * P + qo) * CQ + 4 * q) = *(const f32x4*)(Us + NPX * CQ + pc * CQ + 4 * q);
+        stp4(pre + (0 * P + qo) * CQ + 4 * q, *(const f32x4*)(Us + pc * CQ + 4 * q));
+        stp4(pre + (1 * P + qo) * CQ + 4 * q, *(const f32x4*)(Us + NPX * CQ + pc * CQ + 4 * q));
       }
     }
     stats_from_lds<CQ, NPX, TPB>(Us, 3, seg, acc, 0, 7);
@@ -592,9 +641,10 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_fwd_a2_kernel(const float* __
       for (int m = 0; m < 4; m++) u5 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[2][m], d3[m], u5, 0, 0, 0);
 #pragma unroll
       for (int m = 0; m < 4; m++) u6 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[3][m], d5[m], u6, 0, 0, 0);
+      u5 = rndp4(u5); u6 = rndp4(u6);
       if (live) {
-        *(f32x4*)(pre + (5 * P + qo) * CQ + 4 * qB) = u5;
-        *(f32x4*)(pre + (6 * P + qo) * CQ + 4 * qB) = u6;
+        stp4(pre + (5 * P + qo) * CQ + 4 * qB, u5);
+        stp4(pre + (6 * P + qo) * CQ + 4 * qB, u6);
       }
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       ukeep[t][0] = live ? u5 : z;
@@ -620,7 +670,7 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_fwd_a2_kernel(const float* __
 template <int CQ, int TH, int TW, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void edge_fwd_b2_kernel(int B, int Ho, int Wo, EdgeW wts, const float* __restrict__ wq,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                 float* __restrict__ pre, double* __restrict__ part /* [grid][2*CQ][2] */) {
+                                                                 pre_t* __restrict__ pre, double* __restrict__ part /* [grid][2*CQ][2] */) {
   constexpr int TPB = 64 * NW, NPX = TH * TW, NQ = CQ / 4;
   constexpr int IH = TH + 4, IW = TW + 4, NPOS = IH * IW;
   constexpr int PPW = 64 / NQ, NITP = NPX / PPW, ITP = NITP / NW, NITC = NPX / 64, ITC = NITC * NQ / NW;
@@ -671,8 +721,8 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_fwd_b2_kernel(int B, int Ho, 
           f32x4 v3 = {0.f, 0.f, 0.f, 0.f}, v5 = v3;
           if (ok) {
             const long qi = ((long)n * Ho + y) * Wo + xx;
-            v3 = *(const f32x4*)(pre + (3 * P + qi) * CQ + 4 * q);
-            v5 = *(const f32x4*)(pre + (4 * P + qi) * CQ + 4 * q);
+            v3 = ldp4(pre + (3 * P + qi) * CQ + 4 * q);
+            v5 = ldp4(pre + (4 * P + qi) * CQ + 4 * q);
           }
 #pragma unroll
           for (int e = 0; e < 4; e++) {
@@ -709,9 +759,10 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_fwd_b2_kernel(int B, int Ho, 
       for (int m = 0; m < 4; m++) u7 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[0][m], d3[m], u7, 0, 0, 0);
 #pragma unroll
       for (int m = 0; m < 4; m++) u8 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[1][m], d5[m], u8, 0, 0, 0);
+      u7 = rndp4(u7); u8 = rndp4(u8);
       if (live) {
-        *(f32x4*)(pre + (7 * P + qo) * CQ + 4 * qB) = u7;
-        *(f32x4*)(pre + (8 * P + qo) * CQ + 4 * qB) = u8;
+        stp4(pre + (7 * P + qo) * CQ + 4 * qB, u7);
+        stp4(pre + (8 * P + qo) * CQ + 4 * qB, u8);
       }
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       *(f32x4*)(Us + pc * CQ + 4 * qB) = live ? u7 : z;
@@ -732,7 +783,7 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_fwd_b2_kernel(int B, int Ho, 
 // ------------------------------------------------------------------------------------------------------------------
 template <int CQ, int TH, int TW>
 __global__ __launch_bounds__(TH * TW) void edge_fwd_b_kernel(int B, int Ho, int Wo, EdgeW wts, const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd, float* __restrict__ pre,
+                                                             const float* __restrict__ invstd, pre_t* __restrict__ pre,
                                                              double* __restrict__ part /* [grid][2*CQ][2] */) {
   constexpr int TPB = TH * TW, NQ = CQ / 4;
   constexpr int IH = TH + 4, IW = TW + 4, NPOS = IH * IW;
@@ -787,12 +838,13 @@ __global__ __launch_bounds__(TH * TW) void edge_fwd_b_kernel(int B, int Ho, int 
     pw_at<CQ, CQ>(scalar_ptr(wts.pw[5]), d, u[1]);
 #endif
     const long qo = ((long)n * Ho + oy) * Wo + ox;
+    round_rows<2, CQ>(u);
     if (live) {
 #pragma unroll
       for (int k = 0; k < 2; k++)
 #pragma unroll
         for (int q = 0; q < NQ; q++)
-          *(f32x4*)(pre + ((long)(7 + k) * P + qo) * CQ + 4 * q) = f32x4{u[k][4 * q], u[k][4 * q + 1], u[k][4 * q + 2], u[k][4 * q + 3]};
+          stp4(pre + ((long)(7 + k) * P + qo) * CQ + 4 * q, f32x4{u[k][4 * q], u[k][4 * q + 1], u[k][4 * q + 2], u[k][4 * q + 3]});
     }
     phase_stats<CQ, 2, 2, TPB>(u, live, red, seg, acc, 0);
   }
@@ -845,7 +897,7 @@ __global__ __launch_bounds__(64) void edge_stats_finish_kernel(const double* __r
 // thread = (output pixel, channel quad i..i+3) -> the 16 contiguous output channels 4i .. 4i+15
 // ------------------------------------------------------------------------------------------------------------------
 template <int S>
-__global__ __launch_bounds__(256) void edge_fwd_c_kernel(const float* __restrict__ x, const float* __restrict__ pre, const float* __restrict__ mean,
+__global__ __launch_bounds__(256) void edge_fwd_c_kernel(const float* __restrict__ x, const pre_t* __restrict__ pre, const float* __restrict__ mean,
                                   const float* __restrict__ invstd, const float* __restrict__ wsel /* [7] */,
                                   const float* __restrict__ beta, int B, int Ho, int Wo, int CQ, float* __restrict__ out, long ldo,
                                   int accumulate) {
@@ -864,7 +916,7 @@ __global__ __launch_bounds__(256) void edge_fwd_c_kernel(const float* __restrict
     for (int k = 0; k < 7; k++) {
       if (S == 1 && k == 2) continue;
       const int sl = slot_of[k];
-      const f32x4 v = *(const f32x4*)(pre + ((long)sl * P + q) * CQ + 4 * q4);
+      const f32x4 v = ldp4(pre + ((long)sl * P + q) * CQ + 4 * q4);
       const f32x4 m = *(const f32x4*)(mean + sl * CQ + 4 * q4), is = *(const f32x4*)(invstd + sl * CQ + 4 * q4);
 #pragma unroll
       for (int e = 0; e < 4; e++) mix[e] = fmaf(wk[k], (v[e] - m[e]) * is[e], mix[e]);
@@ -923,7 +975,7 @@ constexpr int COEF = 3 * 16;                                   // per slot: A[16
 
 template <int S>
 __global__ __launch_bounds__(256) void edge_bwd_sums_kernel(const float* __restrict__ dout, long ldd, const float* __restrict__ x,
-                                                            const float* __restrict__ pre, const float* __restrict__ mean,
+                                                            const pre_t* __restrict__ pre, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ beta,
                                                             int B, int Ho, int Wo, int CQ, float* __restrict__ dY,
                                                             float* __restrict__ part /* [grid][8*CQ+1] */,
@@ -950,7 +1002,7 @@ __global__ __launch_bounds__(256) void edge_bwd_sums_kernel(const float* __restr
     for (int k = 0; k < 7; k++) {
       if (S == 1 && k == 2) continue;
       const int sl = slot_of[k];
-      const f32x4 v = *(const f32x4*)(pre + ((long)sl * P + q) * CQ + 4 * q4);
+      const f32x4 v = ldp4(pre + ((long)sl * P + q) * CQ + 4 * q4);
       const f32x4 m = *(const f32x4*)(mean + sl * CQ + 4 * q4), is = *(const f32x4*)(invstd + sl * CQ + 4 * q4);
 #pragma unroll
       for (int e = 0; e < 4; e++) acc[k][e] = fmaf(dy[e], (v[e] - m[e]) * is[e], acc[k][e]);
@@ -1107,11 +1159,11 @@ __global__ __launch_bounds__(64) void edge_bwd_coef_a_kernel(const double* __res
 
 // g[oc] = A (dY - c1 - xhat c2) for one pixel, all CQ channels (rows of dY / u read from memory)
 template <int CQ>
-__device__ __forceinline__ void grad_row(const float* __restrict__ dyr, const float* __restrict__ ur, const float* __restrict__ ms /* LDS: mean[CQ], invstd[CQ] */,
+__device__ __forceinline__ void grad_row(const float* __restrict__ dyr, const pre_t* __restrict__ ur, const float* __restrict__ ms /* LDS: mean[CQ], invstd[CQ] */,
                                          const float* __restrict__ cf /* LDS: A[16], c1[16], c2[16] */, float* __restrict__ g) {
 #pragma unroll
   for (int q = 0; q < CQ / 4; q++) {
-    const f32x4 d = *(const f32x4*)(dyr + 4 * q), u = *(const f32x4*)(ur + 4 * q);
+    const f32x4 d = *(const f32x4*)(dyr + 4 * q), u = ldp4(ur + 4 * q);
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const int c = 4 * q + e;
@@ -1135,7 +1187,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <int CQ, int S, int TH, int TW>
 __global__ __launch_bounds__(TH * TW) void edge_bwd_pools_kernel(const float* __restrict__ x, const float* __restrict__ dY,
                                                                  const float* __restrict__ dout, long ldd, const float* __restrict__ beta,
-                                                                 const float* __restrict__ pre, const float* __restrict__ mean,
+                                                                 const pre_t* __restrict__ pre, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ coef,
                                                                  const float* __restrict__ dx1c, int B, int H, int W, EdgeW wts,
                                                                  float* __restrict__ dx, float* __restrict__ wpart, int wtot, int fr_off,
@@ -1417,8 +1469,9 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_pools_kernel(const float* __
 // reach the owned input pixels (backward halo), and the per-pixel rows g, d (depthwise output) for the 1x1 weight gradient.
 // ------------------------------------------------------------------------------------------------------------------
 template <int CQ, int K, int DIL, int S, int MODE, int TH, int TW>
-__global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __restrict__ in, long ldin, const float* __restrict__ gsrc /* dY or dBN */,
-                                                                const float* __restrict__ usrc /* u or t: pre-BN output of this stage */,
+__global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const typename std::conditional<MODE == 1, pre_t, float>::type* __restrict__ in, long ldin,
+                                                                const float* __restrict__ gsrc /* dY or dBN */,
+                                                                const pre_t* __restrict__ usrc /* u or t: pre-BN output of this stage */,
                                                                 const float* __restrict__ mean_o, const float* __restrict__ invstd_o,
                                                                 const float* __restrict__ coef_o, const float* __restrict__ mean_i,
                                                                 const float* __restrict__ invstd_i, const float* __restrict__ w_dw,
@@ -1495,7 +1548,7 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
         for (int q4 = 0; q4 < NQ; q4++) {
           dv[r][q4] = f32x4{0.f, 0.f, 0.f, 0.f};
           uv[r][q4] = dv[r][q4];
-          if (in[r]) { dv[r][q4] = *(const f32x4*)(gsrc + q * CQ + 4 * q4); uv[r][q4] = *(const f32x4*)(usrc + q * CQ + 4 * q4); }
+          if (in[r]) { dv[r][q4] = *(const f32x4*)(gsrc + q * CQ + 4 * q4); uv[r][q4] = ldp4(usrc + q * CQ + 4 * q4); }
         }
       }
 #pragma unroll
@@ -1702,8 +1755,9 @@ __global__ __launch_bounds__(TH * TW) void edge_bwd_conv_kernel(const float* __r
 // ------------------------------------------------------------------------------------------------------------------
 
 template <int CQ, int K, int DIL, int S, int MODE, int TH, int TW, int NW, int WPE>
-__global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_kernel(const float* __restrict__ in, long ldin, const float* __restrict__ gsrc /* dY or dBN */,
-                                                                 const float* __restrict__ usrc /* u or t: pre-BN output of this stage */,
+__global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_kernel(const typename std::conditional<MODE == 1, pre_t, float>::type* __restrict__ in, long ldin,
+                                                                 const float* __restrict__ gsrc /* dY or dBN */,
+                                                                 const pre_t* __restrict__ usrc /* u or t: pre-BN output of this stage */,
                                                                  const float* __restrict__ mean_o, const float* __restrict__ invstd_o,
                                                                  const float* __restrict__ coef_o, const float* __restrict__ mean_i,
                                                                  const float* __restrict__ invstd_i, const float* __restrict__ w_taps /* [K*K][CQ] */,
@@ -1781,7 +1835,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_kernel(const floa
             dv[u] = f32x4{1.f, 2.f, 3.f, (float)q}; uv[u] = dv[u];
 #else
             dv[u] = *(const f32x4*)(gsrc + q * CQ + 4 * qB);
-            uv[u] = *(const f32x4*)(usrc + q * CQ + 4 * qB);
+            uv[u] = ldp4(usrc + q * CQ + 4 * qB);
 #endif
           }
         }
@@ -1972,7 +2026,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_kernel(const floa
 // ------------------------------------------------------------------------------------------------------------------
 struct StageArgs {
   const float* gsrc;      // dY or dBN
-  const float* usrc;      // pre-BN output of the stage
+  const pre_t* usrc;      // pre-BN output of the stage
   const float* mean_o; const float* invstd_o; const float* coef_o;
   const float* w_taps;    // tap-major depthwise weights [K*K][CQ]
   const float* w_pw;
@@ -2061,7 +2115,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void edge_bwd_conv2_pair_kernel(const
           if (inb[u]) {
             const long q = ((long)n * Ho + oy) * Wo + ox;
             dv[u] = *(const f32x4*)(st.gsrc + q * CQ + 4 * qB);
-            uv[u] = *(const f32x4*)(st.usrc + q * CQ + 4 * qB);
+            uv[u] = ldp4(st.usrc + q * CQ + 4 * qB);
           }
         }
       };
@@ -2369,6 +2423,12 @@ constexpr int MAX_ROWS = 2048;
 
 extern "C" {
 
+#ifdef EDGE_PRE_BF16   // the shape queries are defined once, by the fp32 build of this file
+int lctvqa_mixed_edge_supported(int B, int H, int W, int C, int stride);
+int lctvqa_mixed_edge_grid(int B, int H, int W, int C, int stride);
+int lctvqa_mixed_edge_wgrad_elems(int C);
+long lctvqa_mixed_edge_bwd_scratch_floats(int B, int H, int W, int C, int stride);
+#else
 // 1 when the fused edge kernels take this shape (Cq in {4, 8, 16}; stride-2 edges need even H, W), else 0
 int lctvqa_mixed_edge_supported(int B, int H, int W, int C, int stride) {
   const int CQ = C / 4;
@@ -2396,13 +2456,15 @@ long lctvqa_mixed_edge_bwd_scratch_floats(int B, int H, int W, int C, int stride
   const long G = lctvqa_mixed_edge_grid(B, H, W, C, stride);
   return 3 * P * CQ + 2L * B * H * W * CQ + 1536L * (8 * CQ + 1) + 9 * COEF + 102 * CQ + G * lctvqa_mixed_edge_wgrad_elems(C) + 2 * (2 * G * 2 * CQ * 2) + 8;
 }
+#endif
 
 // Forward of one edge.  w: 14 pointers = dw[6], pw[6], fr[2] (fr null on stride-1 edges); bn: 27 pointers = run_mean[9],
 // run_var[9], tracked[9] (null for the identity skip); pre [9][P][Cq]; stats mean/invstd [9][Cq]; part: fp64 scratch of
 // lctvqa_mixed_edge_grid * 7*Cq * 2 doubles; wsel [7] live architecture weights (PRIMITIVES order without 'none'); beta [1];
 // out row stride ldo.
-int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride, const void* const* w, void* const* bn,
-                          float* pre, float* mean, float* invstd, double* part, const float* wsel, const float* beta,
+// (EDGE_PRE_BF16 build: lctvqa_mixed_edge_fwd_bf16pre / _bwd_bf16pre, `pre` = [9][P][Cq] bf16, everything else unchanged)
+int EDGE_SYM(lctvqa_mixed_edge_fwd)(const float* x, int B, int H, int W, int C, int stride, const void* const* w, void* const* bn,
+                          pre_t* pre, float* mean, float* invstd, double* part, const float* wsel, const float* beta,
                           float* out, long ldo, int accumulate, int training, float momentum, float eps, const float* x1d, void* stream) {
   LCT_REQUIRE(lctvqa_mixed_edge_supported(B, H, W, C, stride), "mixed_edge_fwd: unsupported shape B=%d H=%d W=%d C=%d s=%d", B, H, W, C, stride);
   LCT_REQUIRE((((uintptr_t)x | (uintptr_t)pre | (uintptr_t)out | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0 && (ldo & 3) == 0,
@@ -2415,6 +2477,7 @@ int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride
   for (int i = 0; i < NSLOT; i++) { eb.run_mean[i] = (float*)bn[i]; eb.run_var[i] = (float*)bn[9 + i]; eb.tracked[i] = (long*)bn[18 + i]; }
   const int CQ = C / 4, Ho = H / stride, Wo = W / stride;
   const long P = (long)B * Ho * Wo;
+  LCT_REQUIRE((P * CQ * (long)sizeof(pre_t)) % 16 == 0, "mixed_edge: a slot of the pre-BN buffer must be a multiple of 16 bytes (P=%ld Cq=%d)", P, CQ);
   const int rows = lctvqa_mixed_edge_grid(B, H, W, C, stride);
   const int skip_slot = stride == 1 ? 2 : -1;
   int rc, grid = 1;
@@ -2503,8 +2566,8 @@ int lctvqa_mixed_edge_fwd(const float* x, int B, int H, int W, int C, int stride
 // added to (1: the gradient buffer of a state that several edges read); dwsel [7],
 // dbeta [1]; wgrad = flat weight gradients (lctvqa_mixed_edge_wgrad_elems, order dw[6], pw[6], fr[2]); scratch >=
 // lctvqa_mixed_edge_bwd_scratch_floats floats, 16-byte aligned.
-int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, int H, int W, int C, int stride, const void* const* w,
-                          const float* pre, const float* mean, const float* invstd, const float* wsel, const float* beta, float* dx,
+int EDGE_SYM(lctvqa_mixed_edge_bwd)(const float* dout, long ldd, const float* x, int B, int H, int W, int C, int stride, const void* const* w,
+                          const pre_t* pre, const float* mean, const float* invstd, const float* wsel, const float* beta, float* dx,
                           float* dwsel, float* dbeta, float* wgrad, float* scratch, int training, int accumulate_dx, const float* x1d_in,
                           int need_wgrad, void* stream) {
   LCT_REQUIRE(lctvqa_mixed_edge_supported(B, H, W, C, stride), "mixed_edge_bwd: unsupported shape B=%d H=%d W=%d C=%d s=%d", B, H, W, C, stride);
@@ -2516,6 +2579,7 @@ int lctvqa_mixed_edge_bwd(const float* dout, long ldd, const float* x, int B, in
   ew.fr[0] = (const float*)w[12]; ew.fr[1] = (const float*)w[13];
   const int CQ = C / 4, Ho = H / stride, Wo = W / stride;
   const long P = (long)B * Ho * Wo;
+  LCT_REQUIRE((P * CQ * (long)sizeof(pre_t)) % 16 == 0, "mixed_edge: a slot of the pre-BN buffer must be a multiple of 16 bytes (P=%ld Cq=%d)", P, CQ);
   const int G = lctvqa_mixed_edge_grid(B, H, W, C, stride);
   const int wtot = lctvqa_mixed_edge_wgrad_elems(C);
   int dw_off[6], pw_off[6];

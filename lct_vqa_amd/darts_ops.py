@@ -353,6 +353,22 @@ def set_fused_edge(on):
     return prev
 
 
+EDGE_PRE_BF16 = None      # None: follow the compute dtype (bf16 storage of the pre-BN branch tensors under ops.set_compute_dtype('bf16'))
+
+
+def set_edge_pre_bf16(on):
+    """Storage of the nine pre-BatchNorm branch tensors of a fused edge: True = bf16 (values rounded before they are stored AND counted
+    into the batch statistics; fp32 arithmetic everywhere), False = fp32, None = bf16 exactly when the compute dtype is bf16.
+    Returns the previous setting."""
+    global EDGE_PRE_BF16
+    prev, EDGE_PRE_BF16 = EDGE_PRE_BF16, (None if on is None else bool(on))
+    return prev
+
+
+def edge_pre_bf16():
+    return ops.linear_xent_fused() if EDGE_PRE_BF16 is None else EDGE_PRE_BF16
+
+
 class EdgeWeightsFn(torch.autograd.Function):
     """The per-edge operands of a cell from its two weight tables in one autograd node: (w [E,K], b [E]) ->
     (w[0, lo:hi], b[0:1], w[1, lo:hi], b[1:2], ...) as views.  Taken one by one with ``w[e]`` / ``b[e]`` every edge costs a
@@ -478,7 +494,8 @@ class MixedEdgeFn(torch.autograd.Function):
         else:
             out, acc = prev, 1
             ctx.mark_dirty(prev)
-        pre = torch.empty((9, P, Cq), dtype=torch.float32, device=dev)
+        pbf = edge_pre_bf16() and (P * Cq) % 8 == 0                 # every slot of the bf16 buffer on a 16-byte boundary
+        pre = torch.empty((9, P, Cq), dtype=torch.bfloat16 if pbf else torch.float32, device=dev)
         stats = torch.empty((2, 9, Cq), dtype=torch.float32, device=dev)          # mean, invstd per slot
         grid = lib.query('mixed_edge_grid', B, H, W, C, stride)
         part = _scratch(grid * 7 * Cq * 2 + 51 * Cq, torch.float64, dev)      # + the forward kernels' regrouped depthwise weights
@@ -491,7 +508,7 @@ class MixedEdgeFn(torch.autograd.Function):
             momentum, eps = bn.momentum, bn.eps
             if bn.track_running_stats:
                 bnp[slot], bnp[9 + slot], bnp[18 + slot] = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()
-        lib('mixed_edge_fwd', x, B, H, W, C, stride, wptr, (ctypes.c_void_p * 27)(*bnp), pre, stats[0], stats[1], part, wsel, beta,
+        lib('mixed_edge_fwd_bf16pre' if pbf else 'mixed_edge_fwd', x, B, H, W, C, stride, wptr, (ctypes.c_void_p * 27)(*bnp), pre, stats[0], stats[1], part, wsel, beta,
             out, out.stride(2), acc, int(training), float(momentum), float(eps), x1d)
         ctx.save_for_backward(x, wsel, beta, pre, stats, *weights)
         ctx.params = weights                                        # the Parameter objects (ops.grad_sink accumulates into their .grad)
@@ -522,7 +539,7 @@ class MixedEdgeFn(torch.autograd.Function):
         wgrad = torch.empty(lib.query('mixed_edge_wgrad_elems', C), dtype=torch.float32, device=dev)
         scratch = _scratch(lib.query('mixed_edge_bwd_scratch_floats', B, H, W, C, stride), torch.float32, dev)
         wptr = (ctypes.c_void_p * 14)(*([w.data_ptr() for w in weights] + [None] * (14 - len(weights))))
-        lib('mixed_edge_bwd', dout, ldd, x, B, H, W, C, stride, wptr, pre, stats[0], stats[1], wsel, beta, dx, dw, dbeta,
+        lib('mixed_edge_bwd_bf16pre' if pre.dtype == torch.bfloat16 else 'mixed_edge_bwd', dout, ldd, x, B, H, W, C, stride, wptr, pre, stats[0], stats[1], wsel, beta, dx, dw, dbeta,
             wgrad, scratch, training, acc_dx, ctx.x1d, int(_WEIGHT_GRADS))
         grads, o = [], 0
         for w in weights:

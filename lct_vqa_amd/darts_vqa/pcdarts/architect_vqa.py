@@ -20,6 +20,7 @@ class Architect(object):
         self.compute_grads(img_train, qst_train, label_train, img_valid, qst_valid, label_valid, eta, unrolled)
         self.optimizer.step()
 
+    @bilevel.architecture_pass
     def compute_grads(self, img_train, qst_train, label_train, img_valid, qst_valid, label_valid, eta, unrolled=True):
         """Leave the architecture gradient in the ``.grad`` of the architecture parameters (no optimizer step)."""
         alphas = self.model.arch_parameters()

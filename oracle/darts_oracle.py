@@ -12,8 +12,14 @@ PRIMITIVES = ['none', 'max_pool_3x3', 'avg_pool_3x3', 'skip_connect', 'sep_conv_
               'dil_conv_3x3', 'dil_conv_5x5']
 
 
+PRE_BN_ROUND = None      # test hook (tests/test_gpu_edge.py): a callable applied to every BatchNorm INPUT, used to restate the bf16 STORAGE of
+                         # the pre-BN tensors of the fused edge kernels (round to bf16, straight-through gradient); None = the reference
+
+
 def _bn(x, P, key, train, new_stats, affine=False):
     """nn.BatchNorm2d(momentum 0.1, eps 1e-5)."""
+    if PRE_BN_ROUND is not None:
+        x = PRE_BN_ROUND(x)
     w = P.get(key + '.weight') if affine else None
     b = P.get(key + '.bias') if affine else None
     rm, rv = P[key + '.running_mean'].clone(), P[key + '.running_var'].clone()

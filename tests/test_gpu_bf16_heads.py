@@ -214,9 +214,13 @@ def test_resnet_gru_model_train_step_bf16(hip_lib, bf16_mode):
 def test_darts_vqa_weight_step_bf16_vs_fp32(hip_lib, bf16_mode):
     """BASELINE configs[4]'s model (darts_vqa VqaModel with the PC-DARTS search encoder) under the bf16 compute dtype at its own
     shapes (224x224, QV = 17 858, A = 3129, B = 2): the heads -- encoder fc 12544 -> 512, LSTM input projection, fused token head +
-    cross entropy, fusion fc1 / fc2 -- run on the bf16 GEMMs, the MixedOp edges stay fp32 (HBM-bound stencils: DESIGN.md).  One
-    weight step against the same step in fp32: loss 2e-3, every gradient within 5e-2 of its largest entry (alpha / beta included),
-    and the fused token-head path is really taken (no [B,T,QV] logits tensor is allocated)."""
+    cross entropy, fusion fc1 / fc2 -- run on the bf16 GEMMs; the MixedOp edges compute in fp32 and STORE their nine pre-BatchNorm branch
+    tensors in bf16 (round 4; pinned kernel by kernel against the oracle with the same roundings at 1e-3:
+    tests/test_gpu_edge.py::test_fused_edge_bf16_storage_vs_oracle).  One weight step against the same step in fp32: loss 2e-3; the
+    gradients of the heads and of alpha / beta within 5e-2 of their largest entry; the encoder's parameters -- whose gradients cross up to
+    56 edges in which a pre-activation within one bf16 rounding of zero takes the other ReLU branch than in fp32 -- cosine >= 0.97 and
+    the largest deviation of an entry within 3.5e-1 of the tensor's largest entry (measured at this B = 2: cosine >= 0.994, 0.23 on one
+    16 x 16 pointwise weight, 0.09 at the stem).  The fused token-head path is really taken (no [B,T,QV] logits tensor)."""
     ops = bf16_mode
     from lct_vqa_amd.darts_vqa import config, vqa_model
     from lct_vqa_amd.basic_vqa import config as bconfig
@@ -246,7 +250,11 @@ def test_darts_vqa_weight_step_bf16_vs_fp32(hip_lib, bf16_mode):
     assert abs(l16 - l32) < 2e-3 * abs(l32)
     for (n, _), a, r in zip(list(m.named_parameters()) + [(f'arch{i}', None) for i in range(4)], g16, g32):
         assert torch.isfinite(a).all(), n
-        assert rel_err(a, r) < 5e-2, (n, rel_err(a, r))
+        if n.startswith('img_encoder.darts'):
+            cos = torch.nn.functional.cosine_similarity(a.flatten().double(), r.flatten().double(), dim=0).item()
+            assert rel_err(a, r) < 3.5e-1 and cos > 0.97, (n, rel_err(a, r), cos)
+        else:
+            assert rel_err(a, r) < 5e-2, (n, rel_err(a, r))
 
 
 def test_trainable_resnet_gru_bf16_vs_fp32(hip_lib, bf16_mode):

@@ -29,7 +29,35 @@ RAGGED_SHAPES = [(16, 1, 2, 40, 72), (16, 2, 2, 40, 72), (32, 1, 2, 20, 68), (32
                  (16, 1, 1, 9, 33), (64, 1, 3, 7, 7)]
 
 
-def _case(hip_lib, C, stride, B, H, W, training, with_prev, seed):
+class _RoundBf16(torch.autograd.Function):
+    """x -> bf16 -> fp32 with a straight-through gradient: what storing a tensor in bf16 does to the values every later reader sees"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _case(hip_lib, C, stride, B, H, W, training, with_prev, seed, pre_bf16=False):
+    """pre_bf16: the build of the edge kernels that STORES the nine pre-BN tensors as bf16 (lctvqa_mixed_edge_*_bf16pre) against the oracle
+    with every BatchNorm input rounded to bf16 (same decisions: the statistics, the normalisation, the backward x-hat and the ReLU masks of
+    the sep_conv second stages all see the rounded numbers); tolerance 1e-3 (a value that the CPU and the GPU arithmetic round to different
+    bf16 neighbours moves by 2^-8 of itself)."""
+    from lct_vqa_amd import darts_ops as D
+    from oracle import darts_oracle as DO
+    prev_flag = D.set_edge_pre_bf16(pre_bf16)
+    DO.PRE_BN_ROUND = _RoundBf16.apply if pre_bf16 else None
+    try:
+        _case_body(hip_lib, C, stride, B, H, W, training, with_prev, seed, 1e-3 if pre_bf16 else TOL, 1e-4 if pre_bf16 else 1e-5)
+    finally:
+        D.set_edge_pre_bf16(prev_flag)
+        DO.PRE_BN_ROUND = None
+
+
+def _case_body(hip_lib, C, stride, B, H, W, training, with_prev, seed, TOL, BUF_TOL):
     from lct_vqa_amd import darts_ops as D
     from lct_vqa_amd.basic_vqa import config
     from lct_vqa_amd.basic_vqa.pcdarts import model_search as MS
@@ -88,7 +116,7 @@ def _case(hip_lib, C, stride, B, H, W, training, with_prev, seed):
         sd = mod.state_dict()
         for k, v in ns.items():
             e = rel_err(sd[k[2:]], v)
-            if not e < 1e-5:
+            if not e < BUF_TOL:
                 bad['buf ' + k] = e
         for k, v in sd.items():
             if k.endswith('num_batches_tracked'):
@@ -111,6 +139,15 @@ def test_fused_edge_at_encoder_shapes_vs_oracle(hip_lib, C, stride, B, H, W):
 @pytest.mark.parametrize('training,with_prev', [(True, False), (True, True), (False, True)])
 def test_fused_edge_at_ragged_multi_tile_maps_vs_oracle(hip_lib, C, stride, B, H, W, training, with_prev):
     _case(hip_lib, C, stride, B, H, W, training, with_prev, 300 + C + stride + H)
+
+
+@pytest.mark.parametrize('C,stride,B,H,W', ENCODER_SHAPES + [(16, 2, 2, 40, 72), (32, 1, 2, 20, 68), (64, 1, 1, 18, 50), (64, 2, 2, 36, 44), (16, 1, 2, 9, 34)])
+def test_fused_edge_bf16_storage_vs_oracle(hip_lib, C, stride, B, H, W):
+    """bf16 STORAGE of the pre-BN branch tensors (the darts_vqa step under the bf16 compute dtype): output, running statistics, dx, d alpha,
+    d beta, d prev and every weight gradient against the oracle with the same roundings, train and eval mode."""
+    assert (B * (H // stride) * (W // stride) * (C // 4)) % 8 == 0, 'a shape the bf16 build takes (16-byte aligned slots)'
+    _case(hip_lib, C, stride, B, H, W, True, True, 500 + C + stride, pre_bf16=True)
+    _case(hip_lib, C, stride, B, H, W, False, False, 600 + C + stride, pre_bf16=True)
 
 
 def test_fused_edge_gradient_through_a_strided_slice_of_the_cell_output(hip_lib):

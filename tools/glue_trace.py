@@ -40,3 +40,19 @@ rows.sort(reverse=True)
 print('count  device_ms  op  shapes')
 for r in rows[:45]:
     print(f'{r[0]:6d} {r[1]:9.3f}  {r[2]:28s} {r[3]}')
+print('\nby call count (every aten op, device time or not)')
+cnt = {}
+for e in prof.key_averages(group_by_input_shape=True):
+    if e.key.startswith('aten::'):
+        k = (e.key, str(e.input_shapes)[:90])
+        cnt[k] = cnt.get(k, 0) + e.count
+for (k, sh), c in sorted(cnt.items(), key=lambda kv: -kv[1])[:40]:
+    print(f'{c:6d}  {k:28s} {sh}')
+print('\nmemcpy / memset events')
+mc = {}
+for e in prof.events():
+    n = e.name
+    if 'emcpy' in n or 'emset' in n or 'copyBuffer' in n:
+        mc[n] = mc.get(n, 0) + 1
+for n, c in sorted(mc.items(), key=lambda kv: -kv[1])[:10]:
+    print(f'{c:6d}  {n}')
