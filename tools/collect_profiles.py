@@ -23,7 +23,8 @@ def main():
     names = {'kt_f32': 'kernel_stats_bench_f32_b256', 'kt_bf16': 'kernel_stats_bench_bf16_b256', 'kt_lct': 'kernel_stats_bench_lct_b256',
              'kt_lct_bf16': 'kernel_stats_bench_lct_bf16_b256', 'kt_darts_enc': 'kernel_stats_darts_encoder_b16',
              'kt_darts_vqa': 'kernel_stats_darts_vqa_b64', 'kt_resnet_train_bf16': 'kernel_stats_resnet_train_bf16_b256',
-             'kt_lct_train_bf16': 'kernel_stats_lct_train_bf16_b256'}
+             'kt_lct_train_bf16': 'kernel_stats_lct_train_bf16_b256', 'kt_darts_vqa_bf16': 'kernel_stats_darts_vqa_bf16_b64',
+             'kt_lct_bf16_1s': 'kernel_stats_bench_lct_bf16_one_stream_b256'}
     copied = []
     for d, n in names.items():
         f = glob.glob(os.path.join(src, d, '**', '*kernel_stats.csv'), recursive=True)
@@ -41,6 +42,7 @@ def main():
             copied.append(f'{tag}_bench_{dt}_under_rocprof.json')
     for f, n in (('kt_lct.json', 'bench_lct_under_rocprof.json'), ('kt_lct_bf16.json', 'bench_lct_bf16_under_rocprof.json'),
                  ('kt_darts_vqa.json', 'bench_darts_vqa_under_rocprof.json'), ('kt_darts_enc.txt', 'darts_encoder_b16.txt'),
+                 ('kt_darts_vqa_bf16.json', 'bench_darts_vqa_bf16_under_rocprof.json'), ('kt_lct_bf16_1s.json', 'bench_lct_bf16_one_stream_under_rocprof.json'),
                  ('kt_resnet_train_bf16.json', 'bench_resnet_train_bf16_under_rocprof.json'), ('kt_lct_train_bf16.json', 'bench_lct_train_bf16_under_rocprof.json'),
                  ('pmc_resnet_train_bf16.json', 'pmc_resnet_train_bf16.json')):
         p = os.path.join(src, f)

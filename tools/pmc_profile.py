@@ -30,13 +30,13 @@ GRID = {}          # (pass directory, dispatch id) -> work-items of the dispatch
 
 def in_conv_family(k, d, disp):
     """Kernels of the trunk's 3x3 convolutions: the fused kernels, and the three kernels of the split F(4x4,3x3) path -- its input
-    and output transforms by name, its 36 batched transformed-domain products as the gemm_f32_dma_kernel dispatches of more than 2000
+    and output transforms by name, its 36 batched transformed-domain products as the gemm_f32_nt_buf_kernel / gemm_f32_dma_kernel dispatches of more than 2000
     workgroups (the heads' products on the same kernel are far smaller)."""
     if 'conv3x3_mfma_kernel' in k or 'conv3x3_wino' in k or 'conv3x3_bf16_kernel' in k:
         return True
     if 'wino4_wgrad_xform_x' in k or 'wino4_split_out_kernel' in k:
         return True
-    return 'gemm_f32_dma_kernel' in k and GRID.get((d, disp), 0) >= 2000 * 256
+    return ('gemm_f32_dma_kernel' in k or 'gemm_f32_nt_buf_kernel' in k) and GRID.get((d, disp), 0) >= 2000 * 256
 
 
 def is_layer_launch(k):

@@ -28,6 +28,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_lct -o kt -- pytho
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_lct_bf16 -o kt -- python3 $R/bench.py --workload lct --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > $O/kt_lct_bf16.json 2> $O/kt_lct_bf16.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_darts_enc -o kt -- python3 $R/tools/bench_darts.py --batch 16 --iters 6 > $O/kt_darts_enc.txt 2> $O/kt_darts_enc.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_darts_vqa -o kt -- python3 $R/bench.py --workload darts_vqa --batch 64 --steps 4 --warmup 1 --no-cpu-baseline > $O/kt_darts_vqa.json 2> $O/kt_darts_vqa.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_darts_vqa_bf16 -o kt -- python3 $R/bench.py --workload darts_vqa --batch 64 --dtype bf16 --steps 4 --warmup 1 --no-cpu-baseline > $O/kt_darts_vqa_bf16.json 2> $O/kt_darts_vqa_bf16.err
+# the bf16 LCT step on ONE stream: kernel durations without a convolution sharing the chip (the recurrent step's own share)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_lct_bf16_1s -o kt -- python3 $R/bench.py --workload lct --dtype bf16 --no-pipeline --steps 5 --warmup 2 --no-cpu-baseline > $O/kt_lct_bf16_1s.json 2> $O/kt_lct_bf16_1s.err
 fi
 if [ "$PART" != "base" ]; then
 # round 4: the bf16-native trainable trunks -- kernel-trace summaries, and the PMC passes of the ResNet-152 + GRU step (its
