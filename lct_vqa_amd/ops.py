@@ -859,6 +859,8 @@ _conv_algo = os.environ.get('LCTVQA_CONV_ALGO', 'winograd')   # see set_conv_alg
 
 _CONV_ALGOS = ('winograd', 'winograd2', 'direct')
 _wino4_split = os.environ.get('LCTVQA_WINO4_SPLIT', '1') != '0'     # A/B switch of the split F(4x4,3x3) path (see _conv_block)
+_SPLIT_CIN = int(os.environ.get('LCTVQA_SPLIT_CIN', '256'))        # least input channels of a layer that takes it (512: the rule until the batched GEMM
+                                                                    # got its flat grid and buffer addressing; 256 adds conv4_1: 31.60 -> 31.39 ms/step)
 
 
 def set_wino4_split(on=True):
@@ -1002,11 +1004,11 @@ def _conv_block(cur, w, b, B, H, W, pool, cache=False, relu=1):
     dev = cur.device
     Cout, Cin = w.shape[0], w.shape[1]
     wv = _wino_variant(B, H, W, Cin, Cout, pool)
-    if wv == 'wino4' and _wino4_split and H * W <= 28 * 28 and Cin >= 512 and Cout >= 512 and B * H * W >= 4096:
+    if wv == 'wino4' and _wino4_split and H * W <= 28 * 28 and Cin >= _SPLIT_CIN and Cout >= 512 and B * H * W >= 4096:
         # F(4x4,3x3) as input transform + 36 batched fp32 GEMMs + output transform (csrc/conv3x3_wino_wgrad.hip, round 4): faster than
         # the fused kernel on the 28x28 and 14x14 512 -> 512 layers (profiles/r04_ab_wino_split.txt: 2.59 vs 2.85, 0.84 vs 0.93 ms alone on
-        # the chip at B = 256; inside the two-stream step 2.56 vs 2.87 with the pool, 0.76 vs 0.83), slower at 56x56 and, inside the
-        # step, on 28x28 256 -> 512; same arithmetic (exact fp32 MFMA products, the published transform matrices), 6e-6 apart
+        # the chip at B = 256; inside the two-stream step 2.56 vs 2.87 with the pool, 0.76 vs 0.83), slower at 56x56; the 28x28 256 -> 512 layer lost inside the
+        # step until the batched GEMM got its flat grid and buffer-addressed DMA (_SPLIT_CIN); same arithmetic (exact fp32 MFMA products, the published transform matrices), 6e-6 apart
         U = _packed_weights(w, 'wino4split', 36 * Cout * Cin, lambda dst: lib('conv3x3_wino4_split_pack_weights', w, dst, Cout, Cin), cache)
         n = lib.query('conv3x3_wino4_split_workspace_elems', B, H, W, Cin, Cout)
         ws = _workspace(4 * n, dev)

@@ -76,6 +76,36 @@ def test_conv3x3_winograd_f4x4(hip_lib, B, H, W, Cin, Cout, pool):
     assert _wino_case(hip_lib, B, H, W, Cin, Cout, 0, seed=1, variant='wino4', relu=0, flip=1) < 3e-5      # dgrad form
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout,pool', [
+    (8, 28, 28, 512, 512, 0), (6, 28, 28, 256, 512, 0), (5, 28, 28, 512, 512, 1),     # the headline's 28x28 layers (49 tiles per image)
+    (24, 14, 14, 512, 512, 0), (21, 14, 14, 512, 512, 1),                             # 14x14 on a padded 16x16 tile grid
+    (3, 12, 20, 128, 256, 0), (2, 30, 30, 64, 128, 1),                                # ragged tile grids, other channel counts
+])
+def test_conv3x3_winograd_f4x4_split_path(hip_lib, B, H, W, Cin, Cout, pool):
+    """F(4x4,3x3) as input transform + 36 batched fp32 GEMMs + output transform (conv3x3_wino4_split_nhwc: what bench.py's headline runs on
+    the 28x28 / 14x14 layers with >= 256 input channels) against an fp64 convolution: the fused kernel's error budget (3e-5 of the
+    layer's largest output).  Tile counts that are not multiples of 256 rows, and member x row-block counts that are not multiples of 8,
+    take the batched GEMM's ragged and flat-grid paths."""
+    g = torch.Generator().manual_seed(B * H + Cin + pool)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    U = torch.empty(36 * Cout * Cin, device=DEV)
+    hip_lib('conv3x3_wino4_split_pack_weights', w.to(DEV), U, Cout, Cin)
+    ws = torch.empty(hip_lib.query('conv3x3_wino4_split_workspace_elems', B, H, W, Cin, Cout), device=DEV)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.full((B, Ho, Wo, Cout), float('nan'), device=DEV)
+    hip_lib('conv3x3_wino4_split_nhwc', xd, U, b.to(DEV), y, ws, ws.numel(), B, H, W, Cin, Cout, 1, pool)
+    torch.cuda.synchronize()
+    got = y.permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got).all()
+    assert rel_err(got, ref.float()) < 3e-5
+
+
 def test_conv3x3_winograd_f4x4_full_res_and_limits(hip_lib):
     for (H, Cin, Cout, pool) in [(224, 64, 64, 1), (112, 64, 128, 0)]:
         assert _wino_case(hip_lib, 1, H, H, Cin, Cout, pool, variant='wino4') < 3e-5
