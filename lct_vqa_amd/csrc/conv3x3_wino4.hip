@@ -231,6 +231,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
     for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
   const float* ubg0 = up + (long)(n_tile * 2) * NCH * UCH + (h * 32 + j) * 4;     // channel group cg = 0 / 1 of this n_tile
   const float* ubg1 = ubg0 + (long)NCH * UCH;
+#ifndef W4_GLOBALW   // (-DW4_GLOBALW: the global_load form, for the A/B -- same process, 8 layers at B = 256: 30.65 vs 30.30 ms)
+  // the packed weights through BUFFER loads: a wave-uniform descriptor on this n_tile's two channel groups, the lane's 16 bytes as the only
+  // vector offset (loop-invariant), and (channel group, chunk, tile) as a SCALAR byte offset -- no 64-bit vector address arithmetic in the
+  // loop (the global_load form pays a v_add_co / v_addc pair on every fourth load)
+  typedef int w4_i32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int w4_u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void*)(up + (long)(n_tile * 2) * NCH * UCH), 0,
+                                                                         (int)(2L * NCH * UCH * 4), 0x00020000);
+  const int uvo = (h * 32 + j) * 16;
+  const int ucg1 = (int)((long)NCH * UCH * 4);
+#define W4_LDW(CG1, CH, XN) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uvo, ((CG1) ? ucg1 : 0) + (int)((long)(CH) * UCH * 4) + (XN) * 1024, 0))
+#else
+#define W4_LDW(CG1, CH, XN) (*(const f32x4*)(((CG1) ? ubg1 : ubg0) + (long)(CH) * UCH + (XN) * 256))
+#endif
   const float* va0 = V + h * 128 + j * 4;
   // accumulator tiles per wave (sum 72).  Default 8 8 8 8 | 9 9 11 11 (SIMDs 17 17 19 19).
 #ifndef W4_N0
@@ -280,9 +294,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
     W4_SB();                                                                                          \
     W4_MF(S, ACUR, 3, R);                                                                             \
     if ((S) + (R) < (NTW)) {                                                                          \
-      Bw[(S) % (R)] = *(const f32x4*)(W4_UB(T0, (S) + (R)) + (long)chunk * UCH + W4_XN(T0, (S) + (R)) * 256);   \
+      Bw[(S) % (R)] = W4_LDW(((T0) + (S) + (R)) / 36, chunk, W4_XN(T0, (S) + (R)));                       \
     } else if (NXT) {                                                                                 \
-      Bw[(S) % (R)] = *(const f32x4*)(W4_UB(T0, (S) % (R)) + (long)(chunk + 1) * UCH + W4_XN(T0, (S) % (R)) * 256); \
+      Bw[(S) % (R)] = W4_LDW(((T0) + (S) % (R)) / 36, chunk + 1, W4_XN(T0, (S) % (R)));                   \
     }                                                                                                 \
     W4_SB();                                                                                          \
   }
@@ -319,7 +333,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
 #pragma unroll
   for (int sl = 0; sl < 5; sl++) {
     const int t = t0w + sl;
-    if (sl < ringw) Bw[sl] = *(const f32x4*)((t >= 36 ? ubg1 : ubg0) + (t % 36) * 256);
+    if (sl < ringw) Bw[sl] = W4_LDW(t >= 36, 0, t % 36);
   }
   // builtin (not asm): the compiler's waitcnt bookkeeping then sees the prologue loads retired and derives the counted
   // waits of the loop from the loop's own issue order.  0x0F70 = vmcnt(0), expcnt/lgkmcnt untouched.
