@@ -39,6 +39,25 @@ __device__ __forceinline__ void glds16_opaque(const float* g, float* lds_wave_ba
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
 }
 
+// The same copy with BUFFER addressing: a wave-uniform 128-bit descriptor (lct_make_rsrc on a wave-uniform base pointer), the lane's byte
+// offset (32 bits, usually loop-invariant) and a wave-uniform byte offset in an SGPR (the loop's advance): no 64-bit vector address
+// arithmetic per copy.  Opaque to the compiler's waitcnt bookkeeping like glds16_opaque.  Every lane must address bytes inside the
+// buffer (a range-checked lane does not write its LDS slot): callers clamp, they do not mask.
+typedef int lct_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ lct_i32x4 lct_make_rsrc(const void* base) {
+  const unsigned long a = (unsigned long)(uintptr_t)base;
+  lct_i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);     // stride 0: raw buffer
+  r[2] = 0x7ffffff0;                                                             // bytes addressable from base
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void bufdma16(unsigned voff, lct_i32x4 rsrc, unsigned soff, float* lds_wave_base) {
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) void*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(l) : "memory", "m0");
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

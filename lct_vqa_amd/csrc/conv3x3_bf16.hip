@@ -162,13 +162,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const unsigned sho
       }
     }
   };
-  auto stage_w = [&](int s, float* dst) {
+  // The step's weight tile.  BUFFER-addressed LDS-DMA (common.h: bufdma16): the lane's byte offset inside its piece is loop-invariant and
+  // the step a scalar byte offset -- no per-step 64-bit address arithmetic on the vector ALU.  Same process, B = 256 (tools/ab_conv_bf16.py,
+  // -DBF16_W_GLOBAL for the A/B): -1.4 ... -3.8 % on the 112x112 and 56x56 layers, +-0 at 28x28 / 14x14, +4.6 % on conv1_2's 8x32 patch,
+  // which keeps the global_load_lds form.
+#ifdef BF16_W_GLOBAL
+  constexpr bool WBUF = false;
+#else
+  constexpr bool WBUF = TW != 32;
+#endif
+  const lct_i32x4 wrs = lct_make_rsrc(wsrc);
+  unsigned wvo[(WCHUNKS + 255) / 256];
 #pragma unroll
-    for (int r = 0; r < (WCHUNKS + 255) / 256; r++) {
-      const int q = r * 256 + tid;
-      if (WCHUNKS >= 256 * (r + 1) || q < WCHUNKS) {
-        const int piece = q >> 7, within = q & 127;
-        glds16((const float*)(wsrc + ((long)piece * S + s) * 1024 + within * 8), dst + (r * 256 + wave * 64) * 4);
+  for (int r = 0; r < (WCHUNKS + 255) / 256; r++) {
+    const int q = min(r * 256 + tid, WCHUNKS - 1);
+    wvo[r] = (unsigned)((((long)(q >> 7) * S) * 1024 + (q & 127) * 8) * 2);
+  }
+  auto stage_w = [&](int s, float* dst) {
+    if constexpr (WBUF) {
+      const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)s * 2048u);
+#pragma unroll
+      for (int r = 0; r < (WCHUNKS + 255) / 256; r++) {
+        // (WCHUNKS is a multiple of 128: a wave is inside a round or outside it as a whole)
+        if (WCHUNKS >= 256 * (r + 1) || r * 256 + wave * 64 < WCHUNKS) bufdma16(wvo[r], wrs, so, dst + (r * 256 + wave * 64) * 4);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < (WCHUNKS + 255) / 256; r++) {
+        const int q = r * 256 + tid;
+        if (WCHUNKS >= 256 * (r + 1) || q < WCHUNKS) {
+          const int piece = q >> 7, within = q & 127;
+          glds16((const float*)(wsrc + ((long)piece * S + s) * 1024 + within * 8), dst + (r * 256 + wave * 64) * 4);
+        }
       }
     }
   };

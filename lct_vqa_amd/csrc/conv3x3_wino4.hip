@@ -266,7 +266,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(const float* __re
 #define W4_T7 (W4_T6 + W4_N6)
   static_assert(W4_T7 + W4_N7 == 72, "the eight waves must cover the 72 accumulator tiles");
   // ring size of the weight registers for a wave with N steps: every load needs at least three steps of lead (see below)
-#define W4_RING(N) ((N) == 6 ? 3 : ((N) % 4 == 1 || (N) == 10) ? 5 : 4)
+#define W4_RING(N) ((N) == 6 ? 3 : ((N) % 4 == 1 || (N) == 10) ? 5 : 4)   // (round 4: 5 slots for every wave measured +2 %: 256 registers, spills)
   const int t0w = wave == 0 ? 0 : wave == 1 ? W4_T1 : wave == 2 ? W4_T2 : wave == 3 ? W4_T3 : wave == 4 ? W4_T4 : wave == 5 ? W4_T5
                   : wave == 6 ? W4_T6 : W4_T7;
   const int ringw = wave == 0 ? W4_RING(W4_N0) : wave == 1 ? W4_RING(W4_N1) : wave == 2 ? W4_RING(W4_N2) : wave == 3 ? W4_RING(W4_N3)

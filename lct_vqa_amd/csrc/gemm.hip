@@ -386,21 +386,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __res
 // wave-uniform 128-bit descriptor (SGPRs), one 32-bit byte offset per lane that is the same for every K step, and the step's byte offset
 // as a scalar -- no per-step address arithmetic on the vector ALU and half the address registers of `global_load_lds` (64-bit per lane).
 // Rows past M / N are CLAMPED to the last row (their products land in output rows / columns that the epilogue does not store).
-typedef int gemm_i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void bufdma16(unsigned voff, gemm_i32x4 rsrc, unsigned soff, float* lds_wave_base) {
-  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) void*)lds_wave_base);
-  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(l) : "memory", "m0");
-}
-__device__ __forceinline__ gemm_i32x4 make_rsrc(const float* base) {
-  const unsigned long a = (unsigned long)(uintptr_t)base;
-  gemm_i32x4 r;
-  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);     // stride 0: raw buffer
-  r[2] = 0x7ffffff0;                                                             // bytes addressable from base
-  r[3] = 0x00020000;
-  return r;
-}
-
 template <int NTW>
 __global__ __launch_bounds__(256, 2) void gemm_f32_nt_buf_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb,
                                                                  float* __restrict__ C, long ldc, int M, int N, int K, GemmEpi epi, long sA,
@@ -424,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_buf_kernel(const float* __
   if (tm >= ntm) return;
   const int m0 = tm * BM, n0 = tn * BN;
   A += (long)nb * sA + (long)m0 * lda; B += (long)nb * sB + (long)n0 * ldb; C += (long)nb * sC;
-  const gemm_i32x4 ra = make_rsrc(A), rb = make_rsrc(B);
+  const lct_i32x4 ra = lct_make_rsrc(A), rb = lct_make_rsrc(B);
   const int nk = K / 16;
   const int rl = lane >> 2, sq = (lane & 3) ^ ((rl >> 2) & 3);
   unsigned aoff[4], boff[NTW];
