@@ -127,3 +127,37 @@ def test_cached_twin_is_indistinguishable_from_a_fresh_one():
     other = Toy(4)                                              # a different model under the same cache: starts over
     t = bilevel.virtual_step(other, [torch.zeros_like(p) for p in other.parameters()], 0.1, cache)
     assert t is not first and t.w1.shape == (4,)
+
+
+def test_architecture_passes_keep_fp32_edge_storage_and_restore_the_setting():
+    """Every architect's compute_grads is wrapped in bilevel.architecture_pass: inside, the fused MixedOp edges store their pre-BN tensors in
+    fp32 whatever the compute dtype (a finite difference of two gradients does not survive an 8-bit mantissa); the caller's setting comes
+    back afterwards, also when the pass raises."""
+    from lct_vqa_amd import darts_ops, ops
+    from lct_vqa_amd.basic_vqa.pcdarts import architect, architect_lct
+    from lct_vqa_amd.darts_vqa.pcdarts import architect_vqa
+    for cls in (architect.Architect, architect_lct.ArchitectLct, architect_vqa.Architect):
+        assert getattr(cls.compute_grads, '__wrapped__', None) is not None, cls
+    prev_dtype = ops.set_compute_dtype('bf16')
+    prev = darts_ops.set_edge_pre_bf16(None)
+    try:
+        assert darts_ops.edge_pre_bf16() is True                  # follows the compute dtype
+        seen = []
+
+        @bilevel.architecture_pass
+        def inside(fail):
+            seen.append(darts_ops.edge_pre_bf16())
+            if fail:
+                raise RuntimeError('boom')
+            return 7
+
+        assert inside(False) == 7 and seen == [False]
+        assert darts_ops.edge_pre_bf16() is True
+        with pytest.raises(RuntimeError):
+            inside(True)
+        assert darts_ops.edge_pre_bf16() is True and darts_ops.EDGE_PRE_BF16 is None
+        darts_ops.set_edge_pre_bf16(False)
+        assert darts_ops.edge_pre_bf16() is False
+    finally:
+        darts_ops.set_edge_pre_bf16(prev)
+        ops.set_compute_dtype(prev_dtype)
