@@ -110,7 +110,7 @@ class MixedOp(nn.Module):
             wsel = weights[idx]
         if beta is None:
             beta = torch.ones(1, dtype=torch.float32, device=x.device)
-        plan = self._fused_plan() if D.FUSED_EDGE else None
+        plan = self._fused_plan() if D.fused_edge_active() else None
         if plan is not None and D.lib.query('mixed_edge_supported', *x.shape, self.stride):
             bns, mods = plan
             modes = {b.training or not b.track_running_stats for b in bns if b is not None}
@@ -141,7 +141,7 @@ class Cell(nn.Module):
             parts = D.EdgeWeightsFn.apply(weights, weights2, live[0], live[-1] + 1)     # every edge's operands, one autograd node
         # a state is read by up to four edges and by the concatenation: one alias per reader (D.FanoutFn), the edges' input gradients
         # meet in one buffer inside their kernels instead of in ATen adds
-        fan = D.FUSED_EDGE and parts is not None and torch.is_grad_enabled()
+        fan = D.fused_edge_active() and parts is not None and torch.is_grad_enabled()
         nstates = self._steps + 2
         readers = [sum(1 for first, last in _node_slices(self._steps) if last - first > i) + (1 if i >= nstates - self._multiplier else 0)
                    for i in range(nstates)]
@@ -150,7 +150,7 @@ class Cell(nn.Module):
 
         def x1_of(i):
             """dense x[..., :C/4] of state i when at least two fused edges read it (one strided pass instead of one per reader)"""
-            if not (D.FUSED_EDGE and parts is not None) or edge_readers[i] < 2:
+            if not (D.fused_edge_active() and parts is not None) or edge_readers[i] < 2:
                 return None
             if i not in dense:
                 with torch.no_grad():

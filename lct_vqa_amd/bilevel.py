@@ -60,7 +60,8 @@ def data_parallel(on=True, process_group=None):
     What it equals: for models WITHOUT BatchNorm (VGG / LSTM / fusion head) the single-process step on the concatenated batch
     (losses are means over samples; equal shards).  For the PC-DARTS and trainable ResNet encoders it equals N reference
     processes whose gradients are averaged: BatchNorm uses each rank's own batch statistics (the reference's semantics per
-    process; a SyncBN that all-reduces the per-channel sums between the statistics kernels and their finish is not built), and
+    process; ``parallel.set_sync_bn(True)`` pools the per-channel sums of all ranks instead -- the PC-DARTS network then runs its
+    per-primitive kernels), and
     the running statistics are per rank -- ``parallel.broadcast_buffers(model)`` copies rank 0's to every rank (before a
     validation pass or a checkpoint)."""
     prev = _dp['on']

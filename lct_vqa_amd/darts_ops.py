@@ -175,21 +175,76 @@ def _bn_backward(dy, x, mean, invstd, gamma, training):
     return dx, dg, db
 
 
+_unit = {}
+
+
+def _unit_affine(C, dev):
+    """(ones[C], zeros[C]) standing in for the gamma / beta of an affine=False BatchNorm where a kernel wants the pointers"""
+    key = (C, dev)
+    if key not in _unit:
+        _unit[key] = (torch.ones(C, dtype=torch.float32, device=dev), torch.zeros(C, dtype=torch.float32, device=dev))
+    return _unit[key]
+
+
+def sync_bn_active():
+    """True while parallel.set_sync_bn is on in a process group of more than one rank: the PC-DARTS layers then run their per-primitive
+    kernels (no fused edge, no fused conv + BatchNorm node), whose BatchNormFn pools the per-channel sums of all ranks."""
+    from . import parallel
+    return parallel.sync_bn_world() > 1
+
+
 class BatchNormFn(torch.autograd.Function):
-    """nn.BatchNorm2d: batch statistics + running update in train mode, running statistics in eval."""
+    """nn.BatchNorm2d: batch statistics + running update in train mode, running statistics in eval.  Under SyncBN (parallel.set_sync_bn,
+    more than one rank, train mode) the statistics -- and the two sums of the backward -- are those of the GLOBAL batch: the kernels of
+    the ResNet trunks' SyncBN (lctvqa_bn_wide_sums / _fwd_from_sums / _bwd_from_sums) with one all-reduce of [C][2] fp64 sums each way."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, run_mean, run_var, tracked, training, momentum, eps):
         x = _chk(x)
-        y, mean, invstd = _bn_forward(x, gamma, beta, run_mean, run_var, tracked, training, momentum, eps)
+        from . import parallel
+        world = parallel.sync_bn_world() if training else 1
+        C = x.shape[-1]
+        if world > 1 and C % 4 == 0:
+            P, dev = x.numel() // C, x.device
+            ones, zeros = _unit_affine(C, dev)
+            y = torch.empty_like(x)
+            stats = torch.empty((2, C), dtype=torch.float32, device=dev)
+            part = _scratch(lib.query('bn_wide_blocks', P) * C * 2, torch.float64, dev)
+            sums = torch.empty((C, 2), dtype=torch.float64, device=dev)
+            lib('bn_wide_sums', x, None, None, None, None, P, C, 0, part, sums)
+            parallel.sync_bn_all_reduce(sums)
+            lib('bn_wide_fwd_from_sums', x, sums, float(P * world), gamma if gamma is not None else ones, beta if beta is not None else zeros,
+                run_mean, run_var, tracked, None, 0, y, stats[0], stats[1], P, C, float(momentum), float(eps))
+            mean, invstd = stats[0], stats[1]
+        else:
+            world = 1
+            y, mean, invstd = _bn_forward(x, gamma, beta, run_mean, run_var, tracked, training, momentum, eps)
         ctx.save_for_backward(x, mean, invstd, gamma)
-        ctx.training = int(training)
+        ctx.training, ctx.world = int(training), world
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, mean, invstd, gamma = ctx.saved_tensors
-        dx, dg, db = _bn_backward(_chk(dy), x, mean, invstd, gamma, ctx.training)
+        dy = _chk(dy)
+        if ctx.world > 1:
+            from . import parallel
+            C = x.shape[-1]
+            P, dev = x.numel() // C, x.device
+            ones, _ = _unit_affine(C, dev)
+            dx = torch.empty_like(x)
+            dg = torch.empty(C, dtype=torch.float32, device=dev)
+            db = torch.empty(C, dtype=torch.float32, device=dev)
+            sums = _scratch(2 * C, torch.float32, dev)
+            part = _scratch(lib.query('bn_wide_blocks', P) * C * 2, torch.float64, dev)
+            loc = torch.empty((C, 2), dtype=torch.float64, device=dev)
+            lib('bn_wide_sums', x, dy, None, mean, invstd, P, C, 1, part, loc)
+            glob = loc.clone()
+            parallel.sync_bn_all_reduce(glob)
+            lib('bn_wide_bwd_from_sums', dy, None, x, mean, invstd, gamma if gamma is not None else ones, loc, glob, float(P * ctx.world), dx, None,
+                dg, db, sums, P, C)
+            return dx, (dg if gamma is not None else None), (db if gamma is not None else None), None, None, None, None, None, None
+        dx, dg, db = _bn_backward(dy, x, mean, invstd, gamma, ctx.training)
         return dx, dg, db, None, None, None, None, None, None
 
 
@@ -343,6 +398,12 @@ class AvgPool7FlattenFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------ fused MixedOp edge
 FUSED_EDGE = os.environ.get('LCTVQA_FUSED_EDGE', '1') != '0'     # A/B switch: 0 = one launch per primitive (the round-1 path)
+
+
+def fused_edge_active():
+    """The fused edge kernels are in use: the switch is on and SyncBN is not (their BatchNorm statistics are taken inside the kernels and
+    cannot leave for an all-reduce; under parallel.set_sync_bn with more than one rank the per-primitive kernels run instead)."""
+    return FUSED_EDGE and not sync_bn_active()
 
 
 def set_fused_edge(on):
@@ -675,18 +736,19 @@ def run_seq(seq, x):
     relu = False
     mods = list(seq)
     i = 0
+    fuse_bn = not sync_bn_active()            # SyncBN: the statistics leave the kernel for an all-reduce, so BatchNorm stays a node of its own
     while i < len(mods):
         m = mods[i]
         i += 1
         if isinstance(m, nn.ReLU):
             relu = True
-        elif (_is_depthwise(m) and i + 1 < len(mods) and _is_pointwise(mods[i]) and isinstance(mods[i + 1], nn.BatchNorm2d)
+        elif (fuse_bn and _is_depthwise(m) and i + 1 < len(mods) and _is_pointwise(mods[i]) and isinstance(mods[i + 1], nn.BatchNorm2d)
               and DwPwBnFn.supported(x, m.weight, mods[i].weight)):
             # (ReLU ->) depthwise -> 1x1 -> BN: one autograd node
             x = DwPwBnFn.apply(x, m.weight, mods[i].weight, *_bn_args(mods[i + 1]), m.stride[0], m.padding[0], m.dilation[0], relu)
             relu = False
             i += 2
-        elif isinstance(m, (nn.AvgPool2d, nn.MaxPool2d)) and i < len(mods) and isinstance(mods[i], nn.BatchNorm2d):
+        elif fuse_bn and isinstance(m, (nn.AvgPool2d, nn.MaxPool2d)) and i < len(mods) and isinstance(mods[i], nn.BatchNorm2d):
             stride = m.stride if isinstance(m.stride, int) else m.stride[0]
             x = PoolBnFn.apply(x, *_bn_args(mods[i]), stride, 1 if isinstance(m, nn.AvgPool2d) else 0)
             i += 1

@@ -172,6 +172,86 @@ def test_sync_bn_dp2_equals_the_single_process_batch(hip_lib, tmp_path, dtype):
         assert p.returncode == 0 and 'SYNCBN_OK' in so, (so[-2000:], se[-4000:])
 
 
+def test_sync_bn_dp2_pcdarts_search_network(hip_lib, tmp_path):
+    """SyncBN for the PC-DARTS search encoder (reference BatchNorms pcdarts/operations.py:29,43,58,62,98; model_search.py:111-113): under
+    parallel.set_sync_bn the network runs its per-primitive kernels (the fused edge kernels take their statistics inside and cannot
+    all-reduce them) and every BatchNorm pools the per-channel sums of the ranks.  Two ranks on half batches == one process (fused
+    edges, the default path) on the full batch: features 1e-4, running statistics 1e-4, rank-averaged gradients of every weight and of
+    alpha / beta within 2e-3 of their largest entry (a ReLU whose pre-activation differs in the last bits between the two summation orders
+    flips: the architects' parity notes).  Without SyncBN the halves do not reproduce the full batch."""
+    script = tmp_path / 'syncbn_darts.py'
+    script.write_text(textwrap.dedent('''
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        rank = int(os.environ['RANK'])
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=2)
+        from lct_vqa_amd import parallel, darts_ops
+        from lct_vqa_amd.basic_vqa import config
+        config.DEVICE = torch.device('cuda')
+        from lct_vqa_amd.basic_vqa.pcdarts.model_search import Network
+        from lct_vqa_amd._lib import lib
+        lib.load()
+        B, S = 8, 32
+        g = torch.Generator().manual_seed(7)
+        img = torch.randn(B, 3, S, S, generator=g).cuda()
+        w = torch.randn(B, 256 * 7 * 7, generator=g).cuda()
+        def run(m, x, wt, denom):
+            m.train()
+            for a in m.arch_parameters():
+                a.grad = None
+            y = m(x)
+            ((y * wt).sum() / denom).backward()
+            return y.detach()
+        torch.manual_seed(3)
+        ref = Network(16, 512, 3).cuda()
+        for a in ref.arch_parameters():
+            a.data.normal_(0, 0.5)
+        sd = {k: v.clone() for k, v in ref.state_dict().items()}
+        arch = [a.detach().clone() for a in ref.arch_parameters()]
+        parallel.set_sync_bn(False)
+        assert darts_ops.fused_edge_active()
+        y_full = run(ref, img, w, B)                                  # one process, whole batch, fused edges
+        def twin():
+            m = Network(16, 512, 3).cuda()
+            m.load_state_dict(sd)
+            for a, r in zip(m.arch_parameters(), arch):
+                a.data.copy_(r)
+            return m
+        m = twin()
+        parallel.set_sync_bn(True)
+        assert not darts_ops.fused_edge_active() and darts_ops.sync_bn_active()
+        lo, hi = rank * B // 2, (rank + 1) * B // 2
+        y = run(m, img[lo:hi], w[lo:hi], B // 2)
+        torch.cuda.synchronize()
+        def rel(a, b): return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+        assert rel(y, y_full[lo:hi]) < 1e-4, ('output', rel(y, y_full[lo:hi]))
+        for (n, b), (_, c) in zip(m.named_buffers(), ref.named_buffers()):
+            if 'running' in n:
+                assert rel(b, c) < 1e-4, (n, rel(b, c))
+            else:
+                assert int(b) == int(c), n
+        pairs = list(zip(m.named_parameters(), ref.named_parameters())) + [((f'arch{i}', a), (None, r)) for i, (a, r) in enumerate(zip(m.arch_parameters(), ref.arch_parameters()))]
+        for (n, p), (_, q) in pairs:
+            gavg = p.grad.clone()
+            dist.all_reduce(gavg)
+            gavg /= 2
+            assert rel(gavg, q.grad) < 2e-3, (n, rel(gavg, q.grad))
+        m2 = twin()
+        parallel.set_sync_bn(False)
+        y2 = run(m2, img[lo:hi], w[lo:hi], B // 2)
+        assert rel(y2, y_full[lo:hi]) > 1e-2                          # per-rank statistics: not the full batch
+        dist.barrier()
+        dist.destroy_process_group()
+        print('SYNCBN_DARTS_OK', rank)
+    ''' % (ROOT,)))
+    procs = [subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=_env(RANK=str(r), WORLD_SIZE='2', MASTER_PORT='29549')) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and 'SYNCBN_DARTS_OK' in so, (so[-2000:], se[-4000:])
+
+
 def test_trainable_bf16_resnet_under_dp_with_the_gradient_sink(hip_lib):
     """BASELINE configs[2] (ResNet-152 + GRU, bf16, encoder trainable, data parallel) rehearsed on two ranks sharing the one GPU: with
     ops.grad_sink the bottleneck nodes accumulate their parameter gradients into the optimizer arena themselves and return None, and
