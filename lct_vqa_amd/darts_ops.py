@@ -204,7 +204,9 @@ class BatchNormFn(torch.autograd.Function):
         from . import parallel
         world = parallel.sync_bn_world() if training else 1
         C = x.shape[-1]
-        if world > 1 and C % 4 == 0:
+        if world > 1:
+            if C % 4 != 0:
+                raise NotImplementedError(f'SyncBN of a BatchNorm2d({C}): the pooled-sum kernels take channel counts that are multiples of 4')
             P, dev = x.numel() // C, x.device
             ones, zeros = _unit_affine(C, dev)
             y = torch.empty_like(x)
@@ -217,7 +219,6 @@ class BatchNormFn(torch.autograd.Function):
                 run_mean, run_var, tracked, None, 0, y, stats[0], stats[1], P, C, float(momentum), float(eps))
             mean, invstd = stats[0], stats[1]
         else:
-            world = 1
             y, mean, invstd = _bn_forward(x, gamma, beta, run_mean, run_var, tracked, training, momentum, eps)
         ctx.save_for_backward(x, mean, invstd, gamma)
         ctx.training, ctx.world = int(training), world
